@@ -1,0 +1,101 @@
+"""Input builders shared by tools/make_golden.py (which feeds them to the reference) and the tests
+(which feed them to the oracle and to the HIP path).  Built only from the portable generators of
+``retinanet_mi355x.synth``, so fixtures hold outputs only."""
+import numpy as np
+import torch
+
+from retinanet_mi355x import synth
+
+LOSS_HW = (96, 128)          # A = 2313
+POST_HW = (256, 320)         # A = 15354 > 10000: the adaptive-threshold loops iterate
+MODEL_HW = (72, 104)         # odd pyramid sizes: both FPN crop fall-backs are taken (D/model.py:92-108)
+
+
+def level_counts(height, width):
+    return [9 * ((height + 2 ** l - 1) // 2 ** l) * ((width + 2 ** l - 1) // 2 ** l) for l in (3, 4, 5, 6, 7)]
+
+
+def num_anchors(height, width):
+    return sum(level_counts(height, width))
+
+
+def loss_labels_dir():
+    """5 images: normal / ragged / no labels / duplicate+outside+degenerate / labels but no positives."""
+    H, W = LOSS_HW
+    ann = synth.labels_dir(5, 6, H, W, num_classes=4, seed=11, size_px=(28, 70))
+    ann[1, 3:] = -1
+    ann[2] = -1
+    ann[3, 1] = ann[3, 0]
+    ann[3, 1, 20] = (ann[3, 0, 20] + 1) % 4            # same box, other class: tie -> lowest index wins
+    ann[3, 2, 0:20:2] += 400.0                         # fully outside the image
+    ann[3, 3, :20] = 50.0                              # degenerate zero-size box
+    ann[4] = synth.labels_dir(1, 6, H, W, num_classes=4, seed=12, size_px=(3, 6))[0]
+    return ann
+
+
+def loss_labels_2d():
+    H, W = LOSS_HW
+    ann = synth.labels_2d(5, 6, H, W, num_classes=4, seed=13, size_px=(28, 70))
+    ann[1, 3:] = -1
+    ann[2] = -1
+    ann[3, 1] = ann[3, 0]
+    ann[3, 1, 4] = (ann[3, 0, 4] + 1) % 4
+    ann[3, 2, 0:4:2] += 400.0
+    ann[3, 3, 2:4] = ann[3, 3, 0:2] + 0.25             # w,h < 1 -> clamp(min=1) path (R/losses.py:143-144)
+    ann[4] = synth.labels_2d(1, 6, H, W, num_classes=4, seed=14, size_px=(3, 6))[0]
+    return ann
+
+
+def loss_heads(n_reg, seed):
+    """cls = u^6 (reaches below 1e-4 and close to 1: both clamp edges), reg ~ N(0, 0.3)."""
+    A = num_anchors(*LOSS_HW)
+    cls = synth.scores_portable(5, A, 4, seed, power=6)
+    reg = torch.from_numpy(synth.normal((5, A, n_reg), seed + 1, 0.3))
+    return cls, reg
+
+
+def post_reg_dir(batch, seed):
+    """Regression whose 2D-box part (cols 8:12) decodes to a jittered copy of the anchor, so NMS has overlaps."""
+    A = num_anchors(*POST_HW)
+    reg = synth.normal((batch, A, 12), seed, 0.4)
+    jit = synth.normal((batch, A, 4), seed + 1, 0.12)
+    reg[:, :, 8:12] = jit + np.array([-0.5, -0.5, 0.5, 0.5], dtype=np.float32)
+    return torch.from_numpy(reg)
+
+
+def post_single_inputs():
+    A = num_anchors(*POST_HW)
+    return synth.scores_portable(1, A, 2, 41, power=3), post_reg_dir(1, 42)
+
+
+def post_multi_inputs():
+    A = num_anchors(*POST_HW)
+    return synth.scores_portable(3, A, 3, 43, power=6), post_reg_dir(3, 44)
+
+
+def post_2d_inputs():
+    A = num_anchors(*POST_HW)
+    return synth.scores_portable(1, A, 3, 45, power=6), torch.from_numpy(synth.normal((1, A, 4), 46, 1.0))
+
+
+def model_inputs(arch, directional=True):
+    H, W = MODEL_HW
+    B = 2 if arch == "resnet18" else 1
+    sd = synth.state_dict(arch, num_classes=4, n_reg=12 if directional else 4, seed=7, head_scale=3e-4)
+    img = synth.frames(B, H, W, seed=8)
+    if directional:
+        ann = synth.labels_dir(B, 5, H, W, num_classes=4, seed=9, size_px=(24, 60))
+        ann[0, 4] = -1
+    else:
+        ann = synth.labels_2d(B, 5, H, W, num_classes=4, seed=9, size_px=(24, 60))
+        ann[0, 4] = -1
+    return sd, img, ann
+
+
+def homography_inputs():
+    Ps, Hs = synth.camera_matrices(18, seed=5)
+    Ps2, Hs2 = synth.camera_matrices(18, seed=55)
+    names = ["p%dc%d" % (p, c) for p in (1, 2, 3) for c in range(1, 7)]
+    state = synth.vehicle_states(90, seed=6)
+    cam_index = np.arange(90) % 18
+    return names, state, cam_index, (Ps, Hs), (Ps2, Hs2)

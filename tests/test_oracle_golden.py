@@ -1,0 +1,213 @@
+"""CPU: pin the oracle (oracle/) to the golden vectors the REFERENCE produced (tools/make_golden.py).
+
+Integer results (assignment indices, kept indices, class ids, image ids) must match bit for bit;
+fp32 values to the tolerance written at each assert.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import anchors as oanchors
+from oracle import boxes as oboxes
+from oracle import homography as ohg
+from oracle import losses as olosses
+from oracle import model as omodel
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------ anchors: bit-exact fp32
+@pytest.mark.parametrize("hw", [(64, 96), (72, 104), (112, 112), (96, 128), (512, 512)])
+def test_anchors_full(golden, hw):
+    g = golden("anchors")["full_%dx%d" % hw]
+    a = oanchors.anchors_for_image(*hw)
+    assert a.dtype == np.float32 and a.shape == g.shape
+    assert np.array_equal(a, g)
+
+
+@pytest.mark.parametrize("hw", [(540, 960), (1080, 1920), (1081, 1917)])
+def test_anchors_large_checksum(golden, hw):
+    z = golden("anchors")
+    a = oanchors.anchors_for_image(*hw)
+    assert a.shape[1] == int(z["count_%dx%d" % hw]) == oanchors.num_anchors(*hw)
+    assert sha(a) == str(z["sha_%dx%d" % hw])
+    assert np.array_equal(a[0, ::997], z["sample_%dx%d" % hw])
+
+
+def test_anchor_count_1080p():
+    assert oanchors.num_anchors(1080, 1920) == 389205
+
+
+# ------------------------------------------------------------------ IoU / assignment: bit-exact
+def test_assignment_bit_exact(golden):
+    z = golden("losses")
+    ann = gc.loss_labels_dir()
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.LOSS_HW))[0]
+    for j in (0, 1, 3, 4):
+        lab = ann[j][ann[j, :, 20] != -1]
+        iou_max, arg, state = olosses.assign(anc, olosses.envelope_boxes(lab[:, :16]))
+        assert np.array_equal(iou_max.numpy(), z["dir_iou_max_%d" % j])      # fp32 bit-exact on CPU
+        assert np.array_equal(arg.numpy(), z["dir_iou_arg_%d" % j])
+    # duplicate GT rows 0 and 1 of image 3: the tie must resolve to the lower index
+    arg3 = z["dir_iou_arg_3"]
+    assert (arg3 == 1).sum() == 0 and (arg3 == 0).sum() > 0
+
+
+# ------------------------------------------------------------------ losses
+def test_focal_loss_dir(golden):
+    z = golden("losses")
+    ann = gc.loss_labels_dir()
+    cls, reg = gc.loss_heads(12, 21)
+    cls.requires_grad_(True)
+    reg.requires_grad_(True)
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.LOSS_HW))
+    l = olosses.focal_loss_dir(cls, reg, anc, ann)
+    got = np.array([float(x) for x in l])
+    assert np.allclose(got, z["dir_losses"], rtol=1e-5, atol=1e-6)
+    (l[0] + 2.0 * l[1] + 3.0 * l[2]).sum().backward()
+    assert np.allclose(cls.grad.numpy(), z["dir_dcls"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(reg.grad.numpy(), z["dir_dreg"], rtol=1e-4, atol=1e-7)
+    for j in (0, 1, 3, 4):
+        lj = olosses.focal_loss_dir(cls[j:j + 1].detach(), reg[j:j + 1].detach(), anc, ann[j:j + 1])
+        assert np.allclose([float(x) for x in lj], z["dir_losses_img%d" % j], rtol=1e-5, atol=1e-6)
+
+
+def test_focal_loss_dir_all_empty_raises():
+    """An all-empty batch makes the reference stack an empty vp list (D/losses.py:362) -> RuntimeError."""
+    cls, reg = gc.loss_heads(12, 21)
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.LOSS_HW))
+    ann = -torch.ones(2, 3, 27)
+    with pytest.raises(RuntimeError):
+        olosses.focal_loss_dir(cls[:2], reg[:2], anc, ann)
+
+
+def test_focal_loss_2d(golden):
+    z = golden("losses")
+    ann = gc.loss_labels_2d()
+    cls, reg = gc.loss_heads(4, 31)
+    cls.requires_grad_(True)
+    reg.requires_grad_(True)
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.LOSS_HW))
+    l = olosses.focal_loss_2d(cls, reg, anc, ann)
+    assert np.allclose([float(x) for x in l], z["2d_losses"], rtol=1e-5, atol=1e-6)
+    (l[0] + 2.0 * l[1]).sum().backward()
+    assert np.allclose(cls.grad.numpy(), z["2d_dcls"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(reg.grad.numpy(), z["2d_dreg"], rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------ decode + post-process
+def test_decode_dir_and_single(golden):
+    z = golden("boxes")
+    cls, reg = gc.post_single_inputs()
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.POST_HW))
+    boxes = oboxes.decode_dir(anc, reg)
+    assert sha(boxes.numpy()) == str(z["dir_decode_sha"])                    # same torch CPU ops: bit-exact
+    assert np.array_equal(boxes.numpy()[0, ::53], z["dir_decode_sample"])
+    s, c, b = oboxes.postprocess_single(cls, boxes)
+    assert np.array_equal(s.numpy(), z["dir_single_scores"])
+    assert np.array_equal(c.numpy(), z["dir_single_classes"])
+    assert sha(b.numpy()) == str(z["dir_single_boxes_sha"])
+
+
+def test_postprocess_multi(golden):
+    z = golden("boxes")
+    cls, reg = gc.post_multi_inputs()
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.POST_HW))
+    s, c, b, im = oboxes.postprocess_multi(cls, oboxes.decode_dir(anc, reg))
+    assert len(z["dir_multi_scores"]) > 1000
+    assert np.array_equal(s.numpy(), z["dir_multi_scores"])
+    assert np.array_equal(c.numpy(), z["dir_multi_classes"])
+    assert np.array_equal(im.numpy(), z["dir_multi_im"])
+    assert sha(b.numpy()) == str(z["dir_multi_boxes_sha"])
+
+
+def test_postprocess_2d(golden):
+    z = golden("boxes")
+    cls, reg = gc.post_2d_inputs()
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.POST_HW))
+    boxes = oboxes.clip_boxes(oboxes.decode_2d(anc, reg), *gc.POST_HW)
+    assert np.allclose(boxes.numpy()[0, ::7], z["2d_decode_clip_sample"], rtol=1e-6, atol=1e-4)
+    s, c, b = oboxes.postprocess_2d(cls, boxes)
+    assert np.array_equal(s.numpy(), z["2d_scores"])
+    assert np.array_equal(c.numpy(), z["2d_classes"])
+    assert np.allclose(b.numpy()[::8], z["2d_boxes_sample"], rtol=1e-6, atol=1e-4)
+
+
+def test_adaptive_threshold_can_return_nothing():
+    """Reference quirk: the 10^0.2 grid jumps 0.631 -> 1.0, so >10000 scores above 0.631 leave no survivor."""
+    s = torch.full((12000,), 0.9)
+    assert int(oboxes.adaptive_threshold(s, 1e-7).sum()) == 0
+
+
+# ------------------------------------------------------------------ whole model (torch CPU kernels underneath)
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_model_dir(golden, arch):
+    z = golden("model")
+    sd, img, ann = gc.model_inputs(arch, True)
+    params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    l = omodel.train_forward(img, ann, params, arch)
+    assert np.allclose([float(x) for x in l], z["%s_dir_losses" % arch], rtol=2e-5)
+    (l[0] + l[1] + l[2]).sum().backward()
+    for k, p in params.items():
+        key = "%s_dir_gsum_%s" % (arch, k)
+        if key not in z.files:
+            continue
+        g = p.grad.numpy().astype(np.float64)
+        ref = z[key]
+        assert abs(np.sqrt((g ** 2).sum()) - ref[2]) <= 1e-4 * ref[2] + 1e-9, k
+        full = "%s_dir_g_%s" % (arch, k)
+        if full in z.files:
+            assert np.allclose(p.grad.numpy(), z[full], rtol=1e-3, atol=1e-5 * np.abs(z[full]).max()), k
+    with torch.no_grad():
+        boxes, cls = omodel.eval_forward(img, sd, arch, LOCALIZE=True)
+    assert np.allclose(boxes.numpy(), z["%s_dir_boxes" % arch], rtol=1e-5, atol=1e-3)
+    assert np.allclose(cls.numpy(), z["%s_dir_cls" % arch], rtol=1e-5, atol=1e-7)
+
+
+def test_model_2d(golden):
+    z = golden("model")
+    sd, img, ann = gc.model_inputs("resnet18", False)
+    with torch.no_grad():
+        l = omodel.train_forward(img, ann, sd, "resnet18")
+        boxes, cls = omodel.eval_forward(img, sd, "resnet18", LOCALIZE=True)
+    assert np.allclose([float(x) for x in l], z["resnet18_2d_losses"], rtol=2e-5)
+    assert np.allclose(boxes.numpy(), z["resnet18_2d_boxes"], rtol=1e-5, atol=1e-3)
+    assert np.allclose(cls.numpy(), z["resnet18_2d_cls"], rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ homography
+def test_homography_golden(golden):
+    z = golden("homography")
+    names, state, cam, (P, H), (P2, H2) = gc.homography_inputs()
+    assert np.allclose(P, z["P"], rtol=0, atol=1e-12) and np.allclose(H, z["H"], rtol=1e-12)
+    P, H, P2, H2 = z["P"], z["H"], z["P2"], z["H2"]
+    st = state.numpy()
+    space = ohg.state_to_space(st)
+    assert np.array_equal(space, z["space"])
+    assert np.array_equal(ohg.space_to_state(space), z["space_to_state"])
+    im_list = ohg.state_to_im(st, P[cam])
+    assert im_list.dtype == np.float64
+    assert np.allclose(im_list, z["im_list"], rtol=1e-12, atol=1e-9)
+    assert np.allclose(ohg.state_to_im(st, P[2]), z["im_one"], rtol=1e-12, atol=1e-9)
+    assert np.allclose(ohg.state_to_im(st, P[0]), z["im_default"], rtol=1e-12, atol=1e-9)
+    h = st[:, 4]
+    assert np.allclose(ohg.im_to_space(z["im_list"], H[cam], h), z["back_space_list"], rtol=1e-10, atol=1e-8)
+    back = ohg.im_to_state(z["im_list"], H[cam], h)
+    assert back.dtype == np.float32
+    assert np.allclose(back, z["back_state_list"], rtol=1e-6, atol=1e-5)
+    assert np.allclose(ohg.im_to_state(z["im_one"], H[2], h), z["back_state_one"], rtol=1e-6, atol=1e-5)
+    assert np.allclose(back, st, atol=2e-3)                                  # round trip
+    assert np.array_equal(ohg.guess_heights(["sedan", "semi", 3, "nonsense", "trailer", "truck (other)"]),
+                          z["guess_heights"])
+    assert np.allclose(ohg.height_from_template(z["im_list"], h, z["im_list"] * 1.07 + 3.0),
+                       z["height_from_template"], rtol=1e-6)
+    wr = ohg.wrapper_space_to_im(space, P[cam], P2[cam])
+    assert np.allclose(wr, z["wr_im_list"], rtol=1e-12, atol=1e-9)
+    assert np.allclose(ohg.wrapper_space_to_im(space, P[9], P2[9]), z["wr_im_one"], rtol=1e-12, atol=1e-9)
+    wr_back = ohg.space_to_state(ohg.wrapper_im_to_space(z["wr_im_list"], H[cam], H2[cam], h))
+    assert np.allclose(wr_back, z["wr_back_state_list"], rtol=1e-6, atol=1e-5)
