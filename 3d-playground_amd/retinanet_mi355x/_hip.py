@@ -1,0 +1,89 @@
+"""ctypes binding of libretinanet_mi355x.so (include/retinanet_mi355x.h).
+
+The library is built in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``).  There is no fallback: if the
+shared object is missing or a tensor is not on a HIP device every op raises -- the product path never runs on
+the CPU and never touches ``oracle/``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libretinanet_mi355x.so")
+_lib = None
+
+c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes); one entry per symbol declared in include/retinanet_mi355x.h
+SIGNATURES = {
+    "rn_version": (ctypes.c_char_p, []),
+    "rn_check_device": (c_i32, []),
+    "rn_anchor_count": (c_i64, [c_i32, c_i32]),
+    "rn_anchor_base_boxes": (None, [c_vp]),
+    "rn_anchors_fwd": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "rn_pairwise_iou": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "rn_focal_workspace_bytes": (c_i64, [c_i32, c_i64]),
+    "rn_focal_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "rn_focal_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rn_assign": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rn_decode_dir": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp]),
+    "rn_decode_2d": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp]),
+    "rn_clip_boxes": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp]),
+    "rn_post_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "rn_rowmax": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "rn_threshold_select": (c_i32, [c_vp, c_i64, c_i64, c_f64, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    "rn_nms": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "rn_state_to_space": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_space_to_state": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_state_to_im": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rn_space_to_im": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rn_im_to_space": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rn_im_to_state": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+}
+
+RN_ERRORS = {10001: "RN_EINVAL (bad size / unsupported shape)",
+             10002: "RN_ETOOMANY (more than RN_MAX_GT=256 label rows per image)"}
+
+
+def load():
+    """Load the shared library once and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libretinanet_mi355x.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C 3d-playground_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, RN_ERRORS.get(rc, "hipError_t %d" % rc)))
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("retinanet_mi355x ops run on an MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32c(t):
+    """Contiguous fp32 view/copy of a tensor (plumbing: layout only)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

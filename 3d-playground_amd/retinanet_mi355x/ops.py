@@ -1,0 +1,341 @@
+"""Functional layer over the C ABI: device tensors in, device tensors out.
+
+Each function mirrors one piece of the reference's Python surface (file:line in the docstrings) and calls one
+or a few entry points of ``libretinanet_mi355x.so`` on the current HIP stream.  torch supplies device memory,
+streams and autograd bookkeeping only.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+
+NMS_MAX = 16384
+KEEP = 10000                  # D/model.py:368
+
+
+# ------------------------------------------------------------------------------------------------ anchors
+def anchors(height, width, device):
+    """[1,A,4] fp32 anchors of an H x W image (Anchors.forward, D/anchors.py:21-40)."""
+    lib = _hip.load()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("anchors are generated on the MI355X (no CPU fallback); got device %s" % device)
+    n = lib.rn_anchor_count(int(height), int(width))
+    out = torch.empty((1, n, 4), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _hip.check(lib.rn_anchors_fwd(out.data_ptr(), int(height), int(width), _hip.stream()), "rn_anchors_fwd")
+    return out
+
+
+def anchor_count(height, width):
+    return int(_hip.load().rn_anchor_count(int(height), int(width)))
+
+
+def pairwise_iou(a, b):
+    """calc_iou (D/losses.py:5-22): [A,4] x [N,4] -> [A,N]."""
+    lib = _hip.load()
+    _hip.need_gpu(a, b)
+    a, b = _hip.f32c(a), _hip.f32c(b)
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if out.numel():
+        with torch.cuda.device(a.device):
+            _hip.check(lib.rn_pairwise_iou(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], b.shape[0],
+                                           _hip.stream()), "rn_pairwise_iou")
+    return out
+
+
+def assign(anchor_boxes, ann, directional=True):
+    """(iou_max [B,A] f32, argmax [B,A] i32 among valid rows, state [B,A] i32 in {-1,0,1}) -- D/losses.py:109-124."""
+    lib = _hip.load()
+    _hip.need_gpu(anchor_boxes, ann)
+    anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
+    ann = _hip.f32c(ann)
+    B, N = ann.shape[0], ann.shape[1]
+    A = anc.shape[0]
+    iou = torch.empty((B, A), dtype=torch.float32, device=anc.device)
+    arg = torch.empty((B, A), dtype=torch.int32, device=anc.device)
+    st = torch.empty((B, A), dtype=torch.int32, device=anc.device)
+    with torch.cuda.device(anc.device):
+        _hip.check(lib.rn_assign(anc.data_ptr(), ann.data_ptr(), B, A, N, int(directional), iou.data_ptr(),
+                                 arg.data_ptr(), st.data_ptr(), _hip.stream()), "rn_assign")
+    return iou, arg, st
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _FocalLossFn(torch.autograd.Function):
+    """FocalLoss.forward (D/losses.py:27-362 / R/losses.py:27-177) with a hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, cls, reg, anchor_boxes, ann, directional):
+        lib = _hip.load()
+        _hip.need_gpu(cls, reg, anchor_boxes, ann)
+        cls_c, reg_c = _hip.f32c(cls), _hip.f32c(reg)
+        anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
+        ann_c = _hip.f32c(ann)
+        B, A, C = cls_c.shape
+        N = ann_c.shape[1]
+        n_reg, cols = (12, 27) if directional else (4, 5)
+        if reg_c.shape != (B, A, n_reg) or anc.shape[0] != A or ann_c.shape[2] != cols or ann_c.shape[0] != B:
+            raise RuntimeError("focal loss: shapes cls %s reg %s anchors %s ann %s do not fit the %s variant"
+                               % (tuple(cls.shape), tuple(reg.shape), tuple(anchor_boxes.shape), tuple(ann.shape),
+                                  "directional" if directional else "2D"))
+        ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=cls_c.device)
+        losses = torch.empty(3, dtype=torch.float32, device=cls_c.device)
+        with torch.cuda.device(cls_c.device):
+            _hip.check(lib.rn_focal_loss_fwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),
+                                             B, A, C, N, int(directional), ws.data_ptr(), losses.data_ptr(),
+                                             _hip.stream()), "rn_focal_loss_fwd")
+        ctx.save_for_backward(cls_c, reg_c, anc, ann_c, ws)
+        ctx.directional = directional
+        return losses[0:1], losses[1:2], losses[2:3]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, g_vp):
+        lib = _hip.load()
+        cls_c, reg_c, anc, ann_c, ws = ctx.saved_tensors
+        B, A, C = cls_c.shape
+        g = torch.cat([t.reshape(1).float() if t is not None else torch.zeros(1, device=cls_c.device)
+                       for t in (g_cls, g_reg, g_vp)])
+        dcls = torch.empty_like(cls_c)
+        dreg = torch.empty_like(reg_c)
+        with torch.cuda.device(cls_c.device):
+            _hip.check(lib.rn_focal_loss_bwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),
+                                             B, A, C, ann_c.shape[1], int(ctx.directional), ws.data_ptr(),
+                                             g.data_ptr(), dcls.data_ptr(), dreg.data_ptr(), _hip.stream()),
+                       "rn_focal_loss_bwd")
+        return dcls, dreg, None, None, None
+
+
+def _check_labels(ann, directional):
+    """The reference stacks an empty list when no image of the batch has a label (D/losses.py:362) and raises;
+    keep that contract (one tiny D2H read of the label classes)."""
+    col = 20 if directional else 4
+    if directional and ann.shape[1] > 0 and not bool((ann[:, :, col] != -1).any()):
+        raise RuntimeError("stack expects a non-empty TensorList (no image in the batch has a label; "
+                           "the reference's FocalLoss raises here, D/losses.py:362)")
+    if directional and ann.shape[1] == 0:
+        raise RuntimeError("stack expects a non-empty TensorList (no labels in the batch)")
+
+
+def focal_loss(cls, reg, anchor_boxes, ann, directional=True, check_labels=True):
+    """-> (cls_loss[1], reg_loss[1], vp_loss[1]) directional, (cls_loss[1], reg_loss[1]) 2D."""
+    if check_labels:
+        _check_labels(ann, directional)
+    out = _FocalLossFn.apply(cls, reg, anchor_boxes, ann, bool(directional))
+    return out if directional else out[:2]
+
+
+# ------------------------------------------------------------------------------------------------ decode
+def decode_dir(anchor_boxes, reg):
+    """BBoxTransform.forward, directional (D/utils.py:102-149): [1,A,4],[B,A,12] -> [B,A,20]."""
+    lib = _hip.load()
+    _hip.need_gpu(anchor_boxes, reg)
+    anc, reg_c = _hip.f32c(anchor_boxes.reshape(-1, 4)), _hip.f32c(reg)
+    B, A, _ = reg_c.shape
+    out = torch.empty((B, A, 20), dtype=torch.float32, device=reg_c.device)
+    with torch.cuda.device(reg_c.device):
+        _hip.check(lib.rn_decode_dir(anc.data_ptr(), reg_c.data_ptr(), out.data_ptr(), B, A, _hip.stream()), "rn_decode_dir")
+    return out
+
+
+def decode_2d(anchor_boxes, deltas, clip_hw=None):
+    """BBoxTransform.forward, 2D (R/utils.py:102-126), optionally with ClipBoxes fused (R/utils.py:134-144)."""
+    lib = _hip.load()
+    _hip.need_gpu(anchor_boxes, deltas)
+    anc, d = _hip.f32c(anchor_boxes.reshape(-1, 4)), _hip.f32c(deltas)
+    B, A, _ = d.shape
+    out = torch.empty((B, A, 4), dtype=torch.float32, device=d.device)
+    h, w = clip_hw if clip_hw is not None else (0.0, 0.0)
+    with torch.cuda.device(d.device):
+        _hip.check(lib.rn_decode_2d(anc.data_ptr(), d.data_ptr(), out.data_ptr(), B, A, int(clip_hw is not None),
+                                    float(w), float(h), _hip.stream()), "rn_decode_2d")
+    return out
+
+
+def clip_boxes_(boxes, height, width):
+    """ClipBoxes.forward (R/utils.py:134-144): in place on a contiguous [..,4] fp32 tensor; returns it."""
+    lib = _hip.load()
+    _hip.need_gpu(boxes)
+    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or boxes.shape[-1] != 4:
+        raise RuntimeError("clip_boxes_ needs a contiguous fp32 [...,4] tensor")
+    if boxes.numel():
+        with torch.cuda.device(boxes.device):
+            _hip.check(lib.rn_clip_boxes(boxes.data_ptr(), boxes.numel() // 4, float(width), float(height),
+                                         _hip.stream()), "rn_clip_boxes")
+    return boxes
+
+
+# ------------------------------------------------------------------------------------------------ post-process
+class _PostBuffers:
+    """Device scratch for C independent select+NMS problems, so one host sync reads every count."""
+
+    def __init__(self, n_scores, n_problems, max_sel, device):
+        lib = _hip.load()
+        self.ws = torch.empty(lib.rn_post_workspace_bytes(n_scores, NMS_MAX), dtype=torch.uint8, device=device)
+        self.count = torch.zeros((n_problems, 2), dtype=torch.int32, device=device)      # [:,0] selected, [:,1] kept
+        self.sel = torch.empty((n_problems, max_sel), dtype=torch.int32, device=device)
+        self.keep = torch.empty((n_problems, NMS_MAX), dtype=torch.int32, device=device)
+
+
+def _select(lib, scores_ptr, n, stride, start, fixed, buf, p):
+    _hip.check(lib.rn_threshold_select(scores_ptr, n, stride, float(start), KEEP, float(fixed), buf.ws.data_ptr(),
+                                       buf.count[p, 0:1].data_ptr(), buf.sel[p].data_ptr(), _hip.stream()),
+               "rn_threshold_select")
+
+
+def _nms(lib, boxes, box_col, scores_ptr, score_stride, category, buf, p, max_cand):
+    _hip.check(lib.rn_nms(boxes.data_ptr(), boxes.shape[-1], box_col, scores_ptr, score_stride, buf.sel[p].data_ptr(),
+                          _hip.ptr(category), buf.count[p, 0:1].data_ptr(), max_cand, 0.5, buf.ws.data_ptr(),
+                          buf.keep[p].data_ptr(), buf.count[p, 1:2].data_ptr(), _hip.stream()), "rn_nms")
+
+
+def postprocess_single(cls, boxes20):
+    """Single-frame eval branch (D/model.py:346-397): per class, adaptive threshold from 1e-25 until <= 10 000
+    survive, NMS(0.5) on cols 16:20.  cls [1,A,C], boxes [1,A,20] -> [scores[K], class_idx[K] i64, boxes[K,20]]."""
+    lib = _hip.load()
+    _hip.need_gpu(cls, boxes20)
+    if cls.shape[0] != 1:
+        raise RuntimeError("single-frame post-process assumes batch 1 (D/model.py:366 squeezes the batch away); "
+                           "use MULTI_FRAME=True for batches")
+    cls, boxes20 = _hip.f32c(cls), _hip.f32c(boxes20)
+    A, C = cls.shape[1], cls.shape[2]
+    buf = _PostBuffers(A, C, KEEP, cls.device)
+    with torch.cuda.device(cls.device):
+        for c in range(C):
+            sp = cls.data_ptr() + 4 * c
+            _select(lib, sp, A, C, 1e-25, -1.0, buf, c)
+            _nms(lib, boxes20, 16, sp, C, None, buf, c, KEEP)
+    counts = buf.count.cpu().numpy()
+    out_s, out_c, out_b = [], [], []
+    for c in range(C):
+        if counts[c, 0] == 0:
+            continue                                                       # D/model.py:376-378
+        idx = buf.sel[c].long()[buf.keep[c, :counts[c, 1]].long()]
+        out_s.append(cls[0, idx, c])
+        out_c.append(torch.full((idx.numel(),), c, dtype=torch.int64, device=cls.device))
+        out_b.append(boxes20[0, idx])
+    if not out_s:
+        e = torch.zeros(0, device=cls.device)
+        return [e, torch.zeros(0, dtype=torch.int64, device=cls.device), e.clone()]
+    return [torch.cat(out_s), torch.cat(out_c), torch.cat(out_b)]
+
+
+def postprocess_multi(cls, boxes20):
+    """MULTI_FRAME eval branch (D/model.py:311-344): flatten B*A, max over classes, adaptive threshold from 1e-7,
+    batched NMS keyed by image.  -> (scores[K], classes[K] i64, boxes[K,20], im_index[K] i64)."""
+    lib = _hip.load()
+    _hip.need_gpu(cls, boxes20)
+    cls, boxes20 = _hip.f32c(cls), _hip.f32c(boxes20)
+    B, A, C = cls.shape
+    n = B * A
+    dev = cls.device
+    scores = torch.empty(n, dtype=torch.float32, device=dev)
+    classes = torch.empty(n, dtype=torch.int64, device=dev)
+    buf = _PostBuffers(n, 1, KEEP, dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.rn_rowmax(cls.data_ptr(), n, C, scores.data_ptr(), classes.data_ptr(), _hip.stream()), "rn_rowmax")
+        _select(lib, scores.data_ptr(), n, 1, 1e-7, -1.0, buf, 0)
+        # image index of each candidate = flat index // A   (D/model.py:314-316)
+        cat = torch.div(buf.sel[0], A, rounding_mode="floor").to(torch.int32)
+        _nms(lib, boxes20.reshape(n, 20), 16, scores.data_ptr(), 1, cat, buf, 0, KEEP)
+    counts = buf.count.cpu().numpy()
+    idx = buf.sel[0].long()[buf.keep[0, :counts[0, 1]].long()]
+    return scores[idx], classes[idx], boxes20.reshape(n, 20)[idx], torch.div(idx, A, rounding_mode="floor")
+
+
+def postprocess_2d(cls, boxes4):
+    """2D eval branch (R/model.py:283-311): per class score > 0.05, NMS(0.5)."""
+    lib = _hip.load()
+    _hip.need_gpu(cls, boxes4)
+    if cls.shape[0] != 1:
+        raise RuntimeError("the 2D post-process assumes batch 1 (R/model.py:288 squeezes the batch away)")
+    cls, boxes4 = _hip.f32c(cls), _hip.f32c(boxes4)
+    A, C = cls.shape[1], cls.shape[2]
+    buf = _PostBuffers(A, C, A, cls.device)
+    with torch.cuda.device(cls.device):
+        for c in range(C):
+            sp = cls.data_ptr() + 4 * c
+            _select(lib, sp, A, C, 0.0, 0.05, buf, c)
+        counts = buf.count.cpu().numpy()
+        if counts[:, 0].max() > NMS_MAX:
+            raise RuntimeError("more than %d boxes above 0.05 in one class (%d): the on-device NMS orders its "
+                               "candidates in LDS and does not take more" % (NMS_MAX, counts[:, 0].max()))
+        for c in range(C):
+            if counts[c, 0]:
+                _nms(lib, boxes4, 0, cls.data_ptr() + 4 * c, C, None, buf, c, NMS_MAX)
+    counts = buf.count.cpu().numpy()
+    out_s, out_c, out_b = [], [], []
+    for c in range(C):
+        if counts[c, 0] == 0:
+            continue
+        idx = buf.sel[c].long()[buf.keep[c, :counts[c, 1]].long()]
+        out_s.append(cls[0, idx, c])
+        out_c.append(torch.full((idx.numel(),), c, dtype=torch.int64, device=cls.device))
+        out_b.append(boxes4[0, idx])
+    if not out_s:
+        e = torch.zeros(0, device=cls.device)
+        return [e, torch.zeros(0, dtype=torch.int64, device=cls.device), e.clone()]
+    return [torch.cat(out_s), torch.cat(out_c), torch.cat(out_b)]
+
+
+# ------------------------------------------------------------------------------------------------ homography
+def _mats(m, device):
+    if m is None:
+        return None
+    return torch.as_tensor(np.ascontiguousarray(m, dtype=np.float64)).to(device)
+
+
+def hg_state_to_space(state):
+    lib = _hip.load()
+    _hip.need_gpu(state)
+    s = _hip.f32c(state)
+    out = torch.empty((s.shape[0], 8, 3), dtype=torch.float32, device=s.device)
+    if s.shape[0]:
+        with torch.cuda.device(s.device):
+            _hip.check(lib.rn_state_to_space(s.data_ptr(), out.data_ptr(), s.shape[0], _hip.stream()), "rn_state_to_space")
+    return out
+
+
+def hg_space_to_state(space):
+    lib = _hip.load()
+    _hip.need_gpu(space)
+    sp = space.double().contiguous()
+    out = torch.empty((sp.shape[0], 6), dtype=torch.float32, device=sp.device)
+    if sp.shape[0]:
+        with torch.cuda.device(sp.device):
+            _hip.check(lib.rn_space_to_state(sp.data_ptr(), out.data_ptr(), sp.shape[0], _hip.stream()), "rn_space_to_state")
+    return out
+
+
+def hg_to_im(points, P, P2=None, mat_index=None, from_state=True):
+    """state [d,6] (from_state) or space [d,8,3] fp32 -> image [d,8,2] fp64.  P: device fp64 [n,3,4]."""
+    lib = _hip.load()
+    _hip.need_gpu(points, P, P2, mat_index)
+    p = _hip.f32c(points)
+    d = p.shape[0]
+    out = torch.empty((d, 8, 2), dtype=torch.float64, device=p.device)
+    if d:
+        fn = lib.rn_state_to_im if from_state else lib.rn_space_to_im
+        with torch.cuda.device(p.device):
+            _hip.check(fn(p.data_ptr(), P.data_ptr(), _hip.ptr(P2), _hip.ptr(mat_index), out.data_ptr(), d,
+                          _hip.stream()), "rn_state_to_im")
+    return out
+
+
+def hg_from_im(im, heights, H, H2=None, mat_index=None, to_state=True):
+    """image [d,8,2] fp64 + heights [d] -> state [d,6] fp32 (to_state) or space [d,8,3] fp64."""
+    lib = _hip.load()
+    _hip.need_gpu(im, heights, H, H2, mat_index)
+    im = im.double().contiguous()
+    hts = _hip.f32c(heights)
+    d = im.shape[0]
+    if to_state:
+        out = torch.empty((d, 6), dtype=torch.float32, device=im.device)
+    else:
+        out = torch.empty((d, 8, 3), dtype=torch.float64, device=im.device)
+    if d:
+        fn = lib.rn_im_to_state if to_state else lib.rn_im_to_space
+        with torch.cuda.device(im.device):
+            _hip.check(fn(im.data_ptr(), hts.data_ptr(), H.data_ptr(), _hip.ptr(H2), _hip.ptr(mat_index),
+                          out.data_ptr(), d, _hip.stream()), "rn_im_to_state")
+    return out

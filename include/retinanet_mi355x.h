@@ -1,0 +1,127 @@
+/*
+ * retinanet_mi355x.h -- C ABI of libretinanet_mi355x.so (gfx950 / MI355X).
+ *
+ * The reference (DerekGloudemans/3D-playground) has no native layer: its hot path is Python on top of
+ * torch / torchvision / numpy.  This library is the hand-written HIP layer inserted under the same Python
+ * surface.  Every entry point takes raw DEVICE pointers, sizes and a hipStream_t (as void*), launches on
+ * that stream without synchronising, allocates nothing, and returns 0 (hipSuccess) or a hipError_t /
+ * RN_E* code.  Tensors are dense row-major fp32 unless a comment says otherwise.  No torch types cross
+ * this boundary; the ctypes binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Each function cites the reference code it replaces.  D/ = pytorch_retinanet_detector_directional/retinanet/,
+ * R/ = retinanet/ of the reference checkout.
+ */
+#ifndef RETINANET_MI355X_H
+#define RETINANET_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RN_OK 0
+#define RN_EINVAL 10001      /* bad size / unsupported shape */
+#define RN_ETOOMANY 10002    /* more ground-truth rows per image than RN_MAX_GT */
+#define RN_MAX_GT 256
+#define RN_LEVELS 5
+
+const char *rn_version(void);
+/* Device the calling thread is bound to must be gfx950; returns 0 when it is. */
+int rn_check_device(void);
+
+/* ---------------------------------------------------------------- anchors ---------------------------------
+ * Replaces Anchors.forward + generate_anchors + shift (D/anchors.py:21-40, 42-73, 109-129): levels 3..7,
+ * 9 boxes per cell (ratio-major, scale-minor), fp64 arithmetic with ONE rounding to fp32, order
+ * level -> row -> col -> box.  out: [A,4] fp32 (x1,y1,x2,y2). */
+int64_t rn_anchor_count(int height, int width);
+void rn_anchor_base_boxes(double out[RN_LEVELS * 9 * 4]);           /* host helper, numpy-identical fp64 */
+int rn_anchors_fwd(float *out, int height, int width, void *stream);
+
+/* ---------------------------------------------------------------- IoU -------------------------------------
+ * Replaces calc_iou (D/losses.py:5-22): a [A,4] x b [N,4] -> iou [A,N]; no +1, union clamped at 1e-8. */
+int rn_pairwise_iou(const float *a, const float *b, float *iou, int64_t A, int N, void *stream);
+
+/* ---------------------------------------------------------------- focal / smooth-L1 / VP loss -------------
+ * Replaces FocalLoss.forward, directional (D/losses.py:27-362, label_cols = 27, n_reg = 12) and 2D
+ * (R/losses.py:27-177, label_cols = 5, n_reg = 4) in one fused pass per image tile: corner-envelope /
+ * box IoU against every valid label row, max + first-argmax, 0.4/0.5 bands, alpha=.25 gamma=2 focal BCE on
+ * clamp(cls,1e-4,1-1e-4), and for positives the smooth-L1 (beta 1/9; 20 values with the 0.5 top-corner
+ * weight, or 4 std-scaled deltas) and the vanishing-point cosine term.
+ *
+ *   cls [B,A,C] post-sigmoid, reg [B,A,n_reg], anchors [A,4], ann [B,N,label_cols] (padding rows: class -1)
+ *   workspace: rn_focal_workspace_bytes(B, A) bytes, written by fwd, read by bwd (per-image statistics)
+ *   losses: 3 floats  (cls, reg, vp; vp = 0 for the 2D variant).  An all-empty batch yields vp = NaN
+ *           (the reference raises there, D/losses.py:362; the Python binding raises before launching).
+ *   bwd: grad_losses = 3 device floats (dL/dcls_loss, dL/dreg_loss, dL/dvp_loss); writes dense
+ *        dcls [B,A,C] and dreg [B,A,n_reg] (zeros where no gradient flows).
+ */
+int64_t rn_focal_workspace_bytes(int B, int64_t A);
+int rn_focal_loss_fwd(const float *cls, const float *reg, const float *anchors, const float *ann,
+                      int B, int64_t A, int C, int N, int directional,
+                      void *workspace, float *losses, void *stream);
+int rn_focal_loss_bwd(const float *cls, const float *reg, const float *anchors, const float *ann,
+                      int B, int64_t A, int C, int N, int directional,
+                      const void *workspace, const float *grad_losses,
+                      float *dcls, float *dreg, void *stream);
+/* Assignment only (test / debugging aid): iou_max [B,A] fp32, argmax [B,A] int32 (index among VALID rows,
+ * -1 for an image without labels), state [B,A] int32 in {-1 ignore, 0 negative, 1 positive}. */
+int rn_assign(const float *anchors, const float *ann, int B, int64_t A, int N, int directional,
+              float *iou_max, int32_t *argmax, int32_t *state, void *stream);
+
+/* ---------------------------------------------------------------- decode / clip ---------------------------
+ * rn_decode_dir replaces BBoxTransform.forward (D/utils.py:102-149): reg [B,A,12] -> boxes [B,A,20].
+ * rn_decode_2d  replaces BBoxTransform.forward (R/utils.py:102-126) with std (.1,.1,.2,.2) and, when
+ * clip != 0, ClipBoxes.forward fused (R/utils.py:134-144): deltas [B,A,4] -> boxes [B,A,4].
+ * rn_clip_boxes is the standalone in-place ClipBoxes. */
+int rn_decode_dir(const float *anchors, const float *reg, float *boxes, int B, int64_t A, void *stream);
+int rn_decode_2d(const float *anchors, const float *deltas, float *boxes, int B, int64_t A,
+                 int clip, float width, float height, void *stream);
+int rn_clip_boxes(float *boxes, int64_t n, float width, float height, void *stream);
+
+/* ---------------------------------------------------------------- score filter + NMS ----------------------
+ * The eval branch of ResNet.forward (D/model.py:311-397, R/model.py:283-311).
+ *
+ * rn_rowmax: scores[n] = max_c cls[n,c], classes[n] = first argmax (int64)          (D/model.py:320)
+ * rn_threshold_select: the adaptive loop "t = start; repeat { mask = s > t; cnt = sum(mask); t *= 10**0.2 }
+ *   until cnt <= keep" (D/model.py:322-328, 368-374) evaluated as one histogram pass; fixed_threshold >= 0
+ *   selects the plain "s > thr" of the 2D path instead (R/model.py:289).  scores has `stride` floats between
+ *   consecutive elements (class column of a [A,C] matrix).  Outputs, all device: count[0] = number selected,
+ *   sel_idx[0..count) = indices in increasing order (the order a boolean mask gives).
+ * rn_nms: greedy NMS (torchvision.ops.nms contract: score-descending, suppress IoU > thr; ties by lower
+ *   index) over `count[0]` candidates: boxes are rows box_idx[i] of `boxes` (row stride box_stride floats,
+ *   4 coords at column box_col); category[i] (may be NULL) reproduces batched_nms' fp32 offset trick
+ *   (D/model.py:47-57).  keep[0..keep_count[0]) = positions into the candidate list, score-descending.
+ * Workspace sizes are returned by rn_post_workspace_bytes(max_candidates).
+ */
+int64_t rn_post_workspace_bytes(int64_t n_scores, int64_t max_candidates);
+int rn_rowmax(const float *cls, int64_t n, int C, float *scores, int64_t *classes, void *stream);
+int rn_threshold_select(const float *scores, int64_t n, int64_t stride, double start, int keep,
+                        double fixed_threshold, void *workspace, int32_t *count, int32_t *sel_idx, void *stream);
+int rn_nms(const float *boxes, int64_t box_stride, int box_col, const float *scores, int64_t score_stride,
+           const int32_t *cand_idx, const int32_t *category, const int32_t *count, int max_candidates,
+           float iou_thr, void *workspace, int32_t *keep, int32_t *keep_count, void *stream);
+
+/* ---------------------------------------------------------------- homography ------------------------------
+ * Replaces Homography.i24_state_to_space + space_to_im = state_to_im (homography.py:305-320, 438-488) and
+ * im_to_space + i24_space_to_state = im_to_state (homography.py:388-435, 274-303, 491-500).
+ *   state [d,6] fp32 (x_rear, y_ctr, l, w, h, dir); image points [d,8,2] fp64; heights [d] fp32.
+ *   P: 3x4 fp64 row-major, H: 3x3 fp64 row-major.  mat_index (may be NULL) picks a matrix per object
+ *   (the reference's name = list of cameras); NULL uses matrix 0 for all (name = str).
+ *   P2/H2 non-NULL = Homography_Wrapper (homography.py:840-862): objects whose corner-0 space y > 60 use
+ *   the second set. */
+int rn_state_to_space(const float *state, float *space, int64_t d, void *stream);
+int rn_space_to_state(const double *space, float *state, int64_t d, void *stream);
+int rn_state_to_im(const float *state, const double *P, const double *P2, const int32_t *mat_index,
+                   double *im, int64_t d, void *stream);
+int rn_space_to_im(const float *space, const double *P, const double *P2, const int32_t *mat_index,
+                   double *im, int64_t d, void *stream);
+int rn_im_to_space(const double *im, const float *heights, const double *H, const double *H2,
+                   const int32_t *mat_index, double *space, int64_t d, void *stream);
+int rn_im_to_state(const double *im, const float *heights, const double *H, const double *H2,
+                   const int32_t *mat_index, float *state, int64_t d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
