@@ -1,0 +1,223 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak).
+//
+// Replaces every nn.Conv2d of the detector -- ResNet stem / BasicBlock / Bottleneck convs (D/model.py:213,
+// D/utils.py:6-80), PyramidFeatures (D/model.py:59-117), RegressionModel / ClassificationModel towers and
+// outputs (D/model.py:120-205) -- together with what the reference runs as separate kernels right after them:
+// the frozen BatchNorm affine (D/model.py:278-282), conv bias, the residual add + ReLU of a block
+// (D/utils.py:38-43, 75-80), the FPN nearest-upsample + add with crop (D/model.py:88-108), the head's Sigmoid
+// and permute(0,2,3,1)+view (D/model.py:155-157, 196-205).  The same kernel computes data gradients: dgrad is a
+// convolution of dY with re-packed weights under a different output->input coordinate map.
+//
+// GEMM view:  M = N*Ho*Wo output pixels,  N = Cout,  K = kh*kw*Cin.
+// Layout:     activations NHWC fp32 (channels contiguous: 16-byte loads along K, 128-byte stores along Cout);
+//             weights packed [Cout][kh][kw][Cin] (K contiguous per output channel) by pack kernels.
+// Tile:       workgroup 64*WM x 64*WN outputs, K-step 32; 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32
+//             accumulators (64 VGPRs).  Both operands are staged as K-contiguous rows in LDS with a 4-float pad
+//             (row stride 144 B): ds_write_b128 by rows is conflict-free, and the fragment read
+//             ds_read_b128 at [row = lane&31][k = 8*step + 4*(lane>>5) .. +3] is conflict-free as well
+//             (16-lane groups hit 16 distinct 16-byte slots: 9*row mod 16 is a bijection on the group's rows);
+//             one b128 per operand tile feeds four MFMAs.  Global->register loads of K-step t+1 are issued before
+//             the 64 MFMAs of step t and written to the other LDS buffer after them: one barrier per K-step.
+// Grid:       1-D, tile id remapped so that consecutive tiles (neighbouring pixel rows, both Cout halves) share
+//             an XCD's L2: halo rows and the 9 taps of a 3x3 filter are re-read from L2, not HBM.
+//
+// Roofline: MFMA (fp32 157.3 TF).  Per K-step a wave issues 64 MFMAs (4096 cycles) against 16 ds_read_b128,
+// 8 global_load_dwordx4 and 8 ds_write_b128.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDK 36                 // padded LDS row, floats
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
+                                                            const float *__restrict__ w, float *__restrict__ y,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            const float *__restrict__ add, const float *__restrict__ mask) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int AR = BM / 32, BR = BN / 32;              // rows of A / B each thread stages per K-step
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ float lds[2][(BM + BN) * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = (d.Cout + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int64_t M = (int64_t)d.N * HoWo;
+    const int K = d.kh * d.kw * d.Cin;
+    const int Kpad = (K + BK - 1) / BK * BK;               // packed weight rows are zero-padded to Kpad
+    const int nks = Kpad / BK;
+    const int dmask = (1 << d.div_shift) - 1;
+
+    // ---- per-thread staging geometry: chunk column q (4 floats of K), rows srow + 32*i
+    const int q = tid & 7, srow = tid >> 3;
+    const float *a_base[AR];
+    int a_h[AR], a_w[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int64_t m = (int64_t)m0 + srow + 32 * i;
+        if (m < M) {
+            const int n = (int)(m / HoWo);
+            const int rem = (int)(m - (int64_t)n * HoWo);
+            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+            a_base[i] = x + (int64_t)n * d.x_batch_stride;
+            a_h[i] = oh * d.a + d.p;
+            a_w[i] = ow * d.a + d.p;
+        } else {
+            a_base[i] = x;
+            a_h[i] = -(1 << 28);                           // fails every bounds test
+            a_w[i] = 0;
+        }
+    }
+    const float *b_base[BR];
+    bool b_ok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + srow + 32 * i;
+        b_ok[i] = n < d.Cout;
+        b_base[i] = w + (int64_t)(b_ok[i] ? n : 0) * Kpad + 4 * q;
+    }
+
+    float4 ra[AR], rb[BR];
+    auto load_step = [&](int ks) {
+        const int k = ks * BK + 4 * q;
+        const int tap = k / d.Cin;
+        const int c0 = k - tap * d.Cin;
+        const int r = tap / d.kw, s = tap - r * d.kw;
+        const bool tap_ok = r < d.kh;
+        const int hoff = r * d.b, woff = s * d.b;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
+            const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+            const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
+            ra[i] = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((int64_t)ih * d.Wi + iw) * d.Cin + c0)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = b_ok[i] ? *reinterpret_cast<const float4 *>(b_base[i] + ks * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_step = [&](int buf) {
+        float *A = lds[buf], *B = lds[buf] + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4 *>(A + (srow + 32 * i) * LDK + 4 * q) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4 *>(B + (srow + 32 * i) * LDK + 4 * q) = rb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    const int frag = (lane & 31) * LDK + (lane >> 5) * 4;   // [row = lane&31][k = 4*(lane>>5)]
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_step(ks + 1);
+        const float *A = lds[buf] + (wm * 64) * LDK + frag;
+        const float *B = lds[buf] + BM * LDK + (wn * 64) * LDK + frag;
+#pragma unroll
+        for (int st = 0; st < BK / 8; ++st) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(A + st * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LDK + st * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(B + st * 8);
+            const float4 b1 = *reinterpret_cast<const float4 *>(B + 32 * LDK + st * 8);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
+        }
+        if (ks + 1 < nks) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: out = act(scale[c]*acc + shift[c] + add) * (mask > 0)
+    // accumulator element e of lane l: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
+    const bool dense_y = d.y_batch_stride == (int64_t)HoWo * d.Cout;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+        const bool col_ok = col < d.Cout;
+        const float sc = (scale != nullptr && col_ok) ? scale[col] : 1.f;
+        const float sh = (shift != nullptr && col_ok) ? shift[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = (int64_t)m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m >= M || !col_ok) continue;
+                float v = acc[tm][tn][e] * sc + sh;
+                int64_t off;
+                int n = 0, rem = 0;
+                if (dense_y && d.add_mode != 2) {
+                    off = m * d.Cout + col;
+                } else {
+                    n = (int)(m / HoWo);
+                    rem = (int)(m - (int64_t)n * HoWo);
+                    off = (int64_t)n * d.y_batch_stride + (int64_t)rem * d.Cout + col;
+                }
+                if (d.add_mode == 1) {
+                    v += add[dense_y ? off : ((int64_t)n * d.add_batch_stride + (int64_t)rem * d.Cout + col)];
+                } else if (d.add_mode == 2) {               // nearest x2 upsample of [N,Ha,Wa,Cout], cropped (D/model.py:88-108)
+                    const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+                    v += add[(int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col];
+                }
+                if (d.act == 1) v = fmaxf(v, 0.f);
+                else if (d.act == 2) v = 1.0f / (1.0f + expf(-v));
+                if (mask != nullptr) v = mask[off] > 0.f ? v : 0.f;
+                y[off] = v;
+            }
+        }
+    }
+}
+
+static int check_desc(const rn_conv_desc *d) {
+    if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
+    if (d->Cin < 4 || (d->Cin & 3)) return RN_EINVAL;                     // 16-byte chunks must not straddle taps
+    if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
+    if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
+    return RN_OK;
+}
+
+extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y, const float *scale,
+                             const float *shift, const float *add, const float *mask, void *stream) {
+    const int rc = check_desc(d);
+    if (rc) return rc;
+    if ((d->add_mode != 0) != (add != nullptr)) return RN_EINVAL;
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cout <= 64) {                                                  // 256 x 64 tile: no wasted N half
+        const int64_t tiles = (M + 255) / 256;
+        if (tiles > 0x7fffffff) return RN_EINVAL;
+        hipLaunchKernelGGL((conv_igemm_kernel<4, 1>), dim3((unsigned)tiles), dim3(256), 0, s, *d, x, w_packed, y, scale,
+                           shift, add, mask);
+    } else {
+        const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+        if (tiles > 0x7fffffff) return RN_EINVAL;
+        hipLaunchKernelGGL((conv_igemm_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, s, *d, x, w_packed, y, scale,
+                           shift, add, mask);
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

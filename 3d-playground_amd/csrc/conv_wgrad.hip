@@ -1,0 +1,170 @@
+// Weight gradient of the convolutions on the fp32 matrix cores.
+//
+// The reference obtains dW from torch autograd (cuDNN wgrad kernels) for every nn.Conv2d of D/model.py; here it
+// is one GEMM per layer:  dW[co][r][s][ci] = sum over output pixels of dY[pixel][co] * X[pixel shifted by the
+// tap][ci], i.e.  M = Cout,  N = kh*kw*Cin (the packed-weight row, so a tile may span several taps of a
+// narrow layer),  K = N*Ho*Wo pixels.
+//
+// Both operands are "K-major" in memory already (NHWC: one pixel = one contiguous channel vector), so tiles are
+// staged into LDS exactly as they lie: [32 pixels][64*WM channels] and [32 pixels][64*WN flattened (tap,ci)].
+// The v_mfma_f32_32x32x2_f32 fragment A[m = lane&31][k = lane>>5] is then one ds_read_b32 with lanes 0-31 on
+// consecutive words (conflict-free), one read per MFMA operand tile; 64 reads against 64 MFMAs (64 cycles each)
+// per wave per K-step.
+//
+// K is split over gridDim.y; partial tiles are added with fp32 atomics (two 128-byte row segments per wave
+// instruction, the full-rate shape) into a buffer the caller zeroes -- the five pyramid levels of a shared head
+// accumulate into the same buffer.  Blocks of one K-slice are adjacent in the grid so they stream the same dY /
+// X slabs through one XCD's L2.
+//
+// Roofline: MFMA (fp32 157.3 TF).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define WK 32                    // pixels per K-step
+
+struct WgradArgs {
+    const float *dy, *x;
+    float *dw;
+    int ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad;
+    int Kflat, Kpad;             // kh*kw*Cin and its round-up to 32
+    int tiles_n;                 // number of N tiles
+    int64_t pixels, per_split;   // K extent and K per grid.y slice (multiple of WK)
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int CA = BM / 4, CB = BN / 4;                  // 16-byte chunks per staged row
+    constexpr int PA = CA / 8, PB = CB / 8;                  // passes (rows per pass = 256 / chunks)
+    constexpr int RA = 256 / CA, RB = 256 / CB;
+    __shared__ float lds[2][WK * (BM + BN)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+    const int64_t kbeg = (int64_t)blockIdx.y * p.per_split;
+    const int64_t kend = (kbeg + p.per_split < p.pixels) ? kbeg + p.per_split : p.pixels;
+    const int nks = (int)((kend - kbeg + WK - 1) / WK);
+    const int HoWo = p.Ho * p.Wo;
+
+    // A staging: chunk ca of the co range, rows (tid / CA) + RA*i
+    const int ca = tid % CA, ra0 = tid / CA;
+    const bool a_col_ok = (m0 + 4 * ca) < p.ldy;
+    // B staging: chunk cb -> fixed (tap, ci0)
+    const int cb = tid % CB, rb0 = tid / CB;
+    const int jcol = n0 + 4 * cb;
+    const int tap = jcol / p.Cin;
+    const int ci0 = jcol - tap * p.Cin;
+    const int fr = tap / p.kw, fs = tap - fr * p.kw;
+    const bool b_col_ok = jcol < p.Kflat;
+
+    float4 va[PA], vb[PB];
+    auto load_step = [&](int ks) {
+        const int64_t kb = kbeg + (int64_t)ks * WK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int64_t pix = kb + ra0 + RA * i;
+            va[i] = (a_col_ok && pix < kend) ? *reinterpret_cast<const float4 *>(p.dy + pix * p.ldy + m0 + 4 * ca)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int64_t pix = kb + rb0 + RB * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_col_ok && pix < kend) {
+                const int n = (int)(pix / HoWo);
+                const int rem = (int)(pix - (int64_t)n * HoWo);
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                const int ih = oh * p.stride + fr - p.pad, iw = ow * p.stride + fs - p.pad;
+                if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+                    v = *reinterpret_cast<const float4 *>(p.x + (((int64_t)n * p.Hi + ih) * p.Wi + iw) * p.Cin + ci0);
+            }
+            vb[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+        float *A = lds[buf], *B = lds[buf] + WK * BM;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4 *>(A + (ra0 + RA * i) * BM + 4 * ca) = va[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4 *>(B + (rb0 + RB * i) * BN + 4 * cb) = vb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nks > 0) {
+        load_step(0);
+        store_step(0);
+    }
+    __syncthreads();
+    const int fa = (lane >> 5) * BM + wm * 64 + (lane & 31);
+    const int fb = (lane >> 5) * BN + wn * 64 + (lane & 31);
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) load_step(ks + 1);
+        const float *A = lds[buf] + fa;
+        const float *B = lds[buf] + WK * BM + fb;
+#pragma unroll
+        for (int kp = 0; kp < WK / 2; ++kp) {
+            const float a0 = A[2 * kp * BM], a1 = A[2 * kp * BM + 32];
+            const float b0 = B[2 * kp * BN], b1 = B[2 * kp * BN + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (ks + 1 < nks) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    if (nks == 0) return;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < p.Cout && col < p.Kflat) atomicAdd(p.dw + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+            }
+        }
+}
+
+extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, int Hi, int Wi, int Cin, int Ho,
+                             int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream) {
+    if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
+        return RN_EINVAL;
+    WgradArgs a;
+    a.dy = dy; a.x = x; a.dw = dw; a.ldy = ldy;
+    a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.Kflat = kh * kw * Cin;
+    a.Kpad = (a.Kflat + 31) / 32 * 32;
+    a.pixels = (int64_t)N * Ho * Wo;
+    const bool narrow_m = Cout <= 64;
+    const int BM = narrow_m ? 64 : 128, BN = narrow_m ? 256 : 128;
+    const int tiles_m = (Cout + BM - 1) / BM;
+    a.tiles_n = (a.Kflat + BN - 1) / BN;
+    const int tiles = tiles_m * a.tiles_n;
+    // enough K slices to put ~4 workgroups on every CU, each at least 16 K-steps long
+    int64_t splits = (1024 + tiles - 1) / tiles;
+    const int64_t max_splits = (a.pixels + 16 * WK - 1) / (16 * WK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    a.per_split = ((a.pixels + splits - 1) / splits + WK - 1) / WK * WK;
+    splits = (a.pixels + a.per_split - 1) / a.per_split;
+    const dim3 grid(tiles, (unsigned)splits);
+    if (narrow_m)
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -42,6 +42,34 @@ SIGNATURES = {
     "rn_im_to_state": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 
+class ConvDesc(ctypes.Structure):
+    """rn_conv_desc of include/retinanet_mi355x.h."""
+    _fields_ = [("N", c_i32), ("Hi", c_i32), ("Wi", c_i32), ("Cin", c_i32),
+                ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
+                ("kh", c_i32), ("kw", c_i32),
+                ("a", c_i32), ("b", c_i32), ("p", c_i32), ("div_shift", c_i32),
+                ("act", c_i32), ("add_mode", c_i32), ("Ha", c_i32), ("Wa", c_i32),
+                ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64)]
+
+
+SIGNATURES.update({
+    "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp] + [c_i32] * 11 + [c_vp]),
+    "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
+    "rn_unpack_wgrad": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp] * 7),
+    "rn_bn_fold": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rn_nchw_to_nhwc4": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "rn_maxpool_fwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
+    "rn_maxpool_bwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
+    "rn_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "rn_colsum_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "rn_upsample_add_bwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
+    "rn_relu_mask": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+})
+
+
 RN_ERRORS = {10001: "RN_EINVAL (bad size / unsupported shape)",
              10002: "RN_ETOOMANY (more than RN_MAX_GT=256 label rows per image)"}
 

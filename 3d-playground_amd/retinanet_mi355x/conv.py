@@ -1,0 +1,176 @@
+"""Thin wrappers over the convolution-engine entry points of the C ABI (NHWC fp32 device tensors).
+
+These are the building blocks ``engine.py`` schedules; they do no autograd themselves.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+
+ConvDesc = _hip.ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def kpad(kh, kw, c):
+    return (kh * kw * c + 31) // 32 * 32
+
+
+def out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None):
+    """OIHW parameter -> packed GEMM rows (mode 0: [Cout][kh][kw][Cin]; mode 1 (dgrad): [Cin][kh][kw][Cout]*scale)."""
+    lib = _hip.load()
+    w = _hip.f32c(weight.detach())
+    _hip.need_gpu(w, scale)
+    cout, cin, kh, kw = w.shape
+    kw_pad = kw if kw_pad is None else kw_pad
+    if c_pad is None:
+        c = cin if mode == 0 else cout
+        c_pad = (c + 3) // 4 * 4
+    rows = cout if mode == 0 else cin
+    out = torch.empty((rows, kpad(kh, kw_pad, c_pad)), dtype=torch.float32, device=w.device)
+    _hip.check(lib.rn_pack_weights(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kw_pad, c_pad, mode,
+                                   _hip.ptr(scale), _hip.stream()), "rn_pack_weights")
+    return out
+
+
+def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
+               act=ACT_NONE, y_batch_stride=None, add_batch_stride=None):
+    """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
+    y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift)."""
+    lib = _hip.load()
+    N, Hi, Wi, Cin = x.shape
+    Ho, Wo, Cout, kh, kw, a, b, p, ds = geom
+    d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p, ds, act, add_mode, add_hw[0], add_hw[1],
+                 Hi * Wi * Cin, Ho * Wo * Cout if y_batch_stride is None else y_batch_stride,
+                 (Ho * Wo * Cout if add_mode == 1 else add_hw[0] * add_hw[1] * Cout) if add_batch_stride is None
+                 else add_batch_stride)
+    _hip.check(lib.rn_conv_igemm(ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale),
+                                 _hip.ptr(shift), _hip.ptr(add), _hip.ptr(mask), _hip.stream()), "rn_conv_igemm")
+    return y
+
+
+def fprop(x, w_packed, cout, k, stride, pad, kw_pad=None, **kw):
+    """Forward convolution, NHWC in -> new NHWC out."""
+    N, Hi, Wi, _ = x.shape
+    Ho, Wo = out_size(Hi, k, stride, pad), out_size(Wi, k, stride, pad)
+    y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    return conv_igemm(x, w_packed, y, (Ho, Wo, cout, k, k if kw_pad is None else kw_pad, stride, 1, -pad, 0), **kw)
+
+
+def dgrad(dy, w_packed_dgrad, in_hw, cin, k, stride, pad, **kw):
+    """Data gradient: dy [N,Ho,Wo,Cout(_pad)] -> dx [N,Hi,Wi,Cin]."""
+    N = dy.shape[0]
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, cin), dtype=torch.float32, device=dy.device)
+    return conv_igemm(dy, w_packed_dgrad, dx, (Hi, Wi, cin, k, k, 1, -1, pad, stride.bit_length() - 1), **kw)
+
+
+def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None):
+    """dw[Cout][Kpad] += wgrad(dy, x).  dy [N,Ho,Wo,ldy] (ldy >= cout), x [N,Hi,Wi,Cin]."""
+    lib = _hip.load()
+    N, Ho, Wo, ldy = dy.shape
+    _, Hi, Wi, Cin = x.shape
+    _hip.check(lib.rn_conv_wgrad(dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Cin, Ho, Wo, cout, k,
+                                 k if kw_pad is None else kw_pad, stride, pad, _hip.stream()), "rn_conv_wgrad")
+    return dw
+
+
+def unpack_wgrad(dw, w_packed, weight_shape, kw_pad=None, c_pad=None, scale=None, mean=None, rstd=None, colsum=None,
+                 want_bn=False):
+    """-> (dweight OIHW, dgamma or None, dbeta or None)."""
+    lib = _hip.load()
+    cout, cin, kh, kw = weight_shape
+    kw_pad = kw if kw_pad is None else kw_pad
+    c_pad = (cin + 3) // 4 * 4 if c_pad is None else c_pad
+    dweight = torch.empty(weight_shape, dtype=torch.float32, device=dw.device)
+    dgamma = torch.empty(cout, dtype=torch.float32, device=dw.device) if want_bn else None
+    dbeta = torch.empty(cout, dtype=torch.float32, device=dw.device) if colsum is not None else None
+    _hip.check(lib.rn_unpack_wgrad(dw.data_ptr(), _hip.ptr(w_packed), dweight.data_ptr(), cout, cin, kh, kw, kw_pad,
+                                   c_pad, _hip.ptr(scale), _hip.ptr(mean), _hip.ptr(rstd), _hip.ptr(colsum),
+                                   _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.stream()), "rn_unpack_wgrad")
+    return dweight, dgamma, dbeta
+
+
+def bn_fold(gamma, beta, mean, var, eps=1e-5):
+    lib = _hip.load()
+    C = gamma.numel()
+    out = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
+    _hip.check(lib.rn_bn_fold(_hip.f32c(gamma.detach()).data_ptr(), _hip.f32c(beta.detach()).data_ptr(),
+                              _hip.f32c(mean).data_ptr(), _hip.f32c(var).data_ptr(), eps, C, out[0].data_ptr(),
+                              out[1].data_ptr(), out[2].data_ptr(), _hip.stream()), "rn_bn_fold")
+    return out[0], out[1], out[2]
+
+
+def nchw_to_nhwc4(img):
+    lib = _hip.load()
+    img = _hip.f32c(img)
+    N, C, H, W = img.shape
+    if C != 3:
+        raise RuntimeError("the stem takes 3-channel images (D/model.py:213), got %d" % C)
+    out = torch.empty((N, H, W, 4), dtype=torch.float32, device=img.device)
+    _hip.check(lib.rn_nchw_to_nhwc4(img.data_ptr(), out.data_ptr(), N, H, W, _hip.stream()), "rn_nchw_to_nhwc4")
+    return out
+
+
+def maxpool_fwd(x):
+    lib = _hip.load()
+    N, H, W, C = x.shape
+    Ho, Wo = out_size(H, 3, 2, 1), out_size(W, 3, 2, 1)
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    _hip.check(lib.rn_maxpool_fwd(x.data_ptr(), y.data_ptr(), N, H, W, C, Ho, Wo, _hip.stream()), "rn_maxpool_fwd")
+    return y
+
+
+def maxpool_bwd(x, dy, relu_mask=True):
+    lib = _hip.load()
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _hip.check(lib.rn_maxpool_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, C, dy.shape[1], dy.shape[2],
+                                  int(relu_mask), _hip.stream()), "rn_maxpool_bwd")
+    return dx
+
+
+def colsum(g, C=None):
+    """Column sums of a [..., ld] tensor over all leading dims, first C columns."""
+    lib = _hip.load()
+    ld = g.shape[-1]
+    C = ld if C is None else C
+    rows = g.numel() // ld
+    ws = torch.empty(lib.rn_colsum_workspace_bytes(rows, C), dtype=torch.uint8, device=g.device)
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    _hip.check(lib.rn_colsum(g.data_ptr(), rows, C, ld, out.data_ptr(), ws.data_ptr(), _hip.stream()), "rn_colsum")
+    return out
+
+
+def upsample_add_bwd(src, dst):
+    """dst[n,h,w,:] += sum of the (in-bounds) 2x2 children in src."""
+    lib = _hip.load()
+    N, Hs, Ws, C = src.shape
+    _hip.check(lib.rn_upsample_add_bwd(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C,
+                                       _hip.stream()), "rn_upsample_add_bwd")
+    return dst
+
+
+def relu_mask_(g, z):
+    _hip.check(_hip.load().rn_relu_mask(g.data_ptr(), z.data_ptr(), g.numel(), _hip.stream()), "rn_relu_mask")
+    return g
+
+
+def sigmoid_bwd_pad(dy, s, C, ld):
+    """dy [rows, C] (+ sigmoid output s or None) -> [rows, ld] zero-padded, multiplied by s(1-s)."""
+    lib = _hip.load()
+    rows = dy.numel() // C
+    out = torch.empty((rows, ld), dtype=torch.float32, device=dy.device)
+    _hip.check(lib.rn_sigmoid_bwd_pad(dy.data_ptr(), _hip.ptr(s), out.data_ptr(), rows, C, ld, _hip.stream()),
+               "rn_sigmoid_bwd_pad")
+    return out
+
+
+def add_(dst, src):
+    _hip.check(_hip.load().rn_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), _hip.stream()), "rn_add_inplace")
+    return dst

@@ -121,6 +121,91 @@ int rn_im_to_space(const double *im, const float *heights, const double *H, cons
 int rn_im_to_state(const double *im, const float *heights, const double *H, const double *H2,
                    const int32_t *mat_index, float *state, int64_t d, void *stream);
 
+/* ---------------------------------------------------------------- convolution engine ----------------------
+ * fp32 implicit-GEMM convolutions on the matrix cores (v_mfma_f32_32x32x2_f32).  Replaces nn.Conv2d +
+ * BatchNorm2d(eval) + ReLU + residual add (D/utils.py:25-43, 60-80), PyramidFeatures (D/model.py:84-117) and
+ * the head towers (D/model.py:139-157, 182-205), forward and backward (the reference gets the latter from
+ * torch autograd / cuDNN).
+ *
+ * Activations are NHWC fp32.  Weights are re-packed once per optimizer step by rn_pack_weights into
+ * [rows][Kpad] with K = kh*kw*Cin contiguous (Kpad = K rounded up to 32, zero filled).
+ *
+ * rn_conv_igemm computes, for every output pixel (n, oh, ow) and output channel c:
+ *     acc = sum_{r<kh, s<kw, ci<Cin} x[n, ih, iw, ci] * w[c][r][s][ci]
+ *     with  ih = (oh*a + p + r*b) >> div_shift  (contributes only if the numerator is >= 0, divisible by
+ *     1 << div_shift and ih < Hi; same for iw),
+ *     y = act(scale[c]*acc + shift[c] + add[...]) and, when mask != NULL, y = mask[...] > 0 ? y : 0.
+ *   forward conv (stride st, padding pd):    a = st, b = +1, p = -pd, div_shift = 0
+ *   data gradient of that conv:              a = 1,  b = -1, p = +pd, div_shift = log2(st), x = dY, and
+ *                                            w packed as [Cin][kh][kw][Cout] (rn_pack_weights mode 1)
+ * add_mode 1: add has the geometry of y (residual / gradient accumulation); 2: add is [N,Ha,Wa,Cout] read at
+ * (oh>>1, ow>>1) -- the FPN nearest-upsample + add, cropped to the output (D/model.py:88-108).
+ * batch strides are in floats; y_batch_stride lets a head write straight into its slice of the concatenated
+ * [B, A, n] tensor (the reference's permute+view+cat, D/model.py:155-157, 302-304).
+ */
+typedef struct rn_conv_desc {
+    int N, Hi, Wi, Cin;            /* input  [N,Hi,Wi,Cin]; Cin % 4 == 0 */
+    int Ho, Wo, Cout;              /* output [N,Ho,Wo,Cout] */
+    int kh, kw;
+    int a, b, p, div_shift;
+    int act;                       /* 0 none, 1 ReLU, 2 sigmoid */
+    int add_mode;                  /* 0 none, 1 same geometry, 2 nearest-upsample x2 */
+    int Ha, Wa;
+    int64_t x_batch_stride, y_batch_stride, add_batch_stride;
+} rn_conv_desc;
+
+int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
+                  const float *scale, const float *shift, const float *add, const float *mask, void *stream);
+
+/* Weight gradient: dw[co][r][s][ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*st + r - pd, ow*st + s - pd, ci]
+ * (fp32 atomics into a zeroed or previously accumulated [Cout][Kpad] buffer, same layout as the packed forward
+ * weights; heads accumulate their five pyramid levels into one buffer).  dy: [N,Ho,Wo,Cout] with channel
+ * stride ldy >= Cout (a padded copy is allowed), x: [N,Hi,Wi,Cin]. */
+int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, int Hi, int Wi, int Cin,
+                  int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream);
+
+/* Weight packing.  src is the reference's OIHW parameter [Cout][Cin][kh][kw] (state_dict layout).
+ *   mode 0 (forward):  dst[co][r][s][ci]          = src[co][ci][r][s]
+ *   mode 1 (dgrad):    dst[ci][r][s][co]          = src[co][ci][r][s] * scale[co]   (scale NULL = 1)
+ * kw_pad >= kw and cin_pad >= Cin (forward) / cout_pad >= Cout (dgrad) give zero-filled padding of the tap and
+ * channel dimensions (stem: 7x7x3 -> 7x8x4); rows are Kpad = roundup(kh*kw_pad*c_pad, 32) floats.
+ * rn_unpack_wgrad converts an accumulated dw[Cout][Kpad] back to OIHW and applies the folded batch-norm:
+ *   dweight[co][ci][r][s] = scale[co] * dw[co][r][s][ci]
+ *   dgamma[co] = (sum_k w[co][k]*dw[co][k] - mean[co]*colsum[co]) * rstd[co],  dbeta[co] = colsum[co]
+ * (any of dgamma/dbeta/scale may be NULL). */
+int rn_pack_weights(const float *src, float *dst, int Cout, int Cin, int kh, int kw, int kw_pad, int c_pad,
+                    int mode, const float *scale, void *stream);
+int rn_unpack_wgrad(const float *dw, const float *w_packed, float *dweight, int Cout, int Cin, int kh, int kw,
+                    int kw_pad, int c_pad, const float *scale, const float *mean, const float *rstd,
+                    const float *colsum, float *dgamma, float *dbeta, void *stream);
+
+/* Frozen batch-norm folding (eval-mode BatchNorm2d, eps 1e-5, D/model.py:278-282):
+ *   scale = gamma / sqrt(var + eps), shift = beta - mean*scale, rstd = 1/sqrt(var + eps). */
+int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
+               float *scale, float *shift, float *rstd, void *stream);
+
+/* Elementwise / data-movement kernels around the convolutions (all NHWC fp32):
+ *   rn_nchw_to_nhwc4:   image [N,3,H,W] -> [N,H,W,4] (4th channel 0) for the stem's 16-byte loads
+ *   rn_maxpool_fwd/bwd: MaxPool2d(3, stride 2, pad 1) (D/model.py:216); bwd routes to the first maximum of each
+ *                       window (torch semantics) and applies the stem ReLU mask (x > 0)
+ *   rn_colsum:          out[c] = sum over rows of g[rows, ld] (bias / beta gradients), deterministic two-pass
+ *   rn_upsample_add_bwd: dst[n,h,w,c] += sum_{dy,dx<2} src[n,2h+dy,2w+dx,c] within src bounds (FPN top-down bwd)
+ *   rn_relu_mask:       g = (z > 0) ? g : 0 in place
+ *   rn_sigmoid_bwd_pad: out[p][c<C] = dy[p][c] * s[p][c]*(1-s[p][c]) (s = sigmoid output, NULL = identity),
+ *                       out[p][C..ld) = 0: head-output gradients padded to a channel count the GEMM accepts
+ *   rn_add_inplace:     dst += src
+ */
+int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *stream);
+int rn_maxpool_fwd(const float *x, float *y, int N, int H, int W, int C, int Ho, int Wo, void *stream);
+int rn_maxpool_bwd(const float *x, const float *dy, float *dx, int N, int H, int W, int C, int Ho, int Wo,
+                   int relu_mask, void *stream);
+int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, void *workspace, void *stream);
+int64_t rn_colsum_workspace_bytes(int64_t rows, int C);
+int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *stream);
+int rn_relu_mask(float *g, const float *z, int64_t n, void *stream);
+int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int64_t rows, int C, int ld, void *stream);
+int rn_add_inplace(float *dst, const float *src, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,229 @@
+"""GPU parity of the fp32 MFMA convolution engine (C ABI: rn_conv_igemm / rn_conv_wgrad / pack / elementwise)
+against torch's fp32 CPU kernels (the same third-party arithmetic the reference runs on).
+
+Tolerance: 1e-4 of the output's max magnitude (north_star: fp32 within 1e-4); achieved ~1e-6 -- the MFMA is an
+exact fp32 fma chain, only the summation order differs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv(dev):
+    from retinanet_mi355x import conv
+    return conv
+
+
+def rnd(shape, seed, std=1.0):
+    from retinanet_mi355x import synth
+    return torch.from_numpy(synth.normal(shape, seed, std))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, tol=1e-4):
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = float((got - want).abs().max())
+    ref = float(want.abs().max()) + 1e-12
+    assert err <= tol * ref, "max err %.3e vs max |ref| %.3e" % (err, ref)
+
+
+FWD_CASES = [  # cin, cout, k, stride, pad, N, H, W
+    (64, 256, 3, 1, 1, 2, 19, 23),
+    (128, 128, 3, 2, 1, 2, 17, 21),
+    (64, 256, 1, 1, 0, 2, 15, 17),
+    (256, 512, 1, 2, 0, 1, 17, 15),
+    (64, 64, 3, 1, 1, 2, 21, 19),        # Cout <= 64: 256x64 tile
+    (256, 108, 3, 1, 1, 1, 9, 15),       # head output, Cout not a multiple of 32
+    (32, 40, 3, 1, 1, 1, 7, 9),          # K = 288, small
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_fprop_dgrad_wgrad(cv, dev, case):
+    cin, cout, k, stride, pad, N, H, W = case
+    x = rnd((N, cin, H, W), 1)
+    w = rnd((cout, cin, k, k), 2, (2.0 / (k * k * cin)) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride, pad)
+    gy = rnd(tuple(y_ref.shape), 3)
+    (y_ref * gy).sum().backward()
+
+    xg, wg = nhwc(x).to(dev), w.to(dev)
+    wp = cv.pack_weights(wg, 0)
+    y = cv.fprop(xg, wp, cout, k, stride, pad)
+    close(nchw(y), y_ref)
+
+    # dgrad (conv Cout padded to a multiple of 4 where needed)
+    cpad = (cout + 3) // 4 * 4
+    gyg = nhwc(gy).to(dev)
+    if cpad != cout:
+        gyg = F.pad(gyg, (0, cpad - cout))
+    wd = cv.pack_weights(wg, 1, c_pad=cpad)
+    dx = cv.dgrad(gyg.contiguous(), wd, (H, W), cin, k, stride, pad)
+    close(nchw(dx), xr.grad)
+
+    # wgrad, accumulated in two halves of the batch when possible, then unpacked to OIHW
+    dw = torch.zeros_like(wp)
+    gy_c = gyg.contiguous()
+    if N > 1:
+        cv.wgrad(gy_c[:1].contiguous(), xg[:1].contiguous(), dw, cout, k, stride, pad)
+        cv.wgrad(gy_c[1:].contiguous(), xg[1:].contiguous(), dw, cout, k, stride, pad)
+    else:
+        cv.wgrad(gy_c, xg, dw, cout, k, stride, pad)
+    dweight, _, _ = cv.unpack_wgrad(dw, wp, tuple(w.shape))
+    close(dweight, wr.grad)
+
+
+def test_stem_conv_bn_relu(cv, dev):
+    """7x7 s2 p3 on a 3-channel NCHW image: NHWC4 staging, kw padded to 8, folded frozen BN + ReLU epilogue."""
+    N, H, W = 2, 37, 45
+    img = rnd((N, 3, H, W), 4)
+    w = rnd((64, 3, 7, 7), 5, 0.1)
+    gamma, beta = rnd((64,), 6, 0.3) + 1.0, rnd((64,), 7, 0.1)
+    mean, var = rnd((64,), 8, 0.1), rnd((64,), 9, 0.1).abs() + 0.5
+    ir, wr = img.clone(), w.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.relu(F.batch_norm(F.conv2d(ir, wr, None, 2, 3), mean, var, gr, br, False, 0.0, 1e-5))
+    gy = rnd(tuple(y_ref.shape), 10)
+    (y_ref * gy).sum().backward()
+
+    x4 = cv.nchw_to_nhwc4(img.to(dev))
+    assert x4.shape == (N, H, W, 4) and float(x4[..., 3].abs().max()) == 0.0
+    wp = cv.pack_weights(w.to(dev), 0, kw_pad=8, c_pad=4)
+    scale, shift, rstd = cv.bn_fold(gamma.to(dev), beta.to(dev), mean.to(dev), var.to(dev))
+    y = cv.fprop(x4, wp, 64, 7, 2, 3, kw_pad=8, scale=scale, shift=shift, act=cv.ACT_RELU)
+    close(nchw(y), y_ref)
+    # backward of the fused layer: g = dy*(y>0); dW = scale*wgrad(g,x); dgamma/dbeta from dWraw, W and colsum(g)
+    g = nhwc(gy).to(dev).contiguous()
+    cv.relu_mask_(g, y)
+    dw = torch.zeros_like(wp)
+    cv.wgrad(g, x4, dw, 64, 7, 2, 3, kw_pad=8)
+    cs = cv.colsum(g)
+    dweight, dgamma, dbeta = cv.unpack_wgrad(dw, wp, (64, 3, 7, 7), kw_pad=8, c_pad=4, scale=scale, mean=mean.to(dev),
+                                             rstd=rstd, colsum=cs, want_bn=True)
+    close(dweight, wr.grad)
+    close(dgamma, gr.grad)
+    close(dbeta, br.grad)
+
+
+def test_residual_block_epilogues(cv, dev):
+    """conv + BN + residual + ReLU in one epilogue; dgrad with gradient accumulation and ReLU mask."""
+    N, C, H, W = 2, 64, 13, 11
+    x = rnd((N, C, H, W), 11)
+    res = rnd((N, 128, H, W), 12)
+    w = rnd((128, C, 3, 3), 13, 0.06)
+    scale_c, shift_c = rnd((128,), 14, 0.2) + 1.0, rnd((128,), 15, 0.1)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xr, w, None, 1, 1) * scale_c[None, :, None, None] + shift_c[None, :, None, None] + res)
+    xg = nhwc(x).to(dev)
+    wp = cv.pack_weights(w.to(dev), 0)
+    y = cv.fprop(xg, wp, 128, 3, 1, 1, scale=scale_c.to(dev), shift=shift_c.to(dev), add=nhwc(res).to(dev),
+                 add_mode=1, act=cv.ACT_RELU)
+    close(nchw(y), y_ref)
+    # dgrad: dx = dgrad(g, scale*W) + other, masked by (zmask > 0)
+    gy = rnd(tuple(y_ref.shape), 16)
+    other = rnd((N, C, H, W), 17)
+    zmask = rnd((N, C, H, W), 18)
+    g_ref = gy * (y_ref > 0)
+    g_ref_x, = torch.autograd.grad(F.conv2d(xr, w * scale_c[:, None, None, None], None, 1, 1), xr, g_ref)
+    want = (g_ref_x + other) * (zmask > 0)
+    g = nhwc(gy).to(dev).contiguous()
+    cv.relu_mask_(g, y)
+    wd = cv.pack_weights(w.to(dev), 1, scale=scale_c.to(dev))
+    dx = cv.dgrad(g, wd, (H, W), C, 3, 1, 1, add=nhwc(other).to(dev), add_mode=1, mask=nhwc(zmask).to(dev))
+    close(nchw(dx), want)
+
+
+def test_fpn_upsample_add_crop(cv, dev):
+    """Lateral 1x1 conv + nearest-upsampled coarser map, cropped to the lateral's size (D/model.py:88-108)."""
+    N = 2
+    c_lat = rnd((N, 128, 9, 13), 19)        # finer level
+    coarse = rnd((N, 256, 5, 7), 20)        # up2 -> 10 x 14, cropped to 9 x 13
+    w = rnd((256, 128, 1, 1), 21, 0.1)
+    b = rnd((256,), 22, 0.1)
+    want = F.conv2d(c_lat, w, b) + F.interpolate(coarse, scale_factor=2, mode="nearest")[:, :, :9, :13]
+    wp = cv.pack_weights(w.to(dev), 0)
+    y = cv.fprop(nhwc(c_lat).to(dev), wp, 256, 1, 1, 0, shift=b.to(dev), add=nhwc(coarse).to(dev), add_mode=2,
+                 add_hw=(5, 7))
+    close(nchw(y), want)
+    # backward of the upsample+crop: children summed into the coarse map
+    g = rnd((N, 256, 9, 13), 23)
+    cr = coarse.clone().requires_grad_(True)
+    (F.interpolate(cr, scale_factor=2, mode="nearest")[:, :, :9, :13] * g).sum().backward()
+    acc = rnd((N, 256, 5, 7), 24)
+    dst = nhwc(acc).to(dev).contiguous()
+    cv.upsample_add_bwd(nhwc(g).to(dev).contiguous(), dst)
+    close(nchw(dst), acc + cr.grad)
+
+
+def test_head_output_into_concat_buffer(cv, dev):
+    """Head output conv writes its level's slice of the concatenated [B, A, n] tensor, sigmoid fused
+    (permute + view + cat of D/model.py:155-157, 196-205, 302-304 for free)."""
+    N, C = 2, 8
+    feats = [rnd((N, 64, 5, 7), 30), rnd((N, 64, 3, 4), 31)]
+    w = rnd((9 * C, 64, 3, 3), 32, 0.05)
+    b = rnd((9 * C,), 33, 0.1)
+    want = torch.cat([torch.sigmoid(F.conv2d(f, w, b, 1, 1)).permute(0, 2, 3, 1).contiguous().view(N, -1, C)
+                      for f in feats], dim=1)
+    A = want.shape[1]
+    out = torch.zeros((N, A, C), dtype=torch.float32, device=dev)
+    wp = cv.pack_weights(w.to(dev), 0)
+    off = 0
+    for f in feats:
+        h, wd = f.shape[2], f.shape[3]
+        view = out.view(N, -1)[:, off * C:]
+        cv.conv_igemm(nhwc(f).to(dev), wp, view, (h, wd, 9 * C, 3, 3, 1, 1, -1, 0), shift=b.to(dev),
+                      act=cv.ACT_SIGMOID, y_batch_stride=A * C)
+        off += h * wd * 9
+    close(out, want)
+    # sigmoid backward + channel padding for the dgrad/wgrad GEMMs
+    dy = rnd((N, 5, 7, 9 * C), 34).to(dev)
+    s = out[:, :5 * 7 * 9].reshape(N, 5, 7, 9 * C).contiguous()
+    pad = cv.sigmoid_bwd_pad(dy, s, 9 * C, 96)
+    wantp = F.pad(dy * s * (1 - s), (0, 96 - 9 * C)).reshape(-1, 96)
+    close(pad, wantp)
+
+
+def test_maxpool_forward_backward_with_ties(cv, dev):
+    N, C, H, W = 2, 8, 13, 15
+    x = F.relu(rnd((N, C, H, W), 40))                    # many exact zeros: ties inside windows
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    gy = rnd(tuple(y_ref.shape), 41)
+    (y_ref * gy).sum().backward()
+    xg = nhwc(x).to(dev)
+    y = cv.maxpool_fwd(xg)
+    assert torch.equal(nchw(y).cpu(), y_ref.detach())
+    dx = cv.maxpool_bwd(xg, nhwc(gy).to(dev), relu_mask=False)
+    close(nchw(dx), xr.grad, 1e-6)
+    dxm = cv.maxpool_bwd(xg, nhwc(gy).to(dev), relu_mask=True)
+    close(nchw(dxm), xr.grad * (x > 0), 1e-6)
+
+
+def test_colsum(cv, dev):
+    g = rnd((3, 7, 11, 40), 50)
+    close(cv.colsum(g.to(dev)), g.reshape(-1, 40).sum(0), 1e-5)
+    close(cv.colsum(g.to(dev), C=36), g.reshape(-1, 40)[:, :36].sum(0), 1e-5)
+
+
+def test_layer_shapes_of_the_benchmark_config(cv, dev):
+    """The dominant benchmark shape (3x3 256->256 on a P3-sized map, B=1 slice of cfg2) against torch CPU."""
+    x = rnd((1, 256, 135, 240), 60)
+    w = rnd((256, 256, 3, 3), 61, (2.0 / 2304) ** 0.5)
+    b = rnd((256,), 62, 0.1)
+    want = F.relu(F.conv2d(x, w, b, 1, 1))
+    y = cv.fprop(nhwc(x).to(dev), cv.pack_weights(w.to(dev), 0), 256, 3, 1, 1, shift=b.to(dev), act=cv.ACT_RELU)
+    close(nchw(y), want)
