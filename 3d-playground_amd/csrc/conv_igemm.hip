@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
             const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
             const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
             const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
-            ra[i] = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((int64_t)ih * d.Wi + iw) * d.Cin + c0)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((int64_t)ih * d.Wi + iw) * d.Cin + c0)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
         __syncthreads();
     }
 
-    // ---- epilogue: out = act(scale[c]*acc + shift[c] + add) * (mask > 0)
+    // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add; act; [mask after]
     // accumulator element e of lane l: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
     const bool dense_y = d.y_batch_stride == (int64_t)HoWo * d.Cout;
 #pragma unroll
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
                     rem = (int)(m - (int64_t)n * HoWo);
                     off = (int64_t)n * d.y_batch_stride + (int64_t)rem * d.Cout + col;
                 }
+                if (d.mask_mode == 1) v = mask[off] > 0.f ? v : 0.f;
                 if (d.add_mode == 1) {
                     v += add[dense_y ? off : ((int64_t)n * d.add_batch_stride + (int64_t)rem * d.Cout + col)];
                 } else if (d.add_mode == 2) {               // nearest x2 upsample of [N,Ha,Wa,Cout], cropped (D/model.py:88-108)
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
                 }
                 if (d.act == 1) v = fmaxf(v, 0.f);
                 else if (d.act == 2) v = 1.0f / (1.0f + expf(-v));
-                if (mask != nullptr) v = mask[off] > 0.f ? v : 0.f;
+                if (d.mask_mode == 2) v = mask[off] > 0.f ? v : 0.f;
                 y[off] = v;
             }
         }
@@ -197,6 +200,7 @@ static int check_desc(const rn_conv_desc *d) {
     if (d->Cin < 4 || (d->Cin & 3)) return RN_EINVAL;                     // 16-byte chunks must not straddle taps
     if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
     if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
+    if (d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;
     return RN_OK;
 }
 
@@ -205,6 +209,7 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     const int rc = check_desc(d);
     if (rc) return rc;
     if ((d->add_mode != 0) != (add != nullptr)) return RN_EINVAL;
+    if ((d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     hipStream_t s = (hipStream_t)stream;
     if (d->Cout <= 64) {                                                  // 256 x 64 tile: no wasted N half

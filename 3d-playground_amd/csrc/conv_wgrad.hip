@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct WgradArgs {
     const float *dy, *x;
     float *dw;
-    int ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad;
+    int ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu;
     int Kflat, Kpad;             // kh*kw*Cin and its round-up to 32
     int tiles_n;                 // number of N tiles
     int64_t pixels, per_split;   // K extent and K per grid.y slice (multiple of WK)
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
                 const int ih = oh * p.stride + fr - p.pad, iw = ow * p.stride + fs - p.pad;
                 if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
                     v = *reinterpret_cast<const float4 *>(p.x + (((int64_t)n * p.Hi + ih) * p.Wi + iw) * p.Cin + ci0);
+                if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             vb[i] = v;
         }
@@ -137,13 +138,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 }
 
 extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, int Hi, int Wi, int Cin, int Ho,
-                             int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream) {
+                             int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
         return RN_EINVAL;
     WgradArgs a;
     a.dy = dy; a.x = x; a.dw = dw; a.ldy = ldy;
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
-    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.in_relu = in_relu;
     a.Kflat = kh * kw * Cin;
     a.Kpad = (a.Kflat + 31) / 32 * 32;
     a.pixels = (int64_t)N * Ho * Wo;

@@ -235,22 +235,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     part[(int64_t)blockIdx.x * C + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int64_t nchunks, int C,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0;
+    double s = accumulate ? (double)out[c] : 0.0;
     for (int64_t k = 0; k < nchunks; ++k) s += part[k * C + c];
     out[c] = (float)s;
 }
 
-extern "C" int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, void *workspace, void *stream) {
+extern "C" int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, int accumulate, void *workspace,
+                         void *stream) {
     if (rows <= 0 || C <= 0 || ld < C) return RN_EINVAL;
     const int64_t nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
     float *part = reinterpret_cast<float *>(workspace);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nchunks, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, g,
                        rows, C, ld, part);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float *)part,
-                       nchunks, C, out);
+                       nchunks, C, out, accumulate);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -304,22 +305,26 @@ extern "C" int rn_relu_mask(float *g, const float *z, int64_t n, void *stream) {
 }
 
 __global__ void sigmoid_bwd_pad_kernel(const float *__restrict__ dy, const float *__restrict__ s, float *__restrict__ out,
-                                       int64_t rows, int C, int ld) {
+                                       int64_t rows, int64_t rpi, int C, int ld, int64_t bstride) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * ld) return;
     const int64_t r = i / ld;
     const int c = (int)(i - r * ld);
     float v = 0.f;
     if (c < C) {
-        v = dy[r * C + c];
-        if (s) { const float p = s[r * C + c]; v *= p * (1.0f - p); }
+        const int64_t b = r / rpi;
+        const int64_t src = b * bstride + (r - b * rpi) * C + c;
+        v = dy[src];
+        if (s) { const float p = s[src]; v *= p * (1.0f - p); }
     }
     out[i] = v;
 }
-extern "C" int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int64_t rows, int C, int ld, void *stream) {
+extern "C" int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int B, int64_t rows_per_image, int C, int ld,
+                                  int64_t src_batch_stride, void *stream) {
+    const int64_t rows = (int64_t)B * rows_per_image;
     if (rows <= 0 || C <= 0 || ld < C) return RN_EINVAL;
     hipLaunchKernelGGL(sigmoid_bwd_pad_kernel, dim3(rn_blocks(rows * ld, 256)), dim3(256), 0, (hipStream_t)stream, dy, s, out,
-                       rows, C, ld);
+                       rows, rows_per_image, C, ld, src_batch_stride);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -49,23 +49,24 @@ class ConvDesc(ctypes.Structure):
                 ("kh", c_i32), ("kw", c_i32),
                 ("a", c_i32), ("b", c_i32), ("p", c_i32), ("div_shift", c_i32),
                 ("act", c_i32), ("add_mode", c_i32), ("Ha", c_i32), ("Wa", c_i32),
+                ("mask_mode", c_i32), ("in_relu", c_i32),
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64)]
 
 
 SIGNATURES.update({
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp] + [c_i32] * 11 + [c_vp]),
+    "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp] + [c_i32] * 12 + [c_vp]),
     "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
     "rn_unpack_wgrad": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp] * 7),
     "rn_bn_fold": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rn_nchw_to_nhwc4": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "rn_maxpool_fwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
     "rn_maxpool_bwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
-    "rn_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "rn_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rn_colsum_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "rn_upsample_add_bwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
     "rn_relu_mask": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
-    "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp]),
     "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
 })
 

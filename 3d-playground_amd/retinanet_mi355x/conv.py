@@ -39,14 +39,14 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None):
 
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
-               act=ACT_NONE, y_batch_stride=None, add_batch_stride=None):
+               mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift)."""
     lib = _hip.load()
     N, Hi, Wi, Cin = x.shape
     Ho, Wo, Cout, kh, kw, a, b, p, ds = geom
     d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p, ds, act, add_mode, add_hw[0], add_hw[1],
-                 Hi * Wi * Cin, Ho * Wo * Cout if y_batch_stride is None else y_batch_stride,
+                 (mask_mode if mask is not None else 0), int(in_relu), Hi * Wi * Cin, Ho * Wo * Cout if y_batch_stride is None else y_batch_stride,
                  (Ho * Wo * Cout if add_mode == 1 else add_hw[0] * add_hw[1] * Cout) if add_batch_stride is None
                  else add_batch_stride)
     _hip.check(lib.rn_conv_igemm(ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale),
@@ -70,13 +70,14 @@ def dgrad(dy, w_packed_dgrad, in_hw, cin, k, stride, pad, **kw):
     return conv_igemm(dy, w_packed_dgrad, dx, (Hi, Wi, cin, k, k, 1, -1, pad, stride.bit_length() - 1), **kw)
 
 
-def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None):
+def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False):
     """dw[Cout][Kpad] += wgrad(dy, x).  dy [N,Ho,Wo,ldy] (ldy >= cout), x [N,Hi,Wi,Cin]."""
     lib = _hip.load()
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
     _hip.check(lib.rn_conv_wgrad(dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Cin, Ho, Wo, cout, k,
-                                 k if kw_pad is None else kw_pad, stride, pad, _hip.stream()), "rn_conv_wgrad")
+                                 k if kw_pad is None else kw_pad, stride, pad, int(in_relu), _hip.stream()),
+               "rn_conv_wgrad")
     return dw
 
 
@@ -135,15 +136,18 @@ def maxpool_bwd(x, dy, relu_mask=True):
     return dx
 
 
-def colsum(g, C=None):
-    """Column sums of a [..., ld] tensor over all leading dims, first C columns."""
+def colsum(g, C=None, out=None):
+    """Column sums of a [..., ld] tensor over all leading dims, first C columns; ``out`` given = accumulate."""
     lib = _hip.load()
     ld = g.shape[-1]
     C = ld if C is None else C
     rows = g.numel() // ld
     ws = torch.empty(lib.rn_colsum_workspace_bytes(rows, C), dtype=torch.uint8, device=g.device)
-    out = torch.empty(C, dtype=torch.float32, device=g.device)
-    _hip.check(lib.rn_colsum(g.data_ptr(), rows, C, ld, out.data_ptr(), ws.data_ptr(), _hip.stream()), "rn_colsum")
+    acc = out is not None
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=g.device)
+    _hip.check(lib.rn_colsum(g.data_ptr(), rows, C, ld, out.data_ptr(), int(acc), ws.data_ptr(), _hip.stream()),
+               "rn_colsum")
     return out
 
 
@@ -161,13 +165,14 @@ def relu_mask_(g, z):
     return g
 
 
-def sigmoid_bwd_pad(dy, s, C, ld):
-    """dy [rows, C] (+ sigmoid output s or None) -> [rows, ld] zero-padded, multiplied by s(1-s)."""
+def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, device):
+    """Gradient slice of a head output (B images, rows_per_image pixels of C channels each, images
+    src_batch_stride floats apart; raw device pointers) -> dense [B*rows_per_image, ld], zero-padded channels,
+    multiplied by s(1-s) when the sigmoid output pointer is given."""
     lib = _hip.load()
-    rows = dy.numel() // C
-    out = torch.empty((rows, ld), dtype=torch.float32, device=dy.device)
-    _hip.check(lib.rn_sigmoid_bwd_pad(dy.data_ptr(), _hip.ptr(s), out.data_ptr(), rows, C, ld, _hip.stream()),
-               "rn_sigmoid_bwd_pad")
+    out = torch.empty((B * rows_per_image, ld), dtype=torch.float32, device=device)
+    _hip.check(lib.rn_sigmoid_bwd_pad(dy_ptr, s_ptr, out.data_ptr(), B, rows_per_image, C, ld, src_batch_stride,
+                                      _hip.stream()), "rn_sigmoid_bwd_pad")
     return out
 
 

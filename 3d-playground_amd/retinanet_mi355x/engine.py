@@ -1,0 +1,345 @@
+"""Explicit forward / backward schedule of the detector over the HIP kernels.
+
+The reference wires ResNet -> PyramidFeatures -> RegressionModel / ClassificationModel -> Anchors -> FocalLoss
+out of torch modules (D/model.py:284-309) and lets torch autograd derive the backward pass.  Here the whole
+network is ONE autograd node: ``forward`` runs a fixed kernel schedule (NHWC activations, batch-norm / bias /
+residual / ReLU / sigmoid fused into conv epilogues, head outputs written straight into the concatenated
+[B,A,n] tensors, fused IoU+focal loss), ``backward`` runs the hand-written reverse schedule and hands back one
+gradient per parameter.  No per-layer autograd bookkeeping, no tracing compiler: plain launches on the current
+HIP stream in a fixed order, so a training step can be captured into a hipGraph and gradient buckets can be
+released to RCCL as soon as a layer's wgrad has retired (``grad_hook``).
+
+Backward identities used (frozen batch-norm folded as y = s*c + t, s = gamma*rstd, t = beta - mean*s):
+  g       = dL/dy masked by the ReLU of the layer output (mask fused into the producing dgrad's epilogue)
+  dx      = dgrad(g, s*W)                      (scale folded into the re-packed dgrad weights)
+  dW      = s * wgrad(g, x)
+  dbeta   = colsum(g)
+  dgamma  = (sum_k W[c,k] * wgrad(g,x)[c,k] - mean[c]*colsum(g)[c]) * rstd[c]
+            (because sum_p g*c = sum_k W*dWraw: the pre-BN conv output never has to be stored)
+"""
+import torch
+
+from . import _hip, arch, conv as cv, ops
+
+
+class Layer:
+    """One convolution with its fused batch-norm / bias, the per-step packed weights and gradient accumulators."""
+
+    def __init__(self, spec, kw_pad=None, cin_pad=None):
+        self.spec = spec
+        self.kw_pad = spec.k if kw_pad is None else kw_pad
+        self.cin_pad = spec.cin if cin_pad is None else cin_pad
+        self.cout_pad = (spec.cout + 31) // 32 * 32 if spec.cout % 4 else spec.cout
+        self.reset()
+
+    def reset(self):
+        self.wf = self.wd = self.scale = self.shift = self.rstd = self.mean = None
+        self.dw = self.cs = None
+
+    # ---- per-step preparation
+    def prepare(self, P, cache):
+        s = self.spec
+        w = P[s.name + ".weight"]
+        self.weight = w
+        self.wf = cache.get(("wf", s.name), w, lambda: cv.pack_weights(w, 0, kw_pad=self.kw_pad, c_pad=self.cin_pad))
+        if s.bn:
+            g, b = P[s.bn + ".weight"], P[s.bn + ".bias"]
+            self.mean = P[s.bn + ".running_mean"]
+            self.scale, self.shift, self.rstd = cache.get(
+                ("bn", s.bn), (g, b), lambda: cv.bn_fold(g, b, self.mean, P[s.bn + ".running_var"], arch.BN_EPS))
+        else:
+            self.scale = self.rstd = self.mean = None
+            self.shift = P[s.name + ".bias"].detach() if s.bias else None
+        self.wd = None
+        self.dw = self.cs = None
+
+    def dgrad_weights(self):
+        if self.wd is None:
+            self.wd = cv.pack_weights(self.weight, 1, scale=self.scale, c_pad=self.cout_pad)
+        return self.wd
+
+    # ---- forward
+    def fwd(self, x, act=cv.ACT_NONE, add=None, add_mode=0, add_hw=(0, 0), out=None, y_batch_stride=None, in_relu=False):
+        s = self.spec
+        N, Hi, Wi, _ = x.shape
+        Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
+        if out is None:
+            out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
+        cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
+                      shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
+                      y_batch_stride=y_batch_stride, in_relu=in_relu)
+        return out
+
+    # ---- backward
+    def bwd_params(self, g, x, in_relu=False):
+        """Accumulate wgrad(g, x) and colsum(g).  g: [N,Ho,Wo,ld] with ld >= cout."""
+        s = self.spec
+        if self.dw is None:
+            self.dw = torch.zeros_like(self.wf)
+        cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu)
+        self.cs = cv.colsum(g, C=s.cout, out=self.cs)
+
+    def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2):
+        s = self.spec
+        return cv.dgrad(g, self.dgrad_weights(), in_hw, s.cin, s.k, s.stride, s.pad, add=add,
+                        add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode)
+
+    def finish(self):
+        """-> {param name: gradient} once every contribution has been accumulated."""
+        s = self.spec
+        dweight, dgamma, dbeta = cv.unpack_wgrad(
+            self.dw, self.wf, tuple(self.weight.shape), kw_pad=self.kw_pad, c_pad=self.cin_pad, scale=self.scale,
+            mean=self.mean, rstd=self.rstd, colsum=self.cs, want_bn=bool(s.bn))
+        out = {s.name + ".weight": dweight}
+        if s.bn:
+            out[s.bn + ".weight"] = dgamma
+            out[s.bn + ".bias"] = dbeta
+        elif s.bias:
+            out[s.name + ".bias"] = dbeta
+        self.dw = self.cs = self.wd = None
+        return out
+
+
+class _Cache:
+    """Derived tensors (packed weights, folded batch-norm) keyed on the source parameters' identity and version,
+    so eval frames reuse them and a replaced or updated Parameter invalidates them."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, src, make):
+        srcs = src if isinstance(src, tuple) else (src,)
+        stamp = tuple((t.data_ptr(), t._version) for t in srcs)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        val = make()
+        self.store[key] = (stamp, val)
+        return val
+
+
+class Engine:
+    def __init__(self, arch_name, num_classes, n_reg):
+        self.arch = arch_name
+        self.num_classes = num_classes
+        self.n_reg = n_reg
+        self.kind = arch.LAYERS[arch_name][0]
+        self.cache = _Cache()
+        self.anchor_cache = {}
+        self.grad_hook = None                      # callable({name: grad}) as soon as a layer's gradients are final
+        # layers
+        self.layers = {}
+        self.blocks = []                            # [(prefix, [roles...])] in forward order
+        cur = None
+        for spec, role, pre in arch.backbone_convs(arch_name):
+            if role == "stem":
+                self.layers[spec.name] = Layer(spec, kw_pad=8, cin_pad=4)
+                continue
+            self.layers[spec.name] = Layer(spec)
+            if cur is None or cur[0] != pre:
+                cur = (pre, {})
+                self.blocks.append(cur)
+            cur[1][role] = self.layers[spec.name]
+        for spec in arch.fpn_convs(arch_name) + arch.head_convs("regressionModel", n_reg) + \
+                arch.head_convs("classificationModel", num_classes):
+            self.layers[spec.name] = Layer(spec)
+        self.param_names = [k for k, shp in arch.state_dict_shapes(arch_name, num_classes, n_reg).items()
+                            if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+
+    # ------------------------------------------------------------------------------------------- helpers
+    def anchors(self, H, W, device):
+        key = (H, W, str(device))
+        if key not in self.anchor_cache:
+            self.anchor_cache[key] = ops.anchors(H, W, device)
+        return self.anchor_cache[key]
+
+    def _prepare(self, P):
+        for L in self.layers.values():
+            L.prepare(P, self.cache)
+
+    # ------------------------------------------------------------------------------------------- forward
+    def forward(self, P, img, save):
+        """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None)."""
+        _hip.need_gpu(img)
+        Ls = self.layers
+        self._prepare(P)
+        B, _, H, W = img.shape
+        S = {} if save else None
+        x4 = cv.nchw_to_nhwc4(img)
+        stem = Ls["conv1"].fwd(x4, act=cv.ACT_RELU)
+        x = cv.maxpool_fwd(stem)
+        if save:
+            S["x4"], S["stem"], S["pool"] = x4, stem, x
+            S["blocks"] = []
+        feats = {}
+        for pre, roles in self.blocks:
+            xin = x
+            t1 = roles["conv1"].fwd(xin, act=cv.ACT_RELU)
+            res = roles["down"].fwd(xin) if "down" in roles else xin
+            if self.kind == "basic":
+                t2 = None
+                x = roles["conv2"].fwd(t1, act=cv.ACT_RELU, add=res, add_mode=1)
+            else:
+                t2 = roles["conv2"].fwd(t1, act=cv.ACT_RELU)
+                x = roles["conv3"].fwd(t2, act=cv.ACT_RELU, add=res, add_mode=1)
+            if save:
+                S["blocks"].append((xin, t1, t2, x))
+            feats[pre.split(".")[0]] = x
+        c3, c4, c5 = feats["layer2"], feats["layer3"], feats["layer4"]
+        # ---- FPN (D/model.py:84-117)
+        p5lat = Ls["fpn.P5_1"].fwd(c5)
+        p5 = Ls["fpn.P5_2"].fwd(p5lat)
+        p4sum = Ls["fpn.P4_1"].fwd(c4, add=p5lat, add_mode=2, add_hw=(p5lat.shape[1], p5lat.shape[2]))
+        p4 = Ls["fpn.P4_2"].fwd(p4sum)
+        p3sum = Ls["fpn.P3_1"].fwd(c3, add=p4sum, add_mode=2, add_hw=(p4sum.shape[1], p4sum.shape[2]))
+        p3 = Ls["fpn.P3_2"].fwd(p3sum)
+        p6 = Ls["fpn.P6"].fwd(c5)
+        p7 = Ls["fpn.P7_2"].fwd(p6, in_relu=True)
+        pyramid = [p3, p4, p5, p6, p7]
+        if save:
+            S["fpn"] = (c3, c4, c5, p5lat, p4sum, p3sum, p6)
+            S["pyramid"] = pyramid
+        # ---- heads: towers share weights across levels; outputs land in their slice of [B, A, n]
+        counts = [f.shape[1] * f.shape[2] * arch.NUM_ANCHORS for f in pyramid]
+        A = sum(counts)
+        reg = torch.empty((B, A, self.n_reg), dtype=torch.float32, device=img.device)
+        cls = torch.empty((B, A, self.num_classes), dtype=torch.float32, device=img.device)
+        if save:
+            S["towers"] = {"regressionModel": [], "classificationModel": []}
+            S["counts"] = counts
+        for prefix, out, width, act in (("regressionModel", reg, self.n_reg, cv.ACT_NONE),
+                                        ("classificationModel", cls, self.num_classes, cv.ACT_SIGMOID)):
+            off = 0
+            for f, cnt in zip(pyramid, counts):
+                t = f
+                acts = []
+                for i in range(1, 5):
+                    t = Ls["%s.conv%d" % (prefix, i)].fwd(t, act=cv.ACT_RELU)
+                    acts.append(t)
+                view = out.view(B, -1)[:, off * width:]
+                Ls[prefix + ".output"].fwd(t, act=act, out=view, y_batch_stride=A * width)
+                off += cnt
+                if save:
+                    S["towers"][prefix].append(acts)
+        return reg, cls, S
+
+    # ------------------------------------------------------------------------------------------- backward
+    def backward(self, S, dreg, dcls, cls):
+        """dreg [B,A,n_reg], dcls [B,A,C] (gradient w.r.t. the post-sigmoid classification) -> {param: grad}."""
+        Ls = self.layers
+        grads = {}
+
+        def done(layer):
+            g = layer.finish()
+            grads.update(g)
+            if self.grad_hook is not None:
+                self.grad_hook(g)
+
+        pyramid, counts = S["pyramid"], S["counts"]
+        B = dreg.shape[0]
+        A = dreg.shape[1]
+        dpyr = [None] * 5
+        # ---- heads
+        for prefix, dout, width, sig in (("regressionModel", dreg, self.n_reg, None),
+                                         ("classificationModel", dcls, self.num_classes, cls)):
+            Lout = Ls[prefix + ".output"]
+            tower = [Ls["%s.conv%d" % (prefix, i)] for i in range(1, 5)]
+            off = 0
+            for li, (f, cnt) in enumerate(zip(pyramid, counts)):
+                acts = S["towers"][prefix][li]
+                Hh, Ww = f.shape[1], f.shape[2]
+                byte_off = 4 * off * width
+                g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
+                                       B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device)
+                g = g.view(B, Hh, Ww, Lout.cout_pad)
+                Lout.bwd_params(g, acts[3])
+                g = Lout.bwd_data(g, (Hh, Ww), mask=acts[3])
+                for i in (3, 2, 1):
+                    tower[i].bwd_params(g, acts[i - 1])
+                    g = tower[i].bwd_data(g, (Hh, Ww), mask=acts[i - 1])
+                tower[0].bwd_params(g, f)
+                dpyr[li] = tower[0].bwd_data(g, (Hh, Ww), add=dpyr[li])
+                off += cnt
+                acts.clear()
+            done(Lout)
+            for L in reversed(tower):
+                done(L)
+        # ---- FPN
+        c3, c4, c5, p5lat, p4sum, p3sum, p6 = S["fpn"]
+        dp3, dp4, dp5, dp6, dp7 = dpyr
+        hw = lambda t: (t.shape[1], t.shape[2])
+        L = Ls["fpn.P7_2"]
+        L.bwd_params(dp7, p6, in_relu=True)
+        dp6 = L.bwd_data(dp7, hw(p6), add=dp6, mask=p6, mask_mode=1)     # d relu(p6) masked, heads' part added raw
+        done(L)
+        L = Ls["fpn.P6"]
+        L.bwd_params(dp6, c5)
+        dc5 = L.bwd_data(dp6, hw(c5))
+        done(L)
+        L = Ls["fpn.P3_2"]
+        L.bwd_params(dp3, p3sum)
+        dp3sum = L.bwd_data(dp3, hw(p3sum))
+        done(L)
+        L = Ls["fpn.P3_1"]
+        L.bwd_params(dp3sum, c3)
+        dc3 = L.bwd_data(dp3sum, hw(c3))
+        done(L)
+        L = Ls["fpn.P4_2"]
+        L.bwd_params(dp4, p4sum)
+        dp4sum = L.bwd_data(dp4, hw(p4sum))
+        cv.upsample_add_bwd(dp3sum, dp4sum)
+        done(L)
+        L = Ls["fpn.P4_1"]
+        L.bwd_params(dp4sum, c4)
+        dc4 = L.bwd_data(dp4sum, hw(c4))
+        done(L)
+        L = Ls["fpn.P5_2"]
+        L.bwd_params(dp5, p5lat)
+        dp5lat = L.bwd_data(dp5, hw(p5lat))
+        cv.upsample_add_bwd(dp4sum, dp5lat)
+        done(L)
+        L = Ls["fpn.P5_1"]
+        L.bwd_params(dp5lat, c5)
+        dc5 = L.bwd_data(dp5lat, hw(c5), add=dc5, mask=c5)                # both consumers in: ReLU mask of C5
+        done(L)
+        # ---- backbone, last block first.  `g` = gradient w.r.t. the block's pre-ReLU output, already masked.
+        lateral = {"layer2": dc3, "layer3": dc4}            # extra consumer of these layers' outputs (FPN)
+        g = dc5
+        nblocks = len(self.blocks)
+        for bi in range(nblocks - 1, -1, -1):
+            pre, roles = self.blocks[bi]
+            xin, t1, t2, z = S["blocks"][bi]
+            S["blocks"][bi] = None
+            in_hw = hw(xin)
+            last = roles["conv2"] if self.kind == "basic" else roles["conv3"]
+            tin = t1 if self.kind == "basic" else t2
+            last.bwd_params(g, tin)
+            gt = last.bwd_data(g, hw(tin), mask=tin)
+            done(last)
+            if self.kind != "basic":
+                roles["conv2"].bwd_params(gt, t1)
+                gt = roles["conv2"].bwd_data(gt, hw(t1), mask=t1)
+                done(roles["conv2"])
+            # gradient reaching the block input: conv1 path + residual path (+ FPN lateral on layer outputs)
+            layer_name = pre.split(".")[0]
+            first_of_layer = pre.endswith(".0")
+            extra = None
+            if first_of_layer and bi > 0:
+                prev_layer = self.blocks[bi - 1][0].split(".")[0]
+                extra = lateral.get(prev_layer)
+            if "down" in roles:
+                roles["down"].bwd_params(g, xin)
+                dres = roles["down"].bwd_data(g, in_hw, add=extra)
+                done(roles["down"])
+            else:
+                dres = g if extra is None else cv.add_(extra, g)
+            roles["conv1"].bwd_params(gt, xin)
+            # the block input is a ReLU output (previous block) except for the very first block (max-pool output)
+            g = roles["conv1"].bwd_data(gt, in_hw, add=dres, mask=xin if bi > 0 else None)
+            done(roles["conv1"])
+            del layer_name
+        # ---- stem
+        gstem = cv.maxpool_bwd(S["stem"], g, relu_mask=True)
+        Ls["conv1"].bwd_params(gstem, S["x4"])
+        done(Ls["conv1"])
+        return grads

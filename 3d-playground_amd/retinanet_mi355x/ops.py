@@ -278,6 +278,29 @@ def postprocess_2d(cls, boxes4):
     return [torch.cat(out_s), torch.cat(out_c), torch.cat(out_b)]
 
 
+def nms(boxes, scores, iou_threshold, idxs=None):
+    """torchvision.ops.nms / batched_nms (D/model.py:19-57) on device: int64 keep indices, decreasing score."""
+    lib = _hip.load()
+    _hip.need_gpu(boxes, scores, idxs)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if n > NMS_MAX:
+        raise RuntimeError("on-device NMS orders its candidates in LDS and takes at most %d boxes, got %d" % (NMS_MAX, n))
+    boxes, scores = _hip.f32c(boxes), _hip.f32c(scores)
+    dev = boxes.device
+    ws = torch.empty(lib.rn_post_workspace_bytes(n, NMS_MAX), dtype=torch.uint8, device=dev)
+    cand = torch.arange(n, dtype=torch.int32, device=dev)
+    count = torch.tensor([n, 0], dtype=torch.int32, device=dev)
+    keep = torch.empty(n, dtype=torch.int32, device=dev)
+    cat = None if idxs is None else idxs.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        _hip.check(lib.rn_nms(boxes.data_ptr(), boxes.shape[1], 0, scores.data_ptr(), 1, cand.data_ptr(), _hip.ptr(cat),
+                              count[0:1].data_ptr(), n, float(iou_threshold), ws.data_ptr(), keep.data_ptr(),
+                              count[1:2].data_ptr(), _hip.stream()), "rn_nms")
+    return keep[:int(count[1])].long()
+
+
 # ------------------------------------------------------------------------------------------------ homography
 def _mats(m, device):
     if m is None:

@@ -134,7 +134,10 @@ int rn_im_to_state(const double *im, const float *heights, const double *H, cons
  *     acc = sum_{r<kh, s<kw, ci<Cin} x[n, ih, iw, ci] * w[c][r][s][ci]
  *     with  ih = (oh*a + p + r*b) >> div_shift  (contributes only if the numerator is >= 0, divisible by
  *     1 << div_shift and ih < Hi; same for iw),
- *     y = act(scale[c]*acc + shift[c] + add[...]) and, when mask != NULL, y = mask[...] > 0 ? y : 0.
+ *     v = scale[c]*acc + shift[c];  mask_mode 1: v = mask[...] > 0 ? v : 0;  v += add[...];  v = act(v);
+ *     mask_mode 2: v = mask[...] > 0 ? v : 0;  y = v.   (mask has the geometry of y: ReLU backward of the
+ *     tensor the gradient flows into, applied before or after other gradient contributions are added.)
+ *     in_relu != 0 applies max(x, 0) to the input as it is loaded (P7 = conv(ReLU(P6)), D/model.py:114-115).
  *   forward conv (stride st, padding pd):    a = st, b = +1, p = -pd, div_shift = 0
  *   data gradient of that conv:              a = 1,  b = -1, p = +pd, div_shift = log2(st), x = dY, and
  *                                            w packed as [Cin][kh][kw][Cout] (rn_pack_weights mode 1)
@@ -151,6 +154,8 @@ typedef struct rn_conv_desc {
     int act;                       /* 0 none, 1 ReLU, 2 sigmoid */
     int add_mode;                  /* 0 none, 1 same geometry, 2 nearest-upsample x2 */
     int Ha, Wa;
+    int mask_mode;                 /* 0 none, 1 before the add, 2 after the activation */
+    int in_relu;                   /* ReLU applied to x on load */
     int64_t x_batch_stride, y_batch_stride, add_batch_stride;
 } rn_conv_desc;
 
@@ -160,9 +165,9 @@ int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, 
 /* Weight gradient: dw[co][r][s][ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*st + r - pd, ow*st + s - pd, ci]
  * (fp32 atomics into a zeroed or previously accumulated [Cout][Kpad] buffer, same layout as the packed forward
  * weights; heads accumulate their five pyramid levels into one buffer).  dy: [N,Ho,Wo,Cout] with channel
- * stride ldy >= Cout (a padded copy is allowed), x: [N,Hi,Wi,Cin]. */
+ * stride ldy >= Cout (a padded copy is allowed), x: [N,Hi,Wi,Cin]; in_relu applies max(x,0) on load. */
 int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, int Hi, int Wi, int Cin,
-                  int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream);
+                  int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
 
 /* Weight packing.  src is the reference's OIHW parameter [Cout][Cin][kh][kw] (state_dict layout).
  *   mode 0 (forward):  dst[co][r][s][ci]          = src[co][ci][r][s]
@@ -188,22 +193,26 @@ int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const f
  *   rn_nchw_to_nhwc4:   image [N,3,H,W] -> [N,H,W,4] (4th channel 0) for the stem's 16-byte loads
  *   rn_maxpool_fwd/bwd: MaxPool2d(3, stride 2, pad 1) (D/model.py:216); bwd routes to the first maximum of each
  *                       window (torch semantics) and applies the stem ReLU mask (x > 0)
- *   rn_colsum:          out[c] = sum over rows of g[rows, ld] (bias / beta gradients), deterministic two-pass
+ *   rn_colsum:          out[c] (+)= sum over rows of g[rows, ld] (bias / beta gradients), deterministic two-pass;
+ *                       accumulate != 0 adds to out (shared heads sum their five pyramid levels)
  *   rn_upsample_add_bwd: dst[n,h,w,c] += sum_{dy,dx<2} src[n,2h+dy,2w+dx,c] within src bounds (FPN top-down bwd)
  *   rn_relu_mask:       g = (z > 0) ? g : 0 in place
- *   rn_sigmoid_bwd_pad: out[p][c<C] = dy[p][c] * s[p][c]*(1-s[p][c]) (s = sigmoid output, NULL = identity),
- *                       out[p][C..ld) = 0: head-output gradients padded to a channel count the GEMM accepts
+ *   rn_sigmoid_bwd_pad: out[b][p][c<C] = dy[b][p][c] * s[b][p][c]*(1-s[b][p][c]) (s = sigmoid output, NULL =
+ *                       identity), out[..][C..ld) = 0: a head-output gradient slice (rows_per_image rows per
+ *                       image, images src_batch_stride floats apart in dy and s) copied to a dense, channel-
+ *                       padded [B*rows_per_image, ld] matrix the GEMMs accept
  *   rn_add_inplace:     dst += src
  */
 int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *stream);
 int rn_maxpool_fwd(const float *x, float *y, int N, int H, int W, int C, int Ho, int Wo, void *stream);
 int rn_maxpool_bwd(const float *x, const float *dy, float *dx, int N, int H, int W, int C, int Ho, int Wo,
                    int relu_mask, void *stream);
-int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, void *workspace, void *stream);
+int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, int accumulate, void *workspace, void *stream);
 int64_t rn_colsum_workspace_bytes(int64_t rows, int C);
 int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *stream);
 int rn_relu_mask(float *g, const float *z, int64_t n, void *stream);
-int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int64_t rows, int C, int ld, void *stream);
+int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int B, int64_t rows_per_image, int C, int ld,
+                       int64_t src_batch_stride, void *stream);
 int rn_add_inplace(float *dst, const float *src, int64_t n, void *stream);
 
 #ifdef __cplusplus

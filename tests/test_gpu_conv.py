@@ -145,6 +145,17 @@ def test_residual_block_epilogues(cv, dev):
     wd = cv.pack_weights(w.to(dev), 1, scale=scale_c.to(dev))
     dx = cv.dgrad(g, wd, (H, W), C, 3, 1, 1, add=nhwc(other).to(dev), add_mode=1, mask=nhwc(zmask).to(dev))
     close(nchw(dx), want)
+    # mask applied before the add (P6: heads' gradient added unmasked to the masked P7 contribution)
+    dx1 = cv.dgrad(g, wd, (H, W), C, 3, 1, 1, add=nhwc(other).to(dev), add_mode=1, mask=nhwc(zmask).to(dev), mask_mode=1)
+    close(nchw(dx1), g_ref_x * (zmask > 0) + other)
+    # ReLU-on-load of the input (P7 = conv(ReLU(P6)))
+    y_in = cv.fprop(xg, wp, 128, 3, 1, 1, in_relu=True)
+    close(nchw(y_in), F.conv2d(F.relu(x), w, None, 1, 1))
+    dwr = torch.zeros_like(wp)
+    cv.wgrad(g, xg, dwr, 128, 3, 1, 1, in_relu=True)
+    wr2 = w.clone().requires_grad_(True)
+    (F.conv2d(F.relu(x), wr2, None, 1, 1) * g_ref).sum().backward()
+    close(cv.unpack_wgrad(dwr, wp, tuple(w.shape))[0], wr2.grad)
 
 
 def test_fpn_upsample_add_crop(cv, dev):
@@ -190,11 +201,17 @@ def test_head_output_into_concat_buffer(cv, dev):
         off += h * wd * 9
     close(out, want)
     # sigmoid backward + channel padding for the dgrad/wgrad GEMMs
-    dy = rnd((N, 5, 7, 9 * C), 34).to(dev)
-    s = out[:, :5 * 7 * 9].reshape(N, 5, 7, 9 * C).contiguous()
-    pad = cv.sigmoid_bwd_pad(dy, s, 9 * C, 96)
-    wantp = F.pad(dy * s * (1 - s), (0, 96 - 9 * C)).reshape(-1, 96)
+    dy = rnd((N, A, C), 34).to(dev)
+    rows = 5 * 7
+    pad = cv.sigmoid_bwd_pad(dy.data_ptr(), out.data_ptr(), N, rows, 9 * C, 96, A * C, dev)
+    lvl = lambda t: t[:, :rows * 9].reshape(N, rows, 9 * C)
+    wantp = F.pad(lvl(dy) * lvl(out) * (1 - lvl(out)), (0, 96 - 9 * C)).reshape(-1, 96)
     close(pad, wantp)
+    # second level: pointer offset into the concatenated tensors, identity (regression-style) variant
+    rows2 = 3 * 4
+    pad2 = cv.sigmoid_bwd_pad(dy.data_ptr() + 4 * rows * 9 * C, None, N, rows2, 9 * C, 80, A * C, dev)
+    want2 = F.pad(dy[:, rows * 9:].reshape(N, rows2, 9 * C), (0, 80 - 9 * C)).reshape(-1, 80)
+    close(pad2, want2)
 
 
 def test_maxpool_forward_backward_with_ties(cv, dev):
@@ -217,6 +234,9 @@ def test_colsum(cv, dev):
     g = rnd((3, 7, 11, 40), 50)
     close(cv.colsum(g.to(dev)), g.reshape(-1, 40).sum(0), 1e-5)
     close(cv.colsum(g.to(dev), C=36), g.reshape(-1, 40)[:, :36].sum(0), 1e-5)
+    acc = cv.colsum(g.to(dev))
+    cv.colsum(g.to(dev), out=acc)
+    close(acc, 2 * g.reshape(-1, 40).sum(0), 1e-5)
 
 
 def test_layer_shapes_of_the_benchmark_config(cv, dev):
