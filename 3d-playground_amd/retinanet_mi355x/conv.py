@@ -6,7 +6,7 @@ import ctypes
 
 import torch
 
-from . import _hip
+from . import _hip, prof
 
 ConvDesc = _hip.ConvDesc
 
@@ -39,7 +39,7 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None):
 
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
-               mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False):
+               mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift)."""
     lib = _hip.load()
@@ -49,8 +49,10 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
                  (mask_mode if mask is not None else 0), int(in_relu), Hi * Wi * Cin, Ho * Wo * Cout if y_batch_stride is None else y_batch_stride,
                  (Ho * Wo * Cout if add_mode == 1 else add_hw[0] * add_hw[1] * Cout) if add_batch_stride is None
                  else add_batch_stride)
-    _hip.check(lib.rn_conv_igemm(ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale),
-                                 _hip.ptr(shift), _hip.ptr(add), _hip.ptr(mask), _hip.stream()), "rn_conv_igemm")
+    rc = prof.timed("conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2", flops, lambda: lib.rn_conv_igemm(
+        ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
+        _hip.ptr(add), _hip.ptr(mask), _hip.stream()))
+    _hip.check(rc, "rn_conv_igemm")
     return y
 
 
@@ -70,14 +72,15 @@ def dgrad(dy, w_packed_dgrad, in_hw, cin, k, stride, pad, **kw):
     return conv_igemm(dy, w_packed_dgrad, dx, (Hi, Wi, cin, k, k, 1, -1, pad, stride.bit_length() - 1), **kw)
 
 
-def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False):
+def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0):
     """dw[Cout][Kpad] += wgrad(dy, x).  dy [N,Ho,Wo,ldy] (ldy >= cout), x [N,Hi,Wi,Cin]."""
     lib = _hip.load()
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
-    _hip.check(lib.rn_conv_wgrad(dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Cin, Ho, Wo, cout, k,
-                                 k if kw_pad is None else kw_pad, stride, pad, int(in_relu), _hip.stream()),
-               "rn_conv_wgrad")
+    rc = prof.timed("conv_wgrad", flops, lambda: lib.rn_conv_wgrad(
+        dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Cin, Ho, Wo, cout, k,
+        k if kw_pad is None else kw_pad, stride, pad, int(in_relu), _hip.stream()))
+    _hip.check(rc, "rn_conv_wgrad")
     return dw
 
 

@@ -67,8 +67,13 @@ class Layer:
             out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
         cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
                       shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
-                      y_batch_stride=y_batch_stride, in_relu=in_relu)
+                      y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo))
         return out
+
+    def flops(self, N, Ho, Wo):
+        """Algorithmic FLOPs of this convolution on N images (2*MACs; the same count prices fprop, dgrad, wgrad)."""
+        s = self.spec
+        return 2.0 * N * Ho * Wo * s.cout * s.cin * s.k * s.k
 
     # ---- backward
     def bwd_params(self, g, x, in_relu=False):
@@ -76,13 +81,15 @@ class Layer:
         s = self.spec
         if self.dw is None:
             self.dw = torch.zeros_like(self.wf)
-        cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu)
+        cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
+                 flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
         self.cs = cv.colsum(g, C=s.cout, out=self.cs)
 
     def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2):
         s = self.spec
         return cv.dgrad(g, self.dgrad_weights(), in_hw, s.cin, s.k, s.stride, s.pad, add=add,
-                        add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode)
+                        add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
+                        flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
 
     def finish(self):
         """-> {param name: gradient} once every contribution has been accumulated."""

@@ -174,7 +174,11 @@ class _NetFn(torch.autograd.Function):
         _hip.check(lib.rn_focal_loss_bwd(cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c), B, A, C,
                                          ann_c.shape[1], int(net.directional), ws.data_ptr(), g.data_ptr(),
                                          dcls.data_ptr(), dreg.data_ptr(), _hip.stream()), "rn_focal_loss_bwd")
+        red = net.__dict__.get("_reducer")
+        net._engine.grad_hook = red.hook if red is not None else None
         grads = net._engine.backward(S, dreg, dcls, cls)
+        if red is not None:
+            grads = red.finalize(grads)
         return (None, None, None) + tuple(grads[n] for n in net._engine.param_names)
 
 
@@ -239,6 +243,12 @@ class ResNet(nn.Module):
         for layer in self.modules():
             if isinstance(layer, nn.BatchNorm2d):
                 layer.eval()
+
+    def set_gradient_reducer(self, reducer):
+        """Attach a ``ddp.GradReducer``: gradients are then averaged over the process group inside backward,
+        bucket by bucket as the reverse schedule finishes layers (replaces nn.DataParallel,
+        train_detector_3D_angle.py:317)."""
+        self.__dict__["_reducer"] = reducer
 
     def _tensor_dict(self):
         d = dict(self.named_parameters())

@@ -1,0 +1,40 @@
+"""HIP-event timing of individual kernel launches on the current stream (used by bench.py for the roofline
+object: achieved = algorithmic work / measured launch duration)."""
+import collections
+
+import torch
+
+ACTIVE = None          # a KernelTimer while bench.py is measuring, else None
+
+
+class KernelTimer:
+    def __init__(self):
+        self.rows = []                 # (kind, work, start event, end event)
+
+    def launch(self, kind, work, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.rows.append((kind, work, e0, e1))
+        return out
+
+    def summary(self):
+        """{kind: dict(launches, ms_total, ms_avg, work_total)} after a device sync."""
+        torch.cuda.synchronize()
+        agg = collections.OrderedDict()
+        for kind, work, e0, e1 in self.rows:
+            a = agg.setdefault(kind, {"launches": 0, "ms_total": 0.0, "work_total": 0.0})
+            a["launches"] += 1
+            a["ms_total"] += e0.elapsed_time(e1)
+            a["work_total"] += work
+        for a in agg.values():
+            a["ms_avg"] = a["ms_total"] / max(a["launches"], 1)
+        return agg
+
+
+def timed(kind, work, fn):
+    if ACTIVE is None:
+        return fn()
+    return ACTIVE.launch(kind, work, fn)

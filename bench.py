@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the ResNet-50 directional 3D-RetinaNet at 1920x1080
+(BASELINE.json metric; workload = configs[1]: batch 8 per GPU, fp32, synthetic frames + 10 random GT boxes).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = what the reference's training loop does per iteration (train_detector_3D_angle.py:368-387):
+zero_grad, forward + loss, sum of the three losses, backward, clip_grad_norm_(0.1), Adam(lr 1e-4) step --
+all on inputs already resident in HBM.  With N > 1 every rank trains on its own 8 images (weak scaling) and
+gradients are averaged over RCCL inside backward (retinanet_mi355x.ddp).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel (fp32 MFMA implicit-GEMM conv, 128x128 tile): algorithmic FLOPs of its launches
+                inside the timed steps / their HIP-event durations, against the 157.3 TF fp32 MFMA peak
+  kernels       the same for the other timed kernels, plus the fused IoU+focal loss against the HBM roof
+  cpu_baseline  the CPU restatement (oracle/, torch CPU kernels = what the reference runs on a GPU-less host)
+                timed on this box's host cores on a bounded sample (1 image, forward+loss+backward), rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "3d-playground_amd"))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0             # HBM3E spec; 6.29 TB/s measured copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE cfg2: 8)")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
+    """Fused IoU + assignment + focal / smooth-L1 / VP forward at the benchmark shape, against the HBM roof.
+    Algorithmic bytes: cls B*A*C*4 + anchors A*16 + labels B*N*27*4."""
+    from retinanet_mi355x import _hip, ops, synth
+    lib = _hip.load()
+    A = ops.anchor_count(H, W)
+    cls, reg = synth.head_outputs(1, A, C, 12, seed=3)
+    cls = cls.to(dev).expand(B, A, C).contiguous()
+    reg = reg.to(dev).expand(B, A, 12).contiguous()
+    ann = synth.labels_dir(B, N, H, W, C, seed=1).to(dev)
+    anc = ops.anchors(H, W, dev)
+    ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=dev)
+    out = torch.empty(3, device=dev)
+
+    def run():
+        _hip.check(lib.rn_focal_loss_fwd(cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), B, A, C, N, 1,
+                                         ws.data_ptr(), out.data_ptr(), _hip.stream()), "rn_focal_loss_fwd")
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = B * A * C * 4 + A * 16 + B * N * 27 * 4
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "focal_kernel<dir,fwd> (+labels, finalize)", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "ms": round(ms, 4),
+            "algorithmic_bytes": nbytes}
+
+
+def cpu_baseline(arch, H, W):
+    """oracle/ (torch CPU kernels, reference algorithm) forward + loss + backward on ONE image of the workload."""
+    from oracle import model as omodel
+    from retinanet_mi355x import synth
+    threads = torch.get_num_threads()
+    sd = synth.state_dict(arch, 8, 12, seed=2)
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+              for k, v in sd.items()}
+    img = synth.frames(1, H, W, seed=0)
+    ann = synth.labels_dir(1, 10, H, W, 8, seed=1)
+    t0 = time.time()
+    losses = omodel.train_forward(img, ann, params, arch)
+    sum(l.mean() for l in losses).backward()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "1 image %dx%d, %s forward+loss+backward, torch CPU fp32 (%.1f s)" % (W, H, arch, dt)}
+
+
+def main():
+    args = parse()
+    from retinanet_mi355x import ddp, modules, prof, synth
+    rank, local, world = ddp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, H, W = args.batch, args.height, args.width
+
+    net = getattr(modules, args.arch)(num_classes=8)
+    net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))          # same weights on every rank
+    net = net.to(dev)
+    net.train()
+    net.freeze_bn()
+    if world > 1:
+        net.set_gradient_reducer(ddp.GradReducer())
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)                                    # train_detector_3D_angle.py:337
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    img = torch.randn(B, 3, H, W, generator=g, device=dev)                     # frames ~N(0,1), resident in HBM
+    ann = synth.labels_dir(B, 10, H, W, 8, seed=1 + rank).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        cls_l, reg_l, vp_l = net([img, ann])
+        loss = cls_l.mean() + reg_l.mean() + vp_l.mean()                       # train_detector_3D_angle.py:374-378
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.1)                            # :385
+        opt.step()                                                             # :387
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = None
+    if not args.no_kernel_timing:
+        timer = prof.ACTIVE = prof.KernelTimer()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.time() - t0
+    prof.ACTIVE = None
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        line = {"metric": "training images/sec at 1920x1080, ResNet-50 3D-RetinaNet", "value": round(value, 3),
+                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s directional 3D-RetinaNet, %dx%d synthetic frames, batch %d per GPU, 10 GT "
+                                       "boxes/image, fp32, fwd+loss+bwd+clip+Adam (BASELINE configs[1])"
+                                       % (args.arch, W, H, B),
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)}}
+        if timer is not None:
+            summ = timer.summary()
+            kernels = {}
+            for kind, a in summ.items():
+                tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12 if a["ms_total"] > 0 else 0.0
+                kernels[kind] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                                 "frac": round(tf / PEAK_F32_MFMA_TF, 4), "launches_per_step": a["launches"] // args.steps,
+                                 "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            r = dict(kernels[dom])
+            r["kernel"] = dom
+            r["traffic"] = None
+            line["roofline"] = r
+            kernels["focal_loss_fwd"] = loss_kernel_roofline(dev, B, H, W)
+            line["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
