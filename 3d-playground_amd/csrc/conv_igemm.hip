@@ -21,8 +21,12 @@
 // Grid:       1-D, tile id remapped so that consecutive tiles (neighbouring pixel rows, both Cout halves) share
 //             an XCD's L2: halo rows and the 9 taps of a 3x3 filter are re-read from L2, not HBM.
 //
+// Epilogue:   the 128x128 (256x64) accumulator tile is staged through the now idle LDS and leaves as float4 rows:
+//             out, residual / gradient addend and ReLU mask are all 16-byte coalesced accesses.
+//
 // Roofline: MFMA (fp32 157.3 TF).  Per K-step a wave issues 64 MFMAs (4096 cycles) against 16 ds_read_b128,
-// 8 global_load_dwordx4 and 8 ds_write_b128.
+// 8 global_load_dwordx4 and 8 ds_write_b128.  Small-K layers (1x1, Cin 64..128) are HBM-bound instead:
+// e.g. 1x1 64->256 at 270x480 moves 1.33 GB per 34 GFLOP.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,11 +39,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool GENERAL>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                             const float *__restrict__ w, float *__restrict__ y,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
-                                                            const float *__restrict__ add, const float *__restrict__ mask) {
+                                                            const float *__restrict__ add, const float *__restrict__ mask,
+                                                            const float *__restrict__ add2) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int AR = BM / 32, BR = BN / 32;              // rows of A / B each thread stages per K-step
     static_assert(WM * WN == 4, "4 waves");
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
             const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
             a_base[i] = x + (int64_t)n * d.x_batch_stride;
             a_h[i] = oh * d.a + d.p;
-            a_w[i] = ow * d.a + d.p;
+            a_w[i] = ow * d.a + d.p_w;
         } else {
             a_base[i] = x;
             a_h[i] = -(1 << 28);                           // fails every bounds test
@@ -154,43 +159,85 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
         __syncthreads();
     }
 
-    // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add; act; [mask after]
-    // accumulator element e of lane l: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
-    const bool dense_y = d.y_batch_stride == (int64_t)HoWo * d.Cout;
+    // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add (+ add2); act; [mask after]
+    // The accumulator tile goes through LDS (the staging buffers are free after the last barrier) so that global
+    // memory sees 16-byte accesses, 32 consecutive lanes on one 512-byte row segment: out, add and mask all move as
+    // float4.  Accumulator element e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile.
+    constexpr int LDT = BN + 4;
+    float *T = &lds[0][0];
+    static_assert(BM * LDT <= 2 * (BM + BN) * LDK, "output tile must fit the staging LDS");
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-        const bool col_ok = col < d.Cout;
-        const float sc = (scale != nullptr && col_ok) ? scale[col] : 1.f;
-        const float sh = (shift != nullptr && col_ok) ? shift[col] : 0.f;
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = (int64_t)m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m >= M || !col_ok) continue;
-                float v = acc[tm][tn][e] * sc + sh;
-                int64_t off;
-                int n = 0, rem = 0;
-                if (dense_y && d.add_mode != 2) {
-                    off = m * d.Cout + col;
-                } else {
-                    n = (int)(m / HoWo);
-                    rem = (int)(m - (int64_t)n * HoWo);
-                    off = (int64_t)n * d.y_batch_stride + (int64_t)rem * d.Cout + col;
-                }
-                if (d.mask_mode == 1) v = mask[off] > 0.f ? v : 0.f;
-                if (d.add_mode == 1) {
-                    v += add[dense_y ? off : ((int64_t)n * d.add_batch_stride + (int64_t)rem * d.Cout + col)];
-                } else if (d.add_mode == 2) {               // nearest x2 upsample of [N,Ha,Wa,Cout], cropped (D/model.py:88-108)
-                    const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
-                    v += add[(int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col];
-                }
-                if (d.act == 1) v = fmaxf(v, 0.f);
-                else if (d.act == 2) v = 1.0f / (1.0f + expf(-v));
-                if (d.mask_mode == 2) v = mask[off] > 0.f ? v : 0.f;
-                y[off] = v;
+            for (int e = 0; e < 16; ++e)
+                T[(wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] =
+                    acc[tm][tn][e];
+    __syncthreads();
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 16-byte chunks per tile row, rows per pass
+    const int c4 = tid % CPR;
+    const int col = n0 + 4 * c4;
+    if (col >= d.Cout) return;
+    const bool vec = (d.Cout & 3) == 0;                      // then col+3 < Cout and every row offset is 16-byte aligned
+    const int ncol = vec ? 4 : (d.Cout - col < 4 ? d.Cout - col : 4);
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < ncol && scale != nullptr) sc[j] = scale[col + j];
+        if (j < ncol && shift != nullptr) sh[j] = shift[col + j];
+    }
+    for (int r = tid / CPR; r < BM; r += RPP) {
+        const int64_t m = (int64_t)m0 + r;
+        if (m >= M) break;
+        const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+        float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]};
+        int64_t off, aoff = -1, a2off = -1;
+        if (!GENERAL) {
+            off = m * d.Cout + col;
+            if (d.add_mode == 1) aoff = off;
+        } else {
+            const int n = (int)(m / HoWo);
+            const int rem = (int)(m - (int64_t)n * HoWo);
+            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+            const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
+            const int64_t pix = (int64_t)ph * d.Wy + pw;
+            off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
+            if (d.add_mode == 1) aoff = (int64_t)n * d.add_batch_stride + pix * d.Cout + col;
+            else if (d.add_mode == 2)                        // nearest x2 upsample of [N,Ha,Wa,Cout], cropped (D/model.py:88-108)
+                aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col;
+            if (d.add2_mode == 3 && ((ph | pw) & 1) == 0)
+                a2off = (int64_t)n * d.add2_batch_stride + ((int64_t)(ph >> 1) * d.Wa2 + (pw >> 1)) * d.Cout + col;
+        }
+        float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            if (d.mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; }
+            if (aoff >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add + aoff); ad[0] = q.x; ad[1] = q.y; ad[2] = q.z; ad[3] = q.w; }
+            if (a2off >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2off); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < ncol && d.mask_mode != 0) mk[j] = mask[off + j];
+                if (j < ncol && aoff >= 0) ad[j] = add[aoff + j];
+                if (j < ncol && a2off >= 0) ad[j] += add2[a2off + j];
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u = v[j];
+            if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f;
+            u += ad[j];
+            if (d.act == 1) u = fmaxf(u, 0.f);
+            else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
+            if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f;
+            v[j] = u;
+        }
+        if (vec) {
+            *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ncol) y[off + j] = v[j];
         }
     }
 }
@@ -201,28 +248,36 @@ static int check_desc(const rn_conv_desc *d) {
     if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
     if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
     if (d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;
+    if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0 || (d->add2_mode != 0 && d->add2_mode != 3)) return RN_EINVAL;
+    if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
+    if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
     return RN_OK;
 }
 
 extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y, const float *scale,
-                             const float *shift, const float *add, const float *mask, void *stream) {
+                             const float *shift, const float *add, const float *mask, const float *add2, void *stream) {
     const int rc = check_desc(d);
     if (rc) return rc;
     if ((d->add_mode != 0) != (add != nullptr)) return RN_EINVAL;
     if ((d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
+    if ((d->add2_mode != 0) != (add2 != nullptr)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cout <= 64) {                                                  // 256 x 64 tile: no wasted N half
-        const int64_t tiles = (M + 255) / 256;
-        if (tiles > 0x7fffffff) return RN_EINVAL;
-        hipLaunchKernelGGL((conv_igemm_kernel<4, 1>), dim3((unsigned)tiles), dim3(256), 0, s, *d, x, w_packed, y, scale,
-                           shift, add, mask);
+    const bool dense = d->os == 1 && d->oo_h == 0 && d->oo_w == 0 && d->Hy == d->Ho && d->Wy == d->Wo &&
+                       d->y_batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->add_mode != 2 && d->add2_mode == 0 &&
+                       (d->add_mode == 0 || d->add_batch_stride == d->y_batch_stride);
+    const bool narrow = d->Cout <= 64;                                    // 256 x 64 tile: no wasted N half
+    const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (tiles > 0x7fffffff) return RN_EINVAL;
+    const dim3 grid((unsigned)tiles), block(256);
+#define RN_LAUNCH_IGEMM(WM, WN, G) \
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
+    if (narrow) {
+        if (dense) RN_LAUNCH_IGEMM(4, 1, false); else RN_LAUNCH_IGEMM(4, 1, true);
     } else {
-        const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
-        if (tiles > 0x7fffffff) return RN_EINVAL;
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, s, *d, x, w_packed, y, scale,
-                           shift, add, mask);
+        if (dense) RN_LAUNCH_IGEMM(2, 2, false); else RN_LAUNCH_IGEMM(2, 2, true);
     }
+#undef RN_LAUNCH_IGEMM
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -16,6 +16,9 @@
 // accumulate into the same buffer.  Blocks of one K-slice are adjacent in the grid so they stream the same dY /
 // X slabs through one XCD's L2.
 //
+// The column sums of dY (bias / batch-norm beta gradients, and the mean term of the gamma gradient) ride along:
+// the workgroups of N-tile 0 add up the dY chunks they stage anyway and finish with one atomic per channel.
+//
 // Roofline: MFMA (fp32 157.3 TF).
 #include "common.h"
 
@@ -25,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct WgradArgs {
     const float *dy, *x;
     float *dw;
+    float *colsum;               // [Cout] accumulated sum over pixels of dy, or NULL
     int ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu;
     int Kflat, Kpad;             // kh*kw*Cin and its round-up to 32
     int tiles_n;                 // number of N tiles
@@ -58,6 +62,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int fr = tap / p.kw, fs = tap - fr * p.kw;
     const bool b_col_ok = jcol < p.Kflat;
 
+    const bool do_cs = p.colsum != nullptr && (blockIdx.x % p.tiles_n) == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[PA], vb[PB];
     auto load_step = [&](int ks) {
         const int64_t kb = kbeg + (int64_t)ks * WK;
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             const int64_t pix = kb + ra0 + RA * i;
             va[i] = (a_col_ok && pix < kend) ? *reinterpret_cast<const float4 *>(p.dy + pix * p.ldy + m0 + 4 * ca)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (do_cs) { cs.x += va[i].x; cs.y += va[i].y; cs.z += va[i].z; cs.w += va[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -124,6 +131,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         __syncthreads();
     }
     if (nks == 0) return;
+    if (do_cs) {                                              // the last barrier of the loop freed the staging LDS
+        float4 *red = reinterpret_cast<float4 *>(lds[0]);
+        red[ra0 * CA + ca] = cs;
+        __syncthreads();
+        if (ra0 == 0) {
+            float4 t = red[ca];
+#pragma unroll
+            for (int j = 1; j < RA; ++j) { const float4 u = red[j * CA + ca]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            const int c = m0 + 4 * ca;
+            if (c + 0 < p.Cout) atomicAdd(p.colsum + c + 0, t.x);
+            if (c + 1 < p.Cout) atomicAdd(p.colsum + c + 1, t.y);
+            if (c + 2 < p.Cout) atomicAdd(p.colsum + c + 2, t.z);
+            if (c + 3 < p.Cout) atomicAdd(p.colsum + c + 3, t.w);
+        }
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -137,12 +159,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         }
 }
 
-extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, int Hi, int Wi, int Cin, int Ho,
-                             int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream) {
+extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
+                             int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
+                             void *stream) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
         return RN_EINVAL;
     WgradArgs a;
-    a.dy = dy; a.x = x; a.dw = dw; a.ldy = ldy;
+    a.dy = dy; a.x = x; a.dw = dw; a.colsum = colsum; a.ldy = ldy;
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.in_relu = in_relu;
     a.Kflat = kh * kw * Cin;

@@ -9,17 +9,26 @@
 
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ void pack_weights_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int kh, int kw,
-                                    int kw_pad, int c_pad, int mode, const float *__restrict__ scale, int rows, int Kpad) {
+                                    int kw_pad, int c_pad, int mode, const float *__restrict__ scale, int rows, int Kpad,
+                                    int r0, int nr, int s0, int ns) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)rows * Kpad) return;
     const int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
     const int tap = k / c_pad, c = k - tap * c_pad;
-    const int r = tap / kw_pad, s = tap - r * kw_pad;
+    int r = tap / kw_pad, s = tap - r * kw_pad;
+    bool in_filter = r < kh && s < kw;
+    if (mode == 2) {                        // tap subset: packed filter is nr x ns, source taps r0 + 2i, s0 + 2j
+        r = tap / ns;
+        s = tap - r * ns;
+        in_filter = r < nr;
+        r = r0 + 2 * r;
+        s = s0 + 2 * s;
+    }
     float v = 0.f;
-    if (r < kh && s < kw) {
+    if (in_filter) {
         if (mode == 0) {                    // row = co, c = ci
             if (c < Cin) v = src[(((int64_t)row * Cin + c) * kh + r) * kw + s];
-        } else {                            // row = ci, c = co
+        } else {                            // dgrad layouts: row = ci, c = co
             if (c < Cout) {
                 v = src[(((int64_t)c * Cin + row) * kh + r) * kw + s];
                 if (scale) v *= scale[c];
@@ -30,13 +39,15 @@ __global__ void pack_weights_kernel(const float *__restrict__ src, float *__rest
 }
 
 extern "C" int rn_pack_weights(const float *src, float *dst, int Cout, int Cin, int kh, int kw, int kw_pad, int c_pad,
-                               int mode, const float *scale, void *stream) {
-    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || kw_pad < kw || (c_pad & 3)) return RN_EINVAL;
+                               int mode, const float *scale, int r0, int nr, int s0, int ns, void *stream) {
+    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || kw_pad < kw || (c_pad & 3) || mode < 0 || mode > 2) return RN_EINVAL;
     if (c_pad < (mode == 0 ? Cin : Cout)) return RN_EINVAL;
+    if (mode == 2 && (nr <= 0 || ns <= 0 || r0 < 0 || s0 < 0 || r0 + 2 * (nr - 1) >= kh || s0 + 2 * (ns - 1) >= kw))
+        return RN_EINVAL;
     const int rows = mode == 0 ? Cout : Cin;
-    const int Kpad = (kh * kw_pad * c_pad + 31) / 32 * 32;
+    const int Kpad = ((mode == 2 ? nr * ns : kh * kw_pad) * c_pad + 31) / 32 * 32;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(rn_blocks((int64_t)rows * Kpad, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       dst, Cout, Cin, kh, kw, kw_pad, c_pad, mode, scale, rows, Kpad);
+                       dst, Cout, Cin, kh, kw, kw_pad, c_pad, mode, scale, rows, Kpad, r0, nr, s0, ns);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -128,8 +139,8 @@ extern "C" int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int 
 }
 
 // ------------------------------------------------------------------------------------------------ max-pool 3x3 s2 p1
-__global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W, int C4, int Ho, int Wo,
-                                   int64_t total) {
+__global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, uchar4 *__restrict__ arg, int H, int W,
+                                   int C4, int Ho, int Wo, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*Ho*Wo*C4
     if (i >= total) return;
     const int c = (int)(i % C4);
@@ -139,6 +150,7 @@ __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
     const int oh = (int)(t % Ho);
     const int64_t n = t / Ho;
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 a = make_uchar4(0, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int ih = oh * 2 - 1 + r;
@@ -148,67 +160,72 @@ __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restr
             const int iw = ow * 2 - 1 + s;
             if ((unsigned)iw >= (unsigned)W) continue;
             const float4 v = x[((n * H + ih) * W + iw) * C4 + c];
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            const unsigned char pos = (unsigned char)(3 * r + s);     // strict > keeps the first maximum
+            if (v.x > m.x) { m.x = v.x; a.x = pos; }
+            if (v.y > m.y) { m.y = v.y; a.y = pos; }
+            if (v.z > m.z) { m.z = v.z; a.z = pos; }
+            if (v.w > m.w) { m.w = v.w; a.w = pos; }
         }
     }
     y[i] = m;
+    if (arg) arg[i] = a;
 }
 
-extern "C" int rn_maxpool_fwd(const float *x, float *y, int N, int H, int W, int C, int Ho, int Wo, void *stream) {
+extern "C" int rn_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo,
+                              void *stream) {
     if (N <= 0 || (C & 3) || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RN_EINVAL;
     const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), H, W, C / 4, Ho, Wo, total);
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), reinterpret_cast<uchar4 *>(argmax), H,
+                       W, C / 4, Ho, Wo, total);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
 
-// Gather form: every input element looks at the (at most 4) windows that contain it and takes dy of those in
-// which it is the FIRST maximum in row-major window order (torch's max_pool2d backward routes there).
-__global__ void maxpool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int H, int W,
-                                   int C, int Ho, int Wo, int relu_mask, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*H*W*C
+// Gather form: every input element looks at the (at most 4) windows that contain it and takes dy of those whose
+// recorded first maximum is this element.
+__global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ dy, const uchar4 *__restrict__ arg,
+                                   float4 *__restrict__ dx, int H, int W, int C4, int Ho, int Wo, int relu_mask, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*H*W*C4
     if (i >= total) return;
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
     const int iw = (int)(t % W);
     t /= W;
     const int ih = (int)(t % H);
     const int64_t n = t / H;
-    const float v = x[i];
-    float g = 0.f;
-    if (!(relu_mask && !(v > 0.f))) {
-        // windows oh with 2*oh-1 <= ih <= 2*oh+1, i.e. ih/2 <= oh <= (ih+1)/2
-        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
-            if (oh >= Ho) continue;
-            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow >= Wo) continue;
-                // is (ih,iw) the first maximum of window (oh,ow)?
-                bool first = true;
-                for (int r = 0; r < 3 && first; ++r) {
-                    const int yh = oh * 2 - 1 + r;
-                    if ((unsigned)yh >= (unsigned)H) continue;
-                    for (int s = 0; s < 3; ++s) {
-                        const int xw = ow * 2 - 1 + s;
-                        if ((unsigned)xw >= (unsigned)W) continue;
-                        const float u = x[((n * H + yh) * W + xw) * C + c];
-                        const bool before = (yh < ih) || (yh == ih && xw < iw);
-                        if (u > v || (before && u == v)) { first = false; break; }
-                    }
-                }
-                if (first) g += dy[((n * Ho + oh) * Wo + ow) * C + c];
-            }
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows oh with 2*oh-1 <= ih <= 2*oh+1, i.e. ih/2 <= oh <= (ih+1)/2
+    for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+        if (oh >= Ho) continue;
+        const int r = ih - (oh * 2 - 1);
+        for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+            if (ow >= Wo) continue;
+            const unsigned char pos = (unsigned char)(3 * r + (iw - (ow * 2 - 1)));
+            const int64_t o = ((n * Ho + oh) * Wo + ow) * C4 + c;
+            const uchar4 a = arg[o];
+            const float4 d = dy[o];
+            if (a.x == pos) g.x += d.x;
+            if (a.y == pos) g.y += d.y;
+            if (a.z == pos) g.z += d.z;
+            if (a.w == pos) g.w += d.w;
         }
+    }
+    if (relu_mask) {
+        const float4 v = x[i];
+        g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
     }
     dx[i] = g;
 }
 
-extern "C" int rn_maxpool_bwd(const float *x, const float *dy, float *dx, int N, int H, int W, int C, int Ho, int Wo,
-                              int relu_mask, void *stream) {
-    if (N <= 0 || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RN_EINVAL;
-    const int64_t total = (int64_t)N * H * W * C;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W, C,
-                       Ho, Wo, relu_mask, total);
+extern "C" int rn_maxpool_bwd(const float *x, const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
+                              int Ho, int Wo, int relu_mask, void *stream) {
+    if (N <= 0 || (C & 3) || argmax == nullptr || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RN_EINVAL;
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy),
+                       reinterpret_cast<const uchar4 *>(argmax), reinterpret_cast<float4 *>(dx), H, W, C / 4, Ho, Wo, relu_mask,
+                       total);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -47,21 +47,23 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("N", c_i32), ("Hi", c_i32), ("Wi", c_i32), ("Cin", c_i32),
                 ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
                 ("kh", c_i32), ("kw", c_i32),
-                ("a", c_i32), ("b", c_i32), ("p", c_i32), ("div_shift", c_i32),
+                ("a", c_i32), ("b", c_i32), ("p", c_i32), ("p_w", c_i32), ("div_shift", c_i32),
                 ("act", c_i32), ("add_mode", c_i32), ("Ha", c_i32), ("Wa", c_i32),
                 ("mask_mode", c_i32), ("in_relu", c_i32),
+                ("os", c_i32), ("oo_h", c_i32), ("oo_w", c_i32), ("Hy", c_i32), ("Wy", c_i32),
+                ("add2_mode", c_i32), ("Ha2", c_i32), ("Wa2", c_i32), ("add2_batch_stride", c_i64),
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64)]
 
 
 SIGNATURES.update({
-    "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp] + [c_i32] * 12 + [c_vp]),
-    "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
+    "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 12 + [c_vp]),
+    "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp] + [c_i32] * 4 + [c_vp]),
     "rn_unpack_wgrad": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp] * 7),
     "rn_bn_fold": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rn_nchw_to_nhwc4": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "rn_maxpool_fwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
-    "rn_maxpool_bwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
+    "rn_maxpool_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
+    "rn_maxpool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
     "rn_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rn_colsum_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "rn_upsample_add_bwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),

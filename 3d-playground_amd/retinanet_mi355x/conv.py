@@ -21,8 +21,9 @@ def out_size(n, k, stride, pad):
     return (n + 2 * pad - k) // stride + 1
 
 
-def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None):
-    """OIHW parameter -> packed GEMM rows (mode 0: [Cout][kh][kw][Cin]; mode 1 (dgrad): [Cin][kh][kw][Cout]*scale)."""
+def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None):
+    """OIHW parameter -> packed GEMM rows (mode 0: [Cout][kh][kw][Cin]; mode 1 (dgrad): [Cin][kh][kw][Cout]*scale;
+    taps=(r0, nr, s0, ns): dgrad layout restricted to taps r0+2i, s0+2j -- one parity class of a stride-2 dgrad)."""
     lib = _hip.load()
     w = _hip.f32c(weight.detach())
     _hip.need_gpu(w, scale)
@@ -32,26 +33,38 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None):
         c = cin if mode == 0 else cout
         c_pad = (c + 3) // 4 * 4
     rows = cout if mode == 0 else cin
-    out = torch.empty((rows, kpad(kh, kw_pad, c_pad)), dtype=torch.float32, device=w.device)
+    r0, nr, s0, ns = (0, 0, 0, 0) if taps is None else taps
+    if taps is not None:
+        mode = 2
+    ktaps = nr * ns if taps is not None else kh * kw_pad
+    out = torch.empty((rows, (ktaps * c_pad + 31) // 32 * 32), dtype=torch.float32, device=w.device)
     _hip.check(lib.rn_pack_weights(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kw_pad, c_pad, mode,
-                                   _hip.ptr(scale), _hip.stream()), "rn_pack_weights")
+                                   _hip.ptr(scale), r0, nr, s0, ns, _hip.stream()), "rn_pack_weights")
     return out
 
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
-               mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0):
+               mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0,
+               out_map=None, add2=None):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
-    y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift)."""
+    y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift) with p an int or (p_rows, p_cols).
+    out_map = (os, oo_h, oo_w, Hy, Wy) stores output pixel (oh,ow) at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
+    tensor.  add2: [N,Ha2,Wa2,Cout] added at even stored positions (1x1 stride-2 shortcut gradient)."""
     lib = _hip.load()
     N, Hi, Wi, Cin = x.shape
     Ho, Wo, Cout, kh, kw, a, b, p, ds = geom
-    d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p, ds, act, add_mode, add_hw[0], add_hw[1],
-                 (mask_mode if mask is not None else 0), int(in_relu), Hi * Wi * Cin, Ho * Wo * Cout if y_batch_stride is None else y_batch_stride,
-                 (Ho * Wo * Cout if add_mode == 1 else add_hw[0] * add_hw[1] * Cout) if add_batch_stride is None
-                 else add_batch_stride)
+    p_h, p_w = p if isinstance(p, tuple) else (p, p)
+    os_, oo_h, oo_w, Hy, Wy = (1, 0, 0, Ho, Wo) if out_map is None else out_map
+    ybs = Hy * Wy * Cout if y_batch_stride is None else y_batch_stride
+    if add_batch_stride is None:
+        add_batch_stride = ybs if add_mode == 1 else add_hw[0] * add_hw[1] * Cout
+    a2 = (0, 0, 0, 0) if add2 is None else (3, add2.shape[1], add2.shape[2], add2.shape[1] * add2.shape[2] * Cout)
+    d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p_h, p_w, ds, act, add_mode, add_hw[0], add_hw[1],
+                 (mask_mode if mask is not None else 0), int(in_relu), os_, oo_h, oo_w, Hy, Wy,
+                 a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride)
     rc = prof.timed("conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2", flops, lambda: lib.rn_conv_igemm(
         ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
-        _hip.ptr(add), _hip.ptr(mask), _hip.stream()))
+        _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm")
     return y
 
@@ -65,20 +78,58 @@ def fprop(x, w_packed, cout, k, stride, pad, kw_pad=None, **kw):
 
 
 def dgrad(dy, w_packed_dgrad, in_hw, cin, k, stride, pad, **kw):
-    """Data gradient: dy [N,Ho,Wo,Cout(_pad)] -> dx [N,Hi,Wi,Cin]."""
+    """Data gradient, generic form: dy [N,Ho,Wo,Cout(_pad)] -> dx [N,Hi,Wi,Cin].  For stride 2 every tap is tried
+    at every input pixel and 3 of 4 fail the divisibility test (wasted MFMAs): prefer dgrad_s2_classes."""
     N = dy.shape[0]
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, cin), dtype=torch.float32, device=dy.device)
     return conv_igemm(dy, w_packed_dgrad, dx, (Hi, Wi, cin, k, k, 1, -1, pad, stride.bit_length() - 1), **kw)
 
 
-def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0):
-    """dw[Cout][Kpad] += wgrad(dy, x).  dy [N,Ho,Wo,ldy] (ldy >= cout), x [N,Hi,Wi,Cin]."""
+def s2_classes(k, pad):
+    """Parity classes of a stride-2 data gradient: [(ph, pw, (r0, nr, s0, ns), (dh0, dw0))] with taps r = r0+2i
+    contributing input row a + dh0 - i to output row 2a + ph."""
+    out = []
+    for ph in (0, 1):
+        r0 = (ph + pad) % 2
+        nr = len(range(r0, k, 2))
+        for pw in (0, 1):
+            s0 = (pw + pad) % 2
+            ns = len(range(s0, k, 2))
+            if nr and ns:
+                out.append((ph, pw, (r0, nr, s0, ns), ((ph + pad - r0) // 2, (pw + pad - s0) // 2)))
+    return out
+
+
+def dgrad_s2_classes(dy, class_weights, in_hw, cin, k, pad, flops=0.0, **kw):
+    """Stride-2 data gradient without wasted taps: one launch per output-parity class, each a stride-1 convolution
+    of dy with that class's tap subset (class_weights[i] from pack_weights(..., taps=...)), stored at the class's
+    strided positions.  add / mask (same geometry as dx) apply per class."""
+    N, Ho, Wo, _ = dy.shape
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, cin), dtype=torch.float32, device=dy.device)
+    classes = s2_classes(k, pad)
+    if len(classes) < 4:
+        dx.zero_()                                  # classes without taps (k = 1) receive no gradient
+    total_taps = sum(c[2][1] * c[2][3] for c in classes)
+    for (ph, pw, (r0, nr, s0, ns), (dh0, dw0)), wc in zip(classes, class_weights):
+        gh, gw = (Hi - ph + 1) // 2, (Wi - pw + 1) // 2
+        if gh <= 0 or gw <= 0:
+            continue
+        # input row = a + dh0 - i, input column = b + dw0 - j  (a = 1, b = -1, p = dh0, p_w = dw0)
+        conv_igemm(dy, wc, dx, (gh, gw, cin, nr, ns, 1, -1, (dh0, dw0), 0), out_map=(2, ph, pw, Hi, Wi),
+                   flops=flops * nr * ns / total_taps, **kw)
+    return dx
+
+
+def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0, colsum=None):
+    """dw[Cout][Kpad] += wgrad(dy, x) and, when given, colsum[Cout] += sum over pixels of dy.
+    dy [N,Ho,Wo,ldy] (ldy >= cout), x [N,Hi,Wi,Cin]."""
     lib = _hip.load()
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
     rc = prof.timed("conv_wgrad", flops, lambda: lib.rn_conv_wgrad(
-        dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Cin, Ho, Wo, cout, k,
+        dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), N, Hi, Wi, Cin, Ho, Wo, cout, k,
         k if kw_pad is None else kw_pad, stride, pad, int(in_relu), _hip.stream()))
     _hip.check(rc, "rn_conv_wgrad")
     return dw
@@ -121,21 +172,24 @@ def nchw_to_nhwc4(img):
     return out
 
 
-def maxpool_fwd(x):
+def maxpool_fwd(x, want_argmax=False):
+    """-> y, or (y, argmax uint8 [N,Ho,Wo,C]) when the backward pass will need it."""
     lib = _hip.load()
     N, H, W, C = x.shape
     Ho, Wo = out_size(H, 3, 2, 1), out_size(W, 3, 2, 1)
     y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    _hip.check(lib.rn_maxpool_fwd(x.data_ptr(), y.data_ptr(), N, H, W, C, Ho, Wo, _hip.stream()), "rn_maxpool_fwd")
-    return y
+    arg = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if want_argmax else None
+    _hip.check(lib.rn_maxpool_fwd(x.data_ptr(), y.data_ptr(), _hip.ptr(arg), N, H, W, C, Ho, Wo, _hip.stream()),
+               "rn_maxpool_fwd")
+    return (y, arg) if want_argmax else y
 
 
-def maxpool_bwd(x, dy, relu_mask=True):
+def maxpool_bwd(x, dy, argmax, relu_mask=True):
     lib = _hip.load()
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
-    _hip.check(lib.rn_maxpool_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, C, dy.shape[1], dy.shape[2],
-                                  int(relu_mask), _hip.stream()), "rn_maxpool_bwd")
+    _hip.check(lib.rn_maxpool_bwd(x.data_ptr(), dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(), N, H, W, C,
+                                  dy.shape[1], dy.shape[2], int(relu_mask), _hip.stream()), "rn_maxpool_bwd")
     return dx
 
 

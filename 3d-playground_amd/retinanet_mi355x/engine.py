@@ -54,8 +54,14 @@ class Layer:
         self.dw = self.cs = None
 
     def dgrad_weights(self):
+        """Packed dgrad weights (BN scale folded in); for a stride-2 k>1 layer: one tap subset per parity class."""
         if self.wd is None:
-            self.wd = cv.pack_weights(self.weight, 1, scale=self.scale, c_pad=self.cout_pad)
+            s = self.spec
+            if s.stride == 2 and s.k > 1:
+                self.wd = [cv.pack_weights(self.weight, 1, scale=self.scale, c_pad=self.cout_pad, taps=c[2])
+                           for c in cv.s2_classes(s.k, s.pad)]
+            else:
+                self.wd = cv.pack_weights(self.weight, 1, scale=self.scale, c_pad=self.cout_pad)
         return self.wd
 
     # ---- forward
@@ -81,15 +87,27 @@ class Layer:
         s = self.spec
         if self.dw is None:
             self.dw = torch.zeros_like(self.wf)
+            self.cs = torch.zeros(s.cout, dtype=torch.float32, device=g.device)
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
-                 flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
-        self.cs = cv.colsum(g, C=s.cout, out=self.cs)
+                 flops=self.flops(g.shape[0], g.shape[1], g.shape[2]), colsum=self.cs)
 
-    def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2):
+    def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2, add2=None):
         s = self.spec
-        return cv.dgrad(g, self.dgrad_weights(), in_hw, s.cin, s.k, s.stride, s.pad, add=add,
-                        add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
-                        flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
+        kw = dict(add=add, add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
+                  flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
+        if s.stride == 2 and s.k > 1:
+            assert add2 is None
+            return cv.dgrad_s2_classes(g, self.dgrad_weights(), in_hw, s.cin, s.k, s.pad, **kw)
+        return cv.dgrad(g, self.dgrad_weights(), in_hw, s.cin, s.k, s.stride, s.pad, add2=add2, **kw)
+
+    def bwd_data_compact(self, g):
+        """1x1 stride-2 shortcut: gradient on the OUTPUT grid only ([N,Ho,Wo,Cin]); it belongs at the even input
+        positions and is added there by the consumer's epilogue (add2), the odd positions get nothing."""
+        s = self.spec
+        assert s.k == 1 and s.stride == 2
+        N, Ho, Wo, _ = g.shape
+        out = torch.empty((N, Ho, Wo, s.cin), dtype=torch.float32, device=g.device)
+        return cv.conv_igemm(g, self.dgrad_weights(), out, (Ho, Wo, s.cin, 1, 1, 1, -1, 0, 0), flops=self.flops(N, Ho, Wo))
 
     def finish(self):
         """-> {param name: gradient} once every contribution has been accumulated."""
@@ -174,9 +192,12 @@ class Engine:
         S = {} if save else None
         x4 = cv.nchw_to_nhwc4(img)
         stem = Ls["conv1"].fwd(x4, act=cv.ACT_RELU)
-        x = cv.maxpool_fwd(stem)
         if save:
-            S["x4"], S["stem"], S["pool"] = x4, stem, x
+            x, pool_arg = cv.maxpool_fwd(stem, want_argmax=True)
+            S["x4"], S["stem"], S["pool_arg"] = x4, stem, pool_arg
+        else:
+            x = cv.maxpool_fwd(stem)
+        if save:
             S["blocks"] = []
         feats = {}
         for pre, roles in self.blocks:
@@ -334,19 +355,24 @@ class Engine:
             if first_of_layer and bi > 0:
                 prev_layer = self.blocks[bi - 1][0].split(".")[0]
                 extra = lateral.get(prev_layer)
+            dcompact = None
             if "down" in roles:
                 roles["down"].bwd_params(g, xin)
-                dres = roles["down"].bwd_data(g, in_hw, add=extra)
+                if roles["down"].spec.stride == 2 and roles["conv1"].spec.stride == 1:
+                    dcompact = roles["down"].bwd_data_compact(g)       # bottleneck: conv1 is 1x1 s1, takes add2
+                    dres = extra
+                else:
+                    dres = roles["down"].bwd_data(g, in_hw, add=extra)
                 done(roles["down"])
             else:
                 dres = g if extra is None else cv.add_(extra, g)
             roles["conv1"].bwd_params(gt, xin)
             # the block input is a ReLU output (previous block) except for the very first block (max-pool output)
-            g = roles["conv1"].bwd_data(gt, in_hw, add=dres, mask=xin if bi > 0 else None)
+            g = roles["conv1"].bwd_data(gt, in_hw, add=dres, mask=xin if bi > 0 else None, add2=dcompact)
             done(roles["conv1"])
             del layer_name
         # ---- stem
-        gstem = cv.maxpool_bwd(S["stem"], g, relu_mask=True)
+        gstem = cv.maxpool_bwd(S["stem"], g, S["pool_arg"], relu_mask=True)
         Ls["conv1"].bwd_params(gstem, S["x4"])
         done(Ls["conv1"])
         return grads

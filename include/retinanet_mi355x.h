@@ -133,13 +133,13 @@ int rn_im_to_state(const double *im, const float *heights, const double *H, cons
  * rn_conv_igemm computes, for every output pixel (n, oh, ow) and output channel c:
  *     acc = sum_{r<kh, s<kw, ci<Cin} x[n, ih, iw, ci] * w[c][r][s][ci]
  *     with  ih = (oh*a + p + r*b) >> div_shift  (contributes only if the numerator is >= 0, divisible by
- *     1 << div_shift and ih < Hi; same for iw),
+ *     1 << div_shift and ih < Hi; iw likewise from ow, s and p_w),
  *     v = scale[c]*acc + shift[c];  mask_mode 1: v = mask[...] > 0 ? v : 0;  v += add[...];  v = act(v);
  *     mask_mode 2: v = mask[...] > 0 ? v : 0;  y = v.   (mask has the geometry of y: ReLU backward of the
  *     tensor the gradient flows into, applied before or after other gradient contributions are added.)
  *     in_relu != 0 applies max(x, 0) to the input as it is loaded (P7 = conv(ReLU(P6)), D/model.py:114-115).
- *   forward conv (stride st, padding pd):    a = st, b = +1, p = -pd, div_shift = 0
- *   data gradient of that conv:              a = 1,  b = -1, p = +pd, div_shift = log2(st), x = dY, and
+ *   forward conv (stride st, padding pd):    a = st, b = +1, p = p_w = -pd, div_shift = 0
+ *   data gradient of that conv:              a = 1,  b = -1, p = p_w = +pd, div_shift = log2(st), x = dY, and
  *                                            w packed as [Cin][kh][kw][Cout] (rn_pack_weights mode 1)
  * add_mode 1: add has the geometry of y (residual / gradient accumulation); 2: add is [N,Ha,Wa,Cout] read at
  * (oh>>1, ow>>1) -- the FPN nearest-upsample + add, cropped to the output (D/model.py:88-108).
@@ -150,28 +150,42 @@ typedef struct rn_conv_desc {
     int N, Hi, Wi, Cin;            /* input  [N,Hi,Wi,Cin]; Cin % 4 == 0 */
     int Ho, Wo, Cout;              /* output [N,Ho,Wo,Cout] */
     int kh, kw;
-    int a, b, p, div_shift;
+    int a, b, p, p_w, div_shift;   /* p applies to rows, p_w to columns */
     int act;                       /* 0 none, 1 ReLU, 2 sigmoid */
     int add_mode;                  /* 0 none, 1 same geometry, 2 nearest-upsample x2 */
     int Ha, Wa;
     int mask_mode;                 /* 0 none, 1 before the add, 2 after the activation */
     int in_relu;                   /* ReLU applied to x on load */
+    int os, oo_h, oo_w, Hy, Wy;    /* output pixel (oh,ow) is stored at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
+                                      tensor (os = 1, offsets 0, Hy = Ho, Wy = Wo: dense).  add (mode 1) and mask
+                                      are read at the same place.  Used by the stride-2 data gradient, which is
+                                      computed per output-parity class. */
+    int add2_mode;                 /* 0 none, 3: add2 is [N,Ha2,Wa2,Cout], added where the stored position has
+                                      even row and column, read at (row/2, col/2): gradient of a 1x1 stride-2
+                                      shortcut (D/model.py:265-270) without materialising its zeros */
+    int Ha2, Wa2;
+    int64_t add2_batch_stride;
     int64_t x_batch_stride, y_batch_stride, add_batch_stride;
 } rn_conv_desc;
 
 int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
-                  const float *scale, const float *shift, const float *add, const float *mask, void *stream);
+                  const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
+                  void *stream);
 
 /* Weight gradient: dw[co][r][s][ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*st + r - pd, ow*st + s - pd, ci]
  * (fp32 atomics into a zeroed or previously accumulated [Cout][Kpad] buffer, same layout as the packed forward
  * weights; heads accumulate their five pyramid levels into one buffer).  dy: [N,Ho,Wo,Cout] with channel
- * stride ldy >= Cout (a padded copy is allowed), x: [N,Hi,Wi,Cin]; in_relu applies max(x,0) on load. */
-int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, int Hi, int Wi, int Cin,
-                  int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
+ * stride ldy >= Cout (a padded copy is allowed), x: [N,Hi,Wi,Cin]; in_relu applies max(x,0) on load.
+ * colsum (may be NULL): colsum[co] += sum over pixels of dy[.,co] -- the bias / batch-norm-beta gradient, fused
+ * because this kernel streams dy anyway. */
+int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
+                  int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
 
 /* Weight packing.  src is the reference's OIHW parameter [Cout][Cin][kh][kw] (state_dict layout).
  *   mode 0 (forward):  dst[co][r][s][ci]          = src[co][ci][r][s]
  *   mode 1 (dgrad):    dst[ci][r][s][co]          = src[co][ci][r][s] * scale[co]   (scale NULL = 1)
+ *   mode 2 (dgrad, tap subset): as mode 1 but only taps r = r0 + 2*i (i < nr), s = s0 + 2*j (j < ns) are
+ *                      packed, as an nr x ns filter: one output-parity class of a stride-2 data gradient
  * kw_pad >= kw and cin_pad >= Cin (forward) / cout_pad >= Cout (dgrad) give zero-filled padding of the tap and
  * channel dimensions (stem: 7x7x3 -> 7x8x4); rows are Kpad = roundup(kh*kw_pad*c_pad, 32) floats.
  * rn_unpack_wgrad converts an accumulated dw[Cout][Kpad] back to OIHW and applies the folded batch-norm:
@@ -179,7 +193,7 @@ int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, int N, in
  *   dgamma[co] = (sum_k w[co][k]*dw[co][k] - mean[co]*colsum[co]) * rstd[co],  dbeta[co] = colsum[co]
  * (any of dgamma/dbeta/scale may be NULL). */
 int rn_pack_weights(const float *src, float *dst, int Cout, int Cin, int kh, int kw, int kw_pad, int c_pad,
-                    int mode, const float *scale, void *stream);
+                    int mode, const float *scale, int r0, int nr, int s0, int ns, void *stream);
 int rn_unpack_wgrad(const float *dw, const float *w_packed, float *dweight, int Cout, int Cin, int kh, int kw,
                     int kw_pad, int c_pad, const float *scale, const float *mean, const float *rstd,
                     const float *colsum, float *dgamma, float *dbeta, void *stream);
@@ -191,8 +205,9 @@ int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const f
 
 /* Elementwise / data-movement kernels around the convolutions (all NHWC fp32):
  *   rn_nchw_to_nhwc4:   image [N,3,H,W] -> [N,H,W,4] (4th channel 0) for the stem's 16-byte loads
- *   rn_maxpool_fwd/bwd: MaxPool2d(3, stride 2, pad 1) (D/model.py:216); bwd routes to the first maximum of each
- *                       window (torch semantics) and applies the stem ReLU mask (x > 0)
+ *   rn_maxpool_fwd/bwd: MaxPool2d(3, stride 2, pad 1) (D/model.py:216); fwd also records (argmax may be NULL) the
+ *                       window position 3*r+s of the FIRST maximum, bwd routes dy there (torch semantics) and
+ *                       applies the stem ReLU mask (x > 0)
  *   rn_colsum:          out[c] (+)= sum over rows of g[rows, ld] (bias / beta gradients), deterministic two-pass;
  *                       accumulate != 0 adds to out (shared heads sum their five pyramid levels)
  *   rn_upsample_add_bwd: dst[n,h,w,c] += sum_{dy,dx<2} src[n,2h+dy,2w+dx,c] within src bounds (FPN top-down bwd)
@@ -204,9 +219,9 @@ int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const f
  *   rn_add_inplace:     dst += src
  */
 int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *stream);
-int rn_maxpool_fwd(const float *x, float *y, int N, int H, int W, int C, int Ho, int Wo, void *stream);
-int rn_maxpool_bwd(const float *x, const float *dy, float *dx, int N, int H, int W, int C, int Ho, int Wo,
-                   int relu_mask, void *stream);
+int rn_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo, void *stream);
+int rn_maxpool_bwd(const float *x, const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
+                   int Ho, int Wo, int relu_mask, void *stream);
 int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, int accumulate, void *workspace, void *stream);
 int64_t rn_colsum_workspace_bytes(int64_t rows, int C);
 int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *stream);

@@ -110,8 +110,9 @@ def test_stem_conv_bn_relu(cv, dev):
     g = nhwc(gy).to(dev).contiguous()
     cv.relu_mask_(g, y)
     dw = torch.zeros_like(wp)
-    cv.wgrad(g, x4, dw, 64, 7, 2, 3, kw_pad=8)
-    cs = cv.colsum(g)
+    cs = torch.zeros(64, device=dev)
+    cv.wgrad(g, x4, dw, 64, 7, 2, 3, kw_pad=8, colsum=cs)
+    close(cs, cv.colsum(g), 1e-5)
     dweight, dgamma, dbeta = cv.unpack_wgrad(dw, wp, (64, 3, 7, 7), kw_pad=8, c_pad=4, scale=scale, mean=mean.to(dev),
                                              rstd=rstd, colsum=cs, want_bn=True)
     close(dweight, wr.grad)
@@ -222,11 +223,12 @@ def test_maxpool_forward_backward_with_ties(cv, dev):
     gy = rnd(tuple(y_ref.shape), 41)
     (y_ref * gy).sum().backward()
     xg = nhwc(x).to(dev)
-    y = cv.maxpool_fwd(xg)
+    y, arg = cv.maxpool_fwd(xg, want_argmax=True)
     assert torch.equal(nchw(y).cpu(), y_ref.detach())
-    dx = cv.maxpool_bwd(xg, nhwc(gy).to(dev), relu_mask=False)
+    assert torch.equal(cv.maxpool_fwd(xg), y)
+    dx = cv.maxpool_bwd(xg, nhwc(gy).to(dev), arg, relu_mask=False)
     close(nchw(dx), xr.grad, 1e-6)
-    dxm = cv.maxpool_bwd(xg, nhwc(gy).to(dev), relu_mask=True)
+    dxm = cv.maxpool_bwd(xg, nhwc(gy).to(dev), arg, relu_mask=True)
     close(nchw(dxm), xr.grad * (x > 0), 1e-6)
 
 
@@ -247,3 +249,44 @@ def test_layer_shapes_of_the_benchmark_config(cv, dev):
     want = F.relu(F.conv2d(x, w, b, 1, 1))
     y = cv.fprop(nhwc(x).to(dev), cv.pack_weights(w.to(dev), 0), 256, 3, 1, 1, shift=b.to(dev), act=cv.ACT_RELU)
     close(nchw(y), want)
+
+
+@pytest.mark.parametrize("case", [(128, 96, 3, 1, 2, 17, 21), (64, 128, 3, 1, 1, 18, 20), (128, 128, 3, 1, 1, 1, 1)])
+def test_stride2_dgrad_by_parity_classes(cv, dev, case):
+    """Stride-2 data gradient as 4 tap-subset convolutions written to strided positions == the generic form,
+    with gradient accumulation and ReLU mask applied per class."""
+    cin, cout, k, pad, N, H, W = case
+    x = rnd((N, cin, H, W), 70)
+    w = rnd((cout, cin, k, k), 71, 0.05)
+    sc = rnd((cout,), 72, 0.2) + 1.0
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, w * sc[:, None, None, None], None, 2, pad)
+    gy = rnd(tuple(y.shape), 73)
+    (y * gy).sum().backward()
+    other, zmask = rnd((N, cin, H, W), 74), rnd((N, cin, H, W), 75)
+    want = (xr.grad + other) * (zmask > 0)
+    wcls = [cv.pack_weights(w.to(dev), 1, scale=sc.to(dev), taps=c[2]) for c in cv.s2_classes(k, pad)]
+    dx = cv.dgrad_s2_classes(nhwc(gy).to(dev), wcls, (H, W), cin, k, pad, add=nhwc(other).to(dev), add_mode=1,
+                             mask=nhwc(zmask).to(dev))
+    close(nchw(dx), want)
+
+
+def test_shortcut_1x1_stride2_gradient_added_at_even_positions(cv, dev):
+    """Bottleneck first block: d(input) = dgrad(conv1 1x1 s1) + lateral + [1x1 s2 shortcut gradient at even pixels],
+    masked -- the shortcut part stays on its compact grid (add2)."""
+    N, C, H, W, Cd = 2, 64, 13, 15, 128
+    x = rnd((N, C, H, W), 80)
+    w1 = rnd((32, C, 1, 1), 81, 0.1)
+    wd = rnd((Cd, C, 1, 1), 82, 0.1)
+    xr = x.clone().requires_grad_(True)
+    y1 = F.conv2d(xr, w1)
+    yd = F.conv2d(xr, wd, None, 2)
+    g1, gd = rnd(tuple(y1.shape), 83), rnd(tuple(yd.shape), 84)
+    ((y1 * g1).sum() + (yd * gd).sum()).backward()
+    lateral, zmask = rnd((N, C, H, W), 85), rnd((N, C, H, W), 86)
+    want = (xr.grad + lateral) * (zmask > 0)
+    compact = torch.empty((N, yd.shape[2], yd.shape[3], C), device=dev)
+    cv.conv_igemm(nhwc(gd).to(dev), cv.pack_weights(wd.to(dev), 1), compact, (yd.shape[2], yd.shape[3], C, 1, 1, 1, -1, 0, 0))
+    dx = cv.dgrad(nhwc(g1).to(dev), cv.pack_weights(w1.to(dev), 1), (H, W), C, 1, 1, 0, add=nhwc(lateral).to(dev),
+                  add_mode=1, mask=nhwc(zmask).to(dev), add2=compact)
+    close(nchw(dx), want)
