@@ -27,26 +27,29 @@
 // Roofline: MFMA (fp32 157.3 TF).  Per K-step a wave issues 64 MFMAs (4096 cycles) against 16 ds_read_b128,
 // 8 global_load_dwordx4 and 8 ds_write_b128.  Small-K layers (1x1, Cin 64..128) are HBM-bound instead:
 // e.g. 1x1 64->256 at 270x480 moves 1.33 GB per 34 GFLOP.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BK 32
-#define LDK 36                 // padded LDS row, floats
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int WM, int WN, bool GENERAL>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
+template <int WM, int WN, bool GENERAL, int BK>
+__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                             const float *__restrict__ w, float *__restrict__ y,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                                             const float *__restrict__ add, const float *__restrict__ mask,
                                                             const float *__restrict__ add2) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int AR = BM / 32, BR = BN / 32;              // rows of A / B each thread stages per K-step
+    constexpr int LDK = BK + 4;                            // padded LDS row, floats (conflict-free b128 reads)
+    constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
+    constexpr int RPS = 256 / CPK;                         // rows staged per pass
+    constexpr int AR = BM / RPS, BR = BN / RPS;            // rows of A / B each thread stages per K-step
     static_assert(WM * WN == 4, "4 waves");
     __shared__ float lds[2][(BM + BN) * LDK];
 
@@ -58,17 +61,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
     const int HoWo = d.Ho * d.Wo;
     const int64_t M = (int64_t)d.N * HoWo;
     const int K = d.kh * d.kw * d.Cin;
-    const int Kpad = (K + BK - 1) / BK * BK;               // packed weight rows are zero-padded to Kpad
+    const int Kpad = (K + 31) / 32 * 32;                   // packed weight rows are zero-padded to a multiple of 32
     const int nks = Kpad / BK;
     const int dmask = (1 << d.div_shift) - 1;
 
     // ---- per-thread staging geometry: chunk column q (4 floats of K), rows srow + 32*i
-    const int q = tid & 7, srow = tid >> 3;
+    const int q = tid % CPK, srow = tid / CPK;
     const float *a_base[AR];
     int a_h[AR], a_w[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int64_t m = (int64_t)m0 + srow + 32 * i;
+        const int64_t m = (int64_t)m0 + srow + RPS * i;
         if (m < M) {
             const int n = (int)(m / HoWo);
             const int rem = (int)(m - (int64_t)n * HoWo);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
     bool b_ok[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        const int n = n0 + srow + 32 * i;
+        const int n = n0 + srow + RPS * i;
         b_ok[i] = n < d.Cout;
         b_base[i] = w + (int64_t)(b_ok[i] ? n : 0) * Kpad + 4 * q;
     }
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
             const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
             const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
             const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
-            float4 v = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((int64_t)ih * d.Wi + iw) * d.Cin + c0)
+            // offsets inside one image fit 32 bits (x_batch_stride < 2^31 floats is checked by the launcher)
+            float4 v = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((ih * d.Wi + iw) * d.Cin + c0))
                           : make_float4(0.f, 0.f, 0.f, 0.f);
             if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             ra[i] = v;
@@ -116,9 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
     auto store_step = [&](int buf) {
         float *A = lds[buf], *B = lds[buf] + BM * LDK;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4 *>(A + (srow + 32 * i) * LDK + 4 * q) = ra[i];
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4 *>(A + (srow + RPS * i) * LDK + 4 * q) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4 *>(B + (srow + 32 * i) * LDK + 4 * q) = rb[i];
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4 *>(B + (srow + RPS * i) * LDK + 4 * q) = rb[i];
     };
 
     f32x16 acc[2][2];
@@ -164,80 +168,89 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
     // memory sees 16-byte accesses, 32 consecutive lanes on one 512-byte row segment: out, add and mask all move as
     // float4.  Accumulator element e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile.
     constexpr int LDT = BN + 4;
+    constexpr int EP = (BM * LDT > 2 * (BM + BN) * LDK) ? 2 : 1;   // passes when the tile outgrows the staging LDS
+    constexpr int RP = BM / EP;                                    // tile rows per pass
+    static_assert(RP * LDT <= 2 * (BM + BN) * LDK && RP % 64 == 0, "output tile pass must fit the staging LDS");
     float *T = &lds[0][0];
-    static_assert(BM * LDT <= 2 * (BM + BN) * LDK, "output tile must fit the staging LDS");
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                T[(wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] =
-                    acc[tm][tn][e];
-    __syncthreads();
-    constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 16-byte chunks per tile row, rows per pass
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 16-byte chunks per tile row, rows per pass of stores
     const int c4 = tid % CPR;
     const int col = n0 + 4 * c4;
-    if (col >= d.Cout) return;
+    const bool col_ok = col < d.Cout;
     const bool vec = (d.Cout & 3) == 0;                      // then col+3 < Cout and every row offset is 16-byte aligned
     const int ncol = vec ? 4 : (d.Cout - col < 4 ? d.Cout - col : 4);
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (j < ncol && scale != nullptr) sc[j] = scale[col + j];
-        if (j < ncol && shift != nullptr) sh[j] = shift[col + j];
+        if (col_ok && j < ncol && scale != nullptr) sc[j] = scale[col + j];
+        if (col_ok && j < ncol && shift != nullptr) sh[j] = shift[col + j];
     }
-    for (int r = tid / CPR; r < BM; r += RPP) {
-        const int64_t m = (int64_t)m0 + r;
-        if (m >= M) break;
-        const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
-        float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]};
-        int64_t off, aoff = -1, a2off = -1;
-        if (!GENERAL) {
-            off = m * d.Cout + col;
-            if (d.add_mode == 1) aoff = off;
-        } else {
-            const int n = (int)(m / HoWo);
-            const int rem = (int)(m - (int64_t)n * HoWo);
-            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
-            const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
-            const int64_t pix = (int64_t)ph * d.Wy + pw;
-            off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
-            if (d.add_mode == 1) aoff = (int64_t)n * d.add_batch_stride + pix * d.Cout + col;
-            else if (d.add_mode == 2)                        // nearest x2 upsample of [N,Ha,Wa,Cout], cropped (D/model.py:88-108)
-                aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col;
-            if (d.add2_mode == 3 && ((ph | pw) & 1) == 0)
-                a2off = (int64_t)n * d.add2_batch_stride + ((int64_t)(ph >> 1) * d.Wa2 + (pw >> 1)) * d.Cout + col;
+#pragma unroll
+    for (int pass = 0; pass < EP; ++pass) {
+        if (pass) __syncthreads();
+        if ((wm * 64) / RP == pass) {
+            const int rbase = wm * 64 - pass * RP;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(rbase + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] =
+                            acc[tm][tn][e];
         }
-        float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec) {
-            if (d.mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; }
-            if (aoff >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add + aoff); ad[0] = q.x; ad[1] = q.y; ad[2] = q.z; ad[3] = q.w; }
-            if (a2off >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2off); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
-        } else {
+        __syncthreads();
+        for (int r = tid / CPR; r < RP; r += RPP) {
+            const int64_t m = (int64_t)m0 + pass * RP + r;
+            if (m >= M || !col_ok) break;
+            const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+            float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]};
+            int64_t off, aoff = -1, a2off = -1;
+            if (!GENERAL) {
+                off = m * d.Cout + col;
+                if (d.add_mode == 1) aoff = off;
+            } else {
+                const int n = (int)(m / HoWo);
+                const int rem = (int)(m - (int64_t)n * HoWo);
+                const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+                const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
+                const int64_t pix = (int64_t)ph * d.Wy + pw;
+                off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
+                if (d.add_mode == 1) aoff = (int64_t)n * d.add_batch_stride + pix * d.Cout + col;
+                else if (d.add_mode == 2)                    // nearest x2 upsample of [N,Ha,Wa,Cout], cropped (D/model.py:88-108)
+                    aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col;
+                if (d.add2_mode == 3 && ((ph | pw) & 1) == 0)
+                    a2off = (int64_t)n * d.add2_batch_stride + ((int64_t)(ph >> 1) * d.Wa2 + (pw >> 1)) * d.Cout + col;
+            }
+            float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                if (d.mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; }
+                if (aoff >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add + aoff); ad[0] = q.x; ad[1] = q.y; ad[2] = q.z; ad[3] = q.w; }
+                if (a2off >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2off); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < ncol && d.mask_mode != 0) mk[j] = mask[off + j];
+                    if (j < ncol && aoff >= 0) ad[j] = add[aoff + j];
+                    if (j < ncol && a2off >= 0) ad[j] += add2[a2off + j];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (j < ncol && d.mask_mode != 0) mk[j] = mask[off + j];
-                if (j < ncol && aoff >= 0) ad[j] = add[aoff + j];
-                if (j < ncol && a2off >= 0) ad[j] += add2[a2off + j];
+                float u = v[j];
+                if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f;
+                u += ad[j];
+                if (d.act == 1) u = fmaxf(u, 0.f);
+                else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
+                if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f;
+                v[j] = u;
             }
-        }
+            if (vec) {
+                *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float u = v[j];
-            if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f;
-            u += ad[j];
-            if (d.act == 1) u = fmaxf(u, 0.f);
-            else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
-            if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f;
-            v[j] = u;
-        }
-        if (vec) {
-            *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < ncol) y[off + j] = v[j];
+                for (int j = 0; j < 4; ++j)
+                    if (j < ncol) y[off + j] = v[j];
+            }
         }
     }
 }
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const rn_conv_desc d
 static int check_desc(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 4 || (d->Cin & 3)) return RN_EINVAL;                     // 16-byte chunks must not straddle taps
+    if ((int64_t)d->Hi * d->Wi * d->Cin > 0x7fffffffLL) return RN_EINVAL; // in-image offsets are 32-bit
     if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
     if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
     if (d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;
@@ -270,12 +284,17 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);
     if (tiles > 0x7fffffff) return RN_EINVAL;
     const dim3 grid((unsigned)tiles), block(256);
-#define RN_LAUNCH_IGEMM(WM, WN, G) \
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
+#define RN_LAUNCH_IGEMM(WM, WN, G, K) \
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G, K>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
+    // K-step 16 keeps 3 workgroups per CU: measured better only when the K loop is a handful of steps long
+    static const int bk16_env = getenv("RN_IGEMM_BK16") ? atoi(getenv("RN_IGEMM_BK16")) : -1;
+    const int bk16 = bk16_env >= 0 ? bk16_env : (d->kh * d->kw * d->Cin <= 256);
     if (narrow) {
-        if (dense) RN_LAUNCH_IGEMM(4, 1, false); else RN_LAUNCH_IGEMM(4, 1, true);
+        if (dense) RN_LAUNCH_IGEMM(4, 1, false, 32); else RN_LAUNCH_IGEMM(4, 1, true, 32);
+    } else if (bk16) {
+        if (dense) RN_LAUNCH_IGEMM(2, 2, false, 16); else RN_LAUNCH_IGEMM(2, 2, true, 16);
     } else {
-        if (dense) RN_LAUNCH_IGEMM(2, 2, false); else RN_LAUNCH_IGEMM(2, 2, true);
+        if (dense) RN_LAUNCH_IGEMM(2, 2, false, 32); else RN_LAUNCH_IGEMM(2, 2, true, 32);
     }
 #undef RN_LAUNCH_IGEMM
     RN_LAUNCH_CHECK();

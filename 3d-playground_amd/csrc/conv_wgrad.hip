@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int PA = CA / 8, PB = CB / 8;                  // passes (rows per pass = 256 / chunks)
     constexpr int RA = 256 / CA, RB = 256 / CB;
     __shared__ float lds[2][WK * (BM + BN)];
+    __shared__ int4 pixtab[2][WK];                           // per K-step: (n*Hi, oh*st - pad, ow*st - pad, valid)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -62,6 +63,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int fr = tap / p.kw, fs = tap - fr * p.kw;
     const bool b_col_ok = jcol < p.Kflat;
 
+    // One lane per pixel of a K-step decomposes it into (n, oh, ow) for everybody: two integer divisions per
+    // K-step instead of two per staged row.
+    auto fill_table = [&](int ks) {
+        if (tid < WK) {
+            const int64_t pix = kbeg + (int64_t)ks * WK + tid;
+            int4 e = make_int4(0, 0, 0, 0);
+            if (pix < kend) {
+                const int n = (int)(pix / HoWo);
+                const int rem = (int)(pix - (int64_t)n * HoWo);
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                e = make_int4(n * p.Hi, oh * p.stride - p.pad, ow * p.stride - p.pad, 1);
+            }
+            pixtab[ks & 1][tid] = e;
+        }
+    };
     const bool do_cs = p.colsum != nullptr && (blockIdx.x % p.tiles_n) == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[PA], vb[PB];
@@ -72,19 +88,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             const int64_t pix = kb + ra0 + RA * i;
             va[i] = (a_col_ok && pix < kend) ? *reinterpret_cast<const float4 *>(p.dy + pix * p.ldy + m0 + 4 * ca)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (do_cs) { cs.x += va[i].x; cs.y += va[i].y; cs.z += va[i].z; cs.w += va[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int64_t pix = kb + rb0 + RB * i;
+            const int4 e = pixtab[ks & 1][rb0 + RB * i];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_col_ok && pix < kend) {
-                const int n = (int)(pix / HoWo);
-                const int rem = (int)(pix - (int64_t)n * HoWo);
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                const int ih = oh * p.stride + fr - p.pad, iw = ow * p.stride + fs - p.pad;
-                if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-                    v = *reinterpret_cast<const float4 *>(p.x + (((int64_t)n * p.Hi + ih) * p.Wi + iw) * p.Cin + ci0);
+            const int ih = e.y + fr, iw = e.z + fs;
+            if (b_col_ok && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+                v = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(e.x + ih) * p.Wi + iw) * p.Cin + ci0);
                 if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
             vb[i] = v;
@@ -93,7 +104,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     auto store_step = [&](int buf) {
         float *A = lds[buf], *B = lds[buf] + WK * BM;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4 *>(A + (ra0 + RA * i) * BM + 4 * ca) = va[i];
+        for (int i = 0; i < PA; ++i) {
+            *reinterpret_cast<float4 *>(A + (ra0 + RA * i) * BM + 4 * ca) = va[i];
+            // column sums ride on the staged dY; accumulated here, after the MFMAs, so the loads stay in flight
+            if (do_cs) { cs.x += va[i].x; cs.y += va[i].y; cs.z += va[i].z; cs.w += va[i].w; }
+        }
 #pragma unroll
         for (int i = 0; i < PB; ++i) *reinterpret_cast<float4 *>(B + (rb0 + RB * i) * BN + 4 * cb) = vb[i];
     };
@@ -106,6 +121,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    fill_table(0);
+    fill_table(1);
+    __syncthreads();
     if (nks > 0) {
         load_step(0);
         store_step(0);
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int fb = (lane >> 5) * BN + wn * 64 + (lane & 31);
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nks) load_step(ks + 1);
+        if (ks + 1 < nks) load_step(ks + 1);                 // reads pixtab[(ks+1)&1], published by an earlier barrier
         const float *A = lds[buf] + fa;
         const float *B = lds[buf] + WK * BM + fb;
 #pragma unroll
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (ks + 2 < nks) fill_table(ks + 2);                 // slot [ks&1] was last read by load_step(ks), before the previous barrier
         if (ks + 1 < nks) store_step(buf ^ 1);
         __syncthreads();
     }
