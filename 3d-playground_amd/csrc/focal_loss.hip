@@ -5,10 +5,11 @@
 // loop and runs ~40 small torch kernels per image, materialising an [A,N] IoU matrix, an [A,C] target matrix
 // and several [A,C] temporaries (348 ms forward at B=8 on 8 CPU threads).
 //
-// One launch covers the whole batch.  A workgroup owns a tile of TILE consecutive anchors of one image:
+// One launch covers the whole batch.  A workgroup owns a tile of 1024 consecutive anchors of one image:
 //   phase 0  the image's label rows are reduced to (box, area, class) in LDS; for the directional variant the
 //            box is the min/max envelope of the 8 corners (D/losses.py:93-107), NOT label cols 16:20;
-//   phase 1  one lane per anchor: IoU against every valid label (fp32, one rounding per operation in the
+//   phase 1  one lane per anchor; labels whose box misses the bounding box of the wave's 64 consecutive anchors are
+//            skipped by a scalar branch (their IoU is exactly 0), the others get the full IoU (fp32, one rounding per operation in the
 //            reference's order -- this file is compiled with -ffp-contract=off so the 0.4 / 0.5 band
 //            comparisons and the first-maximum argmax are bit-identical to torch CPU), state into LDS;
 //            positive anchors (~0.07 %) evaluate the regression / VP terms (forward) or their gradient
@@ -16,8 +17,9 @@
 //   phase 2  the tile's TILE*C classification values are streamed as float4 (16 B per lane, consecutive lanes
 //            consecutive addresses) against the states in LDS; forward accumulates the focal sum, backward
 //            writes dcls.
-// Sums leave the workgroup as one 4-float partial per (image, tile); a finalize kernel adds them in fp64 in
-// a fixed order, so results are bit-reproducible run to run (no float atomics).
+// Sums leave the workgroup as one 4-float partial per (image, tile); a finalize kernel (one wave per image) adds
+// them in fp64 in a fixed order (no float atomics anywhere; the classification sum is bit-reproducible, the
+// positives' terms up to the order in which a tile queues its handful of positive anchors).
 //
 // Roofline: HBM.  Forward algorithmic bytes = B*A*C*4 (cls) + A*16 (anchors, L2/MALL-resident after the first
 // image) + B*N*cols*4 = 105.9 MB at B=8, A=389 205, C=8.  Backward adds the dcls and dreg
@@ -26,8 +28,24 @@
 
 #include "common.h"
 
-#define TILE 256          // anchors per workgroup == threads per workgroup
-#define NWAVES (TILE / 64)
+#define NTHR 256          // threads per workgroup
+#define APT 4             // anchors per thread
+#define TILE (NTHR * APT) // 1024 anchors per workgroup: label setup amortised, 8 float4 in flight per lane in phase 2
+#define NWAVES (NTHR / 64)
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float uniform_f(float v) {      // tell the compiler the value is wave-uniform (scalar branch)
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 
 struct ImageStats {       // one per image, written by finalize, read by backward
     float npos;           // number of positive anchors
@@ -108,9 +126,12 @@ __device__ __forceinline__ void match_anchor(const float4 a, const LabelLds &L, 
         iw = fmaxf(iw, 0.f);
         ih = fmaxf(ih, 0.f);
         const float inter = iw * ih;
-        float ua = (area_a + L.area[n]) - inter;
-        ua = fmaxf(ua, 1e-8f);
-        const float iou = inter / ua;
+        float iou = 0.f;                                     // 0 / max(ua, 1e-8) == 0 exactly: ~99 % of pairs skip the divide
+        if (inter > 0.f) {
+            float ua = (area_a + L.area[n]) - inter;
+            ua = fmaxf(ua, 1e-8f);
+            iou = inter / ua;
+        }
         if (iou > best) { best = iou; arg = n; }
     }
 }
@@ -235,33 +256,27 @@ __device__ __forceinline__ void positive_2d(const float4 a, const float *__restr
     reg_sum += acc;
 }
 
-// Focal term / gradient of one classification value.  target: 1 positive class, 0 negative, -1 ignored.
+// Focal term / gradient of one classification value, branch-free and lean (the kernel is VALU-issue bound:
+// ~11 instructions per value).  With a = (pos ? p : 1-p), m = 1-a:
+//   loss     = w * m^2 * (-ln a)                   (D/losses.py:137-146: both branches of the reference's where())
+//   dloss/dp = +-w * (2 m ln a - m^2 / a)          (+ for the positive class, - otherwise); 0 outside the clamp range
+// `wl` carries the weight: forward  w*ln2 (0 for an ignored anchor) since ln a = ln2 * log2 a (v_log_f32, ~1 ulp);
+//                          backward +-w*scale (0 for an ignored anchor).  v_rcp_f32 (~1 ulp) replaces the divide.
+#define RN_LN2 0.69314718055994530942f
 template <bool BWD>
-__device__ __forceinline__ float focal_elem(float x, int target, float scale) {
-    if (target < 0) return 0.f;
-    const float p = fminf(fmaxf(x, 1e-4f), 1.0f - 1e-4f);                     // D/losses.py:56
-    if (!BWD) {
-        if (target == 1) {
-            const float q = 1.0f - p;
-            return (0.25f * (q * q)) * (-logf(p));                            // D/losses.py:137-146
-        }
-        return (0.75f * (p * p)) * (-logf(1.0f - p));
-    }
-    if (x < 1e-4f || x > 1.0f - 1e-4f) return 0.f;                            // clamp passes no gradient outside
-    float g;
-    if (target == 1) {
-        const float q = 1.0f - p;
-        g = 0.25f * (2.0f * q * logf(p) - (q * q) / p);
-    } else {
-        const float q = 1.0f - p;
-        g = 0.75f * (-2.0f * p * logf(q) + (p * p) / q);
-    }
-    return g * scale;
+__device__ __forceinline__ float focal_elem(float x, bool pos, float wl) {
+    const float p = __builtin_amdgcn_fmed3f(x, 1e-4f, 1.0f - 1e-4f);          // clamp, D/losses.py:56
+    const float a = pos ? p : 1.0f - p;
+    const float m = 1.0f - a;
+    const float l2 = __builtin_amdgcn_logf(a);                                // log2(a), a in [1e-4, 1): no denormals
+    if (!BWD) return (wl * (m * m)) * (-l2);
+    const float g = wl * ((2.0f * RN_LN2) * (m * l2) - (m * m) * __builtin_amdgcn_rcpf(a));
+    return (x < 1e-4f || x > 1.0f - 1e-4f) ? 0.f : g;                         // clamp passes no gradient outside
 }
 
 // ----------------------------------------------------------------------------------------------------------
 template <bool DIR, bool BWD>
-__global__ __launch_bounds__(TILE) void focal_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
+__global__ __launch_bounds__(NTHR) void focal_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
                                                      const float4 *__restrict__ anchors, const float *__restrict__ ann,
                                                      int64_t A, int C, int N, float *__restrict__ partials,
                                                      const ImageStats *__restrict__ stats, float *__restrict__ dcls,
@@ -271,11 +286,31 @@ __global__ __launch_bounds__(TILE) void focal_kernel(const float *__restrict__ c
     constexpr int NREG = DIR ? 12 : 4;
     __shared__ LabelLds L;
     __shared__ int s_state[TILE];     // -1 ignore, 0 negative, 1 + class for a positive
+    __shared__ int s_pos[TILE];       // queue of positive anchors of the tile: local index | label row << 16
+    __shared__ int s_npos;
     __shared__ float s_red[NWAVES * 4];
 
     const int j = blockIdx.y;
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const float *ann_j = ann + (int64_t)j * N * COLS;
+    if (threadIdx.x == 0) s_npos = 0;
+    // Streaming-phase loads are issued first: their HBM latency hides behind label setup and assignment.
+    const int64_t nA = (A - tile0 < TILE) ? (A - tile0) : TILE;               // anchors in this tile
+    const int64_t elems = nA * C;
+    const int64_t base = ((int64_t)j * A + tile0) * C;
+    const float *src = cls + base;
+    constexpr int PRE = 8;                                                     // float4 per lane held in registers
+    const bool pre = (C & 3) == 0 && C <= PRE;                                 // then a tile is <= PRE*NTHR float4
+    float4 xv[PRE];
+    if (pre) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        const int n4 = (int)(elems >> 2);
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {                                        // unconditional (clamped) so all 8 stay in flight
+            const int v = k * NTHR + threadIdx.x;
+            xv[k] = src4[v < n4 ? v : n4 - 1];
+        }
+    }
     load_labels<DIR>(ann_j, N, L);
 
     float cls_scale = 0.f, reg_scale = 0.f, vp_scale = 0.f;
@@ -285,73 +320,136 @@ __global__ __launch_bounds__(TILE) void focal_kernel(const float *__restrict__ c
     }
 
     float sums[4] = {0.f, 0.f, 0.f, 0.f};   // focal, smooth-L1, vp, npos
-    // ---- phase 1: assignment (+ positives)
-    {
-        const int64_t ai = tile0 + threadIdx.x;
+    // ---- phase 1: assignment (+ positives), one lane per anchor, APT anchors per lane.  The 256 consecutive anchors of
+    // a wave lie in a small window of the image; their bounding box is reduced across the wave once, and a label
+    // whose box misses it has IoU exactly 0 with all 64 (skipping it cannot change the max or the first argmax:
+    // IoU >= 0 and ties keep the earlier label).  The test is wave-uniform -- a scalar branch, no divergence -- and
+    // removes ~95 % of the IoU evaluations whatever the anchor order (it is merely conservative for odd layouts).
+    if (BWD) {                                                // dense dreg: zero the tile, positives overwrite below
+        const int64_t nA0 = (A - tile0 < TILE) ? (A - tile0) : TILE;
+        float4 *z = reinterpret_cast<float4 *>(dreg + ((int64_t)j * A + tile0) * NREG);
+        const int nz = (int)(nA0 * (NREG / 4));
+        for (int v = threadIdx.x; v < nz; v += NTHR) z[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    // wave w owns anchors [w*256, w*256+256) of the tile; lane l takes w*256 + u*64 + l in round u (coalesced)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 av[APT];
+    float lx1 = INFINITY, ly1 = INFINITY, lx2 = -INFINITY, ly2 = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+        const int64_t ai = tile0 + wv * (64 * APT) + u * 64 + lane;
+        av[u] = ai < A ? anchors[ai] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        lx1 = fminf(lx1, av[u].x); ly1 = fminf(ly1, av[u].y);
+        lx2 = fmaxf(lx2, av[u].z); ly2 = fmaxf(ly2, av[u].w);
+    }
+    // one set of four independent reductions per wave: bounding box of its 256 consecutive anchors
+    const float wx1 = uniform_f(wave_min_f(lx1)), wy1 = uniform_f(wave_min_f(ly1));
+    const float wx2 = uniform_f(wave_max_f(lx2)), wy2 = uniform_f(wave_max_f(ly2));
+    float best[APT];
+    int arg[APT];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) { best[u] = 0.f; arg[u] = 0; }
+    for (int n = 0; n < L.count; ++n) {
+        const float gx1 = uniform_f(L.x1[n]), gy1 = uniform_f(L.y1[n]);
+        const float gx2 = uniform_f(L.x2[n]), gy2 = uniform_f(L.y2[n]);
+        if (!(wx2 > gx1 && gx2 > wx1 && wy2 > gy1 && gy2 > wy1)) continue;       // every iw or ih <= 0: all IoU = 0
+        const float garea = L.area[n];
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            const float4 a = av[u];
+            float iw = fminf(a.z, gx2) - fmaxf(a.x, gx1);                          // calc_iou's order (D/losses.py:5-22)
+            float ih = fminf(a.w, gy2) - fmaxf(a.y, gy1);
+            iw = fmaxf(iw, 0.f);
+            ih = fmaxf(ih, 0.f);
+            const float inter = iw * ih;
+            if (inter > 0.f) {                                                     // else 0 / max(ua, 1e-8) == 0
+                float ua = ((a.z - a.x) * (a.w - a.y) + garea) - inter;
+                ua = fmaxf(ua, 1e-8f);
+                const float iou = inter / ua;
+                if (iou > best[u]) { best[u] = iou; arg[u] = n; }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+        const int al = wv * (64 * APT) + u * 64 + lane;
+        const int64_t ai = tile0 + al;
         int state = -1;
         if (ai < A) {
             if (L.count == 0) {
                 state = 0;                                                    // empty image: all negative (D/losses.py:58-87)
             } else {
-                const float4 a = anchors[ai];
-                float best; int arg;
-                match_anchor(a, L, best, arg);
-                if (best < 0.4f) state = 0;                                   // D/losses.py:121
-                if (best >= 0.5f) {                                           // D/losses.py:124
-                    const float *g = ann_j + (int64_t)L.row[arg] * COLS;
-                    state = 1 + (int)g[CLS_COL];                              // .long() truncation, D/losses.py:131
-                    sums[3] += 1.f;
-                    const float *r = reg + ((int64_t)j * A + ai) * NREG;
-                    float *dr = BWD ? dreg + ((int64_t)j * A + ai) * NREG : nullptr;
-                    if (DIR) positive_dir<BWD>(a, g, r, sums[1], sums[2], reg_scale, vp_scale, dr);
-                    else positive_2d<BWD>(a, g, r, sums[1], reg_scale, dr);
+                if (best[u] < 0.4f) state = 0;                                // D/losses.py:121
+                if (best[u] >= 0.5f) {                                        // D/losses.py:124
+                    const int row = L.row[arg[u]];
+                    state = 1 + (int)ann_j[(int64_t)row * COLS + CLS_COL];    // .long() truncation, D/losses.py:131
+                    s_pos[atomicAdd(&s_npos, 1)] = al | (row << 16);          // ~0.07 % of anchors: handled below, once
                 }
             }
-            if (BWD && state < 1) {                                           // dense dreg: zeros off the positives
-                float4 *z = reinterpret_cast<float4 *>(dreg + ((int64_t)j * A + ai) * NREG);
-#pragma unroll
-                for (int k = 0; k < NREG / 4; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
         }
-        s_state[threadIdx.x] = state;
+        s_state[al] = state;
     }
     __syncthreads();
+    // positives: regression / VP terms (forward) or their gradient rows (backward), one queued anchor per lane.
+    // Queue order varies run to run, so the fp32 partial sums of these few terms may differ in the last bit.
+    for (int q = threadIdx.x; q < s_npos; q += NTHR) {
+        const int e = s_pos[q];
+        const int al = e & 0xffff, row = e >> 16;
+        const int64_t ai = tile0 + al;
+        const float *g = ann_j + (int64_t)row * COLS;
+        const float *r = reg + ((int64_t)j * A + ai) * NREG;
+        float *dr = BWD ? dreg + ((int64_t)j * A + ai) * NREG : nullptr;
+        sums[3] += 1.f;
+        if (DIR) positive_dir<BWD>(anchors[ai], g, r, sums[1], sums[2], reg_scale, vp_scale, dr);
+        else positive_2d<BWD>(anchors[ai], g, r, sums[1], reg_scale, dr);
+    }
 
     // ---- phase 2: stream the tile's classification values
-    const int64_t nA = (A - tile0 < TILE) ? (A - tile0) : TILE;               // anchors in this tile
-    const int64_t elems = nA * C;
-    const int64_t base = ((int64_t)j * A + tile0) * C;
-    const float *src = cls + base;
     float *dst = BWD ? dcls + base : nullptr;
     if ((C & 3) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(dst);
         const int n4 = (int)(elems >> 2);
         const int cq = C >> 2;                                                // float4 per anchor
-        for (int v = threadIdx.x; v < n4; v += TILE) {
-            const float4 x = src4[v];
-            const int al = v / cq;
+        const int cq_shift = cq == 1 ? 0 : (cq == 2 ? 1 : -1);                // C = 4 / 8: shifts instead of a division
+        auto one = [&](int v, const float4 x) {
+            const int al = cq_shift >= 0 ? (v >> cq_shift) : v / cq;
             const int c0 = (v - al * cq) << 2;
             const int st = s_state[al];
-            const int tc = st - 1;                                            // positive class or < 0
-            const int base_t = st < 0 ? -1 : 0;
+            const int tc = st - 1 - c0;                                       // lane-local index of the positive class, if any
+            // per-anchor weights: negatives 0.75, the positive class 0.25, nothing for an ignored anchor (st < 0)
+            const float wn = st < 0 ? 0.f : (BWD ? -0.75f * cls_scale : 0.75f * RN_LN2);
+            const float wp = BWD ? 0.25f * cls_scale : 0.25f * RN_LN2;
             const float xs[4] = {x.x, x.y, x.z, x.w};
             float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int target = (st > 0 && c0 + k == tc) ? 1 : base_t;
-                o[k] = focal_elem<BWD>(xs[k], target, cls_scale);
+                const bool pos = k == tc;                                     // st <= 0 makes tc negative
+                o[k] = focal_elem<BWD>(xs[k], pos, pos ? wp : wn);
             }
             if (BWD) dst4[v] = make_float4(o[0], o[1], o[2], o[3]);
             else sums[0] += (o[0] + o[1]) + (o[2] + o[3]);
+        };
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) {
+                const int v = k * NTHR + threadIdx.x;
+                if (v < n4) one(v, xv[k]);
+            }
+        } else {
+#pragma unroll 4
+            for (int v = threadIdx.x; v < n4; v += NTHR) one(v, src4[v]);
         }
     } else {
-        for (int e = threadIdx.x; e < (int)elems; e += TILE) {
+        for (int e = threadIdx.x; e < (int)elems; e += NTHR) {
             const int al = e / C;
             const int c = e - al * C;
             const int st = s_state[al];
-            const int target = (st > 0 && c == st - 1) ? 1 : (st < 0 ? -1 : 0);
-            const float o = focal_elem<BWD>(src[e], target, cls_scale);
+            const bool pos = st > 0 && c == st - 1;
+            const float wn = st < 0 ? 0.f : (BWD ? -0.75f * cls_scale : 0.75f * RN_LN2);
+            const float wp = BWD ? 0.25f * cls_scale : 0.25f * RN_LN2;
+            const float o = focal_elem<BWD>(src[e], pos, pos ? wp : wn);
             if (BWD) dst[e] = o;
             else sums[0] += o;
         }
@@ -365,84 +463,84 @@ __global__ __launch_bounds__(TILE) void focal_kernel(const float *__restrict__ c
     }
 }
 
-// One workgroup per launch: per image, add the tile partials in fp64 in tile order, derive the per-image
-// losses and the gradient scales, then the batch means (D/losses.py:152, 350, 304, 359-362).
+// One workgroup, one wave per image (images beyond 16 loop): the wave adds its image's tile partials in fp64 in a
+// fixed lane/tile order (bit-reproducible), checks whether the image has any label row, and derives the per-image
+// loss terms and gradient scales; thread 0 then forms the batch means (D/losses.py:152, 350, 304, 359-362).
 template <bool DIR>
-__global__ __launch_bounds__(256) void focal_finalize(const float4 *__restrict__ partials, int tiles, int B,
-                                                      ImageStats *__restrict__ stats, float *__restrict__ losses) {
-    __shared__ double s_acc[4][4];
-    __shared__ double s_loss[3];
-    __shared__ int s_vp_images;
-    if (threadIdx.x == 0) { s_loss[0] = s_loss[1] = s_loss[2] = 0.0; s_vp_images = 0; }
-    __syncthreads();
-    for (int j = 0; j < B; ++j) {
+__global__ __launch_bounds__(1024) void focal_finalize(const float4 *__restrict__ partials, int tiles, int B,
+                                                       const float *__restrict__ ann, int N,
+                                                       ImageStats *__restrict__ stats, float *__restrict__ losses) {
+    constexpr int COLS = DIR ? 27 : 5;
+    constexpr int CLS_COL = DIR ? 20 : 4;
+    __shared__ double s_l[3][1024];          // per-image loss terms (B <= 1024)
+    __shared__ float s_has[1024];
+    __shared__ double s_part[16][4][64];     // per wave: lane partials, summed in lane order by 4 lanes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < B; j += 16) {
         double v[4] = {0, 0, 0, 0};
-        for (int t = threadIdx.x; t < tiles; t += 256) {
+        for (int t = lane; t < tiles; t += 64) {
             const float4 p = partials[(int64_t)j * tiles + t];
             v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = wave_sum(v[i]);
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_acc[threadIdx.x >> 6][i] = v[i];
+        for (int i = 0; i < 4; ++i) s_part[wave][i][lane] = v[i];
+        bool any = false;
+        for (int r = lane; r < N; r += 64) any |= ann[((int64_t)j * N + r) * COLS + CLS_COL] != -1.0f;
+        const bool has = __ballot(any) != 0ull;
+        if (lane < 4) {                                      // same-wave LDS traffic: program order suffices
+            double t = 0.0;
+            for (int k = 0; k < 64; ++k) t += s_part[wave][lane][k];
+            s_part[wave][lane][0] = t;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s[4];
-            for (int i = 0; i < 4; ++i) s[i] = (s_acc[0][i] + s_acc[1][i]) + (s_acc[2][i] + s_acc[3][i]);
-            const double npos = s[3];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = s_part[wave][i][0];
+            const double npos = v[3];
             ImageStats st;
             st.npos = (float)npos;
-            st.has_labels = stats[j].has_labels;                              // written by labels_kernel
+            st.has_labels = has ? 1.f : 0.f;
+            st.pad[0] = st.pad[1] = st.pad[2] = 0.f;
             const double nvals = DIR ? 20.0 : 4.0;
             double lc, lr = 0.0, lv = 0.0;
-            if (st.has_labels == 0.f) {
-                lc = s[0];                                                    // raw sum, not normalised (D/losses.py:58-87)
+            if (!has) {
+                lc = v[0];                                                    // raw sum, not normalised (D/losses.py:58-87)
                 st.cls_scale = 1.0f; st.reg_scale = 0.f; st.vp_scale = 0.f;
             } else {
                 const double dn = npos > 1.0 ? npos : 1.0;                    // clamp(min=1), D/losses.py:152
-                lc = s[0] / dn;
+                lc = v[0] / dn;
                 st.cls_scale = (float)(1.0 / dn);
                 if (npos > 0.0) {
-                    lr = s[1] / (npos * nvals);                               // mean over [P,20] / [P,4]
-                    lv = s[2] / (3.0 * npos);                                 // mean over P of (sum_k)/3
+                    lr = v[1] / (npos * nvals);                               // mean over [P,20] / [P,4]
+                    lv = v[2] / (3.0 * npos);                                 // mean over P of (sum_k)/3
                     st.reg_scale = (float)(1.0 / (npos * nvals));
                     st.vp_scale = (float)(1.0 / (3.0 * npos));
                 } else {
                     st.reg_scale = 0.f; st.vp_scale = 0.f;
                 }
-                s_vp_images += 1;
             }
-            s_loss[0] += lc; s_loss[1] += lr; s_loss[2] += lv;
+            s_l[0][j] = lc; s_l[1][j] = lr; s_l[2][j] = lv;
+            s_has[j] = st.has_labels;
             stats[j] = st;
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        losses[0] = (float)(s_loss[0] / B);
-        losses[1] = (float)(s_loss[1] / B);
-        // vp: mean over images that have labels; none -> 0/0 = NaN (the reference raises, D/losses.py:362)
-        losses[2] = DIR ? (float)(s_loss[2] / (double)s_vp_images) : 0.f;
-        // fold the batch means into the per-image gradient scales
+        double sum[3] = {0, 0, 0};
+        int vp_images = 0;
         for (int j = 0; j < B; ++j) {
+            sum[0] += s_l[0][j]; sum[1] += s_l[1][j]; sum[2] += s_l[2][j];
+            vp_images += s_has[j] != 0.f;
+        }
+        losses[0] = (float)(sum[0] / B);
+        losses[1] = (float)(sum[1] / B);
+        // vp: mean over images that have labels; none -> 0/0 = NaN (the reference raises, D/losses.py:362)
+        losses[2] = DIR ? (float)(sum[2] / (double)vp_images) : 0.f;
+        for (int j = 0; j < B; ++j) {                                          // fold the batch means into the scales
             stats[j].cls_scale /= (float)B;
             stats[j].reg_scale /= (float)B;
-            stats[j].vp_scale = s_vp_images > 0 ? stats[j].vp_scale / (float)s_vp_images : 0.f;
+            stats[j].vp_scale = vp_images > 0 ? stats[j].vp_scale / (float)vp_images : 0.f;
         }
     }
-}
-
-// has_labels[j] = any row of ann[j] with class != -1
-template <bool DIR>
-__global__ void labels_kernel(const float *__restrict__ ann, int N, ImageStats *__restrict__ stats) {
-    constexpr int COLS = DIR ? 27 : 5;
-    constexpr int CLS_COL = DIR ? 20 : 4;
-    const int j = blockIdx.x;
-    bool any = false;
-    for (int r = threadIdx.x; r < N; r += 64) any |= ann[((int64_t)j * N + r) * COLS + CLS_COL] != -1.0f;
-    const unsigned long long m = __ballot(any);
-    if (threadIdx.x == 0) stats[j].has_labels = m ? 1.f : 0.f;
 }
 
 // Multiply the per-image scales by the incoming loss gradients (device scalars: no host sync).
@@ -473,18 +571,18 @@ extern "C" int rn_focal_loss_fwd(const float *cls, const float *reg, const float
     const int tiles = (int)((A + TILE - 1) / TILE);
     ImageStats *stats = reinterpret_cast<ImageStats *>(workspace);
     float *partials = reinterpret_cast<float *>(stats + 2 * B);
-    const dim3 grid(tiles, B), block(TILE);
+    const dim3 grid(tiles, B), block(NTHR);
     const float4 *anc = reinterpret_cast<const float4 *>(anchors);
     if (directional) {
-        hipLaunchKernelGGL(labels_kernel<true>, dim3(B), dim3(64), 0, s, ann, N, stats);
         hipLaunchKernelGGL((focal_kernel<true, false>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, partials,
                            (const ImageStats *)nullptr, (float *)nullptr, (float *)nullptr);
-        hipLaunchKernelGGL(focal_finalize<true>, dim3(1), dim3(256), 0, s, (const float4 *)partials, tiles, B, stats, losses);
+        hipLaunchKernelGGL(focal_finalize<true>, dim3(1), dim3(1024), 0, s, (const float4 *)partials, tiles, B, ann, N,
+                           stats, losses);
     } else {
-        hipLaunchKernelGGL(labels_kernel<false>, dim3(B), dim3(64), 0, s, ann, N, stats);
         hipLaunchKernelGGL((focal_kernel<false, false>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, partials,
                            (const ImageStats *)nullptr, (float *)nullptr, (float *)nullptr);
-        hipLaunchKernelGGL(focal_finalize<false>, dim3(1), dim3(256), 0, s, (const float4 *)partials, tiles, B, stats, losses);
+        hipLaunchKernelGGL(focal_finalize<false>, dim3(1), dim3(1024), 0, s, (const float4 *)partials, tiles, B, ann, N,
+                           stats, losses);
     }
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -500,7 +598,7 @@ extern "C" int rn_focal_loss_bwd(const float *cls, const float *reg, const float
     const ImageStats *stats = reinterpret_cast<const ImageStats *>(workspace);
     ImageStats *scaled = const_cast<ImageStats *>(stats) + B;                  // second block of the workspace
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1024), 0, s, stats, grad_losses, B, scaled);
-    const dim3 grid(tiles, B), block(TILE);
+    const dim3 grid(tiles, B), block(NTHR);
     const float4 *anc = reinterpret_cast<const float4 *>(anchors);
     if (directional)
         hipLaunchKernelGGL((focal_kernel<true, true>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, (float *)nullptr,
@@ -514,14 +612,14 @@ extern "C" int rn_focal_loss_bwd(const float *cls, const float *reg, const float
 
 // ----------------------------------------------------------------------------------------------------------
 template <bool DIR>
-__global__ __launch_bounds__(TILE) void assign_kernel(const float4 *__restrict__ anchors, const float *__restrict__ ann,
+__global__ __launch_bounds__(NTHR) void assign_kernel(const float4 *__restrict__ anchors, const float *__restrict__ ann,
                                                       int64_t A, int N, float *__restrict__ iou_max,
                                                       int32_t *__restrict__ argmax, int32_t *__restrict__ state) {
     constexpr int COLS = DIR ? 27 : 5;
     __shared__ LabelLds L;
     const int j = blockIdx.y;
     load_labels<DIR>(ann + (int64_t)j * N * COLS, N, L);
-    const int64_t ai = (int64_t)blockIdx.x * TILE + threadIdx.x;
+    const int64_t ai = (int64_t)blockIdx.x * NTHR + threadIdx.x;
     if (ai >= A) return;
     float best = 0.f; int arg = -1; int st = 0;
     if (L.count > 0) {
@@ -539,7 +637,7 @@ extern "C" int rn_assign(const float *anchors, const float *ann, int B, int64_t 
                          float *iou_max, int32_t *argmax, int32_t *state, void *stream) {
     const int rc = check_args(B, A, 1, N);
     if (rc) return rc;
-    const dim3 grid((unsigned)((A + TILE - 1) / TILE), B), block(TILE);
+    const dim3 grid((unsigned)((A + NTHR - 1) / NTHR), B), block(NTHR);
     const float4 *anc = reinterpret_cast<const float4 *>(anchors);
     if (directional)
         hipLaunchKernelGGL(assign_kernel<true>, grid, block, 0, (hipStream_t)stream, anc, ann, A, N, iou_max, argmax, state);

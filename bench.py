@@ -78,7 +78,7 @@ def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
     ms = e0.elapsed_time(e1) / iters
     nbytes = B * A * C * 4 + A * 16 + B * N * 27 * 4
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "focal_kernel<dir,fwd> (+labels, finalize)", "bound": "hbm", "achieved": round(gbs, 1),
+    return {"kernel": "focal_kernel<dir,fwd> + focal_finalize", "bound": "hbm", "achieved": round(gbs, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "ms": round(ms, 4),
             "algorithmic_bytes": nbytes}
 
