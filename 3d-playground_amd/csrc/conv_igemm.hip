@@ -95,23 +95,53 @@ __global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm
     }
 
     float4 ra[AR], rb[BR];
+    // Fast path (Cin a multiple of the K-step, i.e. every layer but the 4-channel stem and channel-padded head
+    // gradients): a K-step lies inside one filter tap, so the per-row input coordinate, bounds test and pixel offset
+    // are recomputed only when the tap changes (every Cin/BK steps); in between a step is one add per row.
+    const bool fast = (d.Cin % BK) == 0;
+    int a_pix[AR];                                         // fast path: in-image offset of the row's pixel for the tap, <0 = zero
+    int f_r = 0, f_s = 0, f_c = 0;                         // tap (r,s) and channel offset of the NEXT step to load
     auto load_step = [&](int ks) {
-        const int k = ks * BK + 4 * q;
-        const int tap = k / d.Cin;
-        const int c0 = k - tap * d.Cin;
-        const int r = tap / d.kw, s = tap - r * d.kw;
-        const bool tap_ok = r < d.kh;
-        const int hoff = r * d.b, woff = s * d.b;
+        if (fast) {
+            if (f_c == 0) {                                // new tap (wave-uniform)
+                const bool tap_ok = f_r < d.kh;
+                const int hoff = f_r * d.b, woff = f_s * d.b;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
-            const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
-            const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
-            // offsets inside one image fit 32 bits (x_batch_stride < 2^31 floats is checked by the launcher)
-            float4 v = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((ih * d.Wi + iw) * d.Cin + c0))
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            ra[i] = v;
+                for (int i = 0; i < AR; ++i) {
+                    const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
+                    const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+                    const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
+                    a_pix[i] = ok ? (ih * d.Wi + iw) * d.Cin : -1;
+                }
+            }
+            const int c = f_c + 4 * q;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                float4 v = a_pix[i] >= 0 ? *reinterpret_cast<const float4 *>(a_base[i] + (a_pix[i] + c))
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                ra[i] = v;
+            }
+            f_c += BK;
+            if (f_c >= d.Cin) { f_c = 0; if (++f_s == d.kw) { f_s = 0; ++f_r; } }
+        } else {
+            const int k = ks * BK + 4 * q;
+            const int tap = k / d.Cin;
+            const int c0 = k - tap * d.Cin;
+            const int r = tap / d.kw, s = tap - r * d.kw;
+            const bool tap_ok = r < d.kh;
+            const int hoff = r * d.b, woff = s * d.b;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
+                const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+                const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
+                // offsets inside one image fit 32 bits (x_batch_stride < 2^31 floats is checked by the launcher)
+                float4 v = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((ih * d.Wi + iw) * d.Cin + c0))
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                ra[i] = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)

@@ -136,14 +136,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         if (ks + 1 < nks) load_step(ks + 1);                 // reads pixtab[(ks+1)&1], published by an earlier barrier
         const float *A = lds[buf] + fa;
         const float *B = lds[buf] + WK * BM + fb;
+        // fragment reads run two k-pairs ahead of the MFMAs that consume them (distinct registers per slot), so an
+        // MFMA group never waits on a read issued one instruction earlier
+        float fa[3][2], fb[3][2];
+#pragma unroll
+        for (int pre = 0; pre < 2; ++pre) {
+            fa[pre][0] = A[2 * pre * BM]; fa[pre][1] = A[2 * pre * BM + 32];
+            fb[pre][0] = B[2 * pre * BN]; fb[pre][1] = B[2 * pre * BN + 32];
+        }
 #pragma unroll
         for (int kp = 0; kp < WK / 2; ++kp) {
-            const float a0 = A[2 * kp * BM], a1 = A[2 * kp * BM + 32];
-            const float b0 = B[2 * kp * BN], b1 = B[2 * kp * BN + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const int cur = kp % 3, nxt = (kp + 2) % 3;
+            if (kp + 2 < WK / 2) {
+                fa[nxt][0] = A[2 * (kp + 2) * BM]; fa[nxt][1] = A[2 * (kp + 2) * BM + 32];
+                fb[nxt][0] = B[2 * (kp + 2) * BN]; fb[nxt][1] = B[2 * (kp + 2) * BN + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+            // keep that order: (2 LDS reads for k-pair kp+2) then (4 MFMAs of k-pair kp)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         if (ks + 2 < nks) fill_table(ks + 2);                 // slot [ks&1] was last read by load_step(ks), before the previous barrier
         if (ks + 1 < nks) store_step(buf ^ 1);

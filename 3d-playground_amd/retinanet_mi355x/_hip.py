@@ -70,6 +70,8 @@ SIGNATURES.update({
     "rn_relu_mask": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp]),
     "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_opt_workspace_bytes": (c_i64, [c_i32]),
+    "rn_opt_clip_adam": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
 })
 
 

@@ -103,7 +103,7 @@ def cpu_baseline(arch, H, W):
 
 def main():
     args = parse()
-    from retinanet_mi355x import ddp, modules, prof, synth
+    from retinanet_mi355x import ddp, modules, optim, prof, synth
     rank, local, world = ddp.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -119,7 +119,8 @@ def main():
     if world > 1:
         net.set_gradient_reducer(ddp.GradReducer())
     params = [p for p in net.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4)                                    # train_detector_3D_angle.py:337
+    # clip_grad_norm_(0.1) + Adam(lr 1e-4) (train_detector_3D_angle.py:337, 385-387) as one fused native step
+    opt = optim.ClipAdam(params, lr=1e-4, max_norm=0.1)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     img = torch.randn(B, 3, H, W, generator=g, device=dev)                     # frames ~N(0,1), resident in HBM
     ann = synth.labels_dir(B, 10, H, W, 8, seed=1 + rank).to(dev)
@@ -129,8 +130,7 @@ def main():
         cls_l, reg_l, vp_l = net([img, ann])
         loss = cls_l.mean() + reg_l.mean() + vp_l.mean()                       # train_detector_3D_angle.py:374-378
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 0.1)                            # :385
-        opt.step()                                                             # :387
+        opt.step()                                                             # clip (:385) + Adam step (:387)
         return loss
 
     def barrier():

@@ -230,6 +230,19 @@ int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int B, int64
                        int64_t src_batch_stride, void *stream);
 int rn_add_inplace(float *dst, const float *src, int64_t n, void *stream);
 
+/* ---------------------------------------------------------------- optimizer step ---------------------------
+ * clip_grad_norm_(params, max_norm) + Adam(lr, betas, eps).step() of the reference trainer
+ * (train_detector_3D_angle.py:337, 385-387) over every parameter tensor in two launches, no host sync.
+ *   tensor_table: device array of n_tensors entries {float *p, *g, *m, *v; int64_t n}
+ *   chunk_table:  device array of n_chunks entries {int tensor; int chunk_in_tensor}, 4096 elements per chunk
+ *   step: 1-based Adam step count (bias correction); max_norm <= 0 disables clipping
+ *   total_norm: device float, receives the pre-clip global L2 norm; write_clipped != 0 stores g*coef back
+ */
+int64_t rn_opt_workspace_bytes(int n_chunks);
+int rn_opt_clip_adam(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
+                     float beta1, float beta2, float eps, int step, int write_clipped, void *workspace,
+                     float *total_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,50 @@ def test_training_step_changes_loss(dev):
         opt.step()
         first = float(loss) if first is None else first
     assert float(loss) < first
+
+
+def test_fused_clip_adam_matches_torch(dev):
+    """retinanet_mi355x.optim.ClipAdam == clip_grad_norm_(0.1) + torch.optim.Adam(lr=1e-4) over 3 steps, and the
+    engine's packed-weight cache notices the in-place update."""
+    from retinanet_mi355x import optim
+    torch.manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (5000,), (256, 256, 3, 3), (1,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.1) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ref = torch.optim.Adam(pb, lr=1e-4)
+    mine = optim.ClipAdam(pa, lr=1e-4, max_norm=0.1)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(mine, mode="min", patience=0)          # the trainer's scheduler
+    sched.step(1.0); sched.step(2.0)
+    assert mine.param_groups[0]["lr"] < 1e-4
+    mine.param_groups[0]["lr"] = 1e-4
+    for it in range(3):
+        grads = [torch.randn(s, device=dev) * (10.0 if it == 1 else 0.001) for s in shapes]   # clipped and unclipped steps
+        for p, q, g in zip(pa, pb, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        v0 = pa[0]._version
+        want_norm = torch.nn.utils.clip_grad_norm_(pb, 0.1)
+        ref.step()
+        got_norm = mine.step()
+        assert pa[0]._version > v0
+        assert abs(float(got_norm) - float(want_norm)) <= 1e-5 * float(want_norm)
+        for p, q in zip(pa, pb):
+            assert float((p - q).abs().max()) <= 1e-6 * float(q.abs().max()) + 1e-9
+            assert float((p.grad - q.grad).abs().max()) <= 1e-6 * float(q.grad.abs().max()) + 1e-12   # clipped grads written back
+
+
+def test_cfg1_resnet18_2d_512(dev):
+    """BASELINE configs[0]: ResNet-18 2D RetinaNet, 512x512 random tensors, 10 random GT boxes, batch 2,
+    forward + FocalLoss -- against the oracle on CPU with the same weights."""
+    from oracle import model as omodel
+    from retinanet_mi355x import modules, synth
+    sd = synth.state_dict("resnet18", num_classes=8, n_reg=4, seed=2, head_scale=3e-4)
+    img = synth.frames(2, 512, 512, seed=0)
+    ann = synth.labels_2d(2, 10, 512, 512, 8, seed=1, size_px=(40, 160))
+    with torch.no_grad():
+        want = omodel.train_forward(img, ann, sd, "resnet18")
+    net = modules.resnet18(num_classes=8, directional=False)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    got = net([img.to(dev), ann.to(dev)])
+    assert len(got) == 2
+    assert np.allclose([float(x) for x in got], [float(x) for x in want], rtol=1e-4), (got, want)
