@@ -83,6 +83,20 @@ def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
             "algorithmic_bytes": nbytes}
 
 
+def pmc_traffic(kind):
+    """Average HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command
+    (tools/collect_traffic.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).
+    PMC counters cannot be read from inside the process, so the number is the last collected one, or None."""
+    prefix = {"conv_igemm_2x2": "conv_igemm_kernel<2, 2", "conv_igemm_4x1": "conv_igemm_kernel<4, 1",
+              "conv_wgrad": "conv_wgrad_kernel"}.get(kind)
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if prefix is None or not os.path.exists(path):
+        return None
+    rows = [v for k, v in json.load(open(path)).items() if k.startswith(prefix)]
+    n = sum(v["launches"] for v in rows)
+    return int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n) if n else None
+
+
 def cpu_baseline(arch, H, W):
     """oracle/ (torch CPU kernels, reference algorithm) forward + loss + backward on ONE image of the workload."""
     from oracle import model as omodel
@@ -178,7 +192,7 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             r = dict(kernels[dom])
             r["kernel"] = dom
-            r["traffic"] = None
+            r["traffic"] = pmc_traffic(dom)
             line["roofline"] = r
             kernels["focal_loss_fwd"] = loss_kernel_roofline(dev, B, H, W)
             line["kernels"] = kernels
