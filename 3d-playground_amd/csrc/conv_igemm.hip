@@ -42,11 +42,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int WM, int WN, bool GENERAL, int BK>
-__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
-                                                            const float *__restrict__ w, float *__restrict__ y,
-                                                            const float *__restrict__ scale, const float *__restrict__ shift,
-                                                            const float *__restrict__ add, const float *__restrict__ mask,
-                                                            const float *__restrict__ add2) {
+__device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const float *__restrict__ x,
+                                                const float *__restrict__ w, float *__restrict__ y,
+                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                const float *__restrict__ add, const float *__restrict__ mask,
+                                                const float *__restrict__ add2, const int tile) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LDK = BK + 4;                            // padded LDS row, floats (conflict-free b128 reads)
     constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = (d.Cout + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int HoWo = d.Ho * d.Wo;
     const int64_t M = (int64_t)d.N * HoWo;
@@ -287,6 +286,36 @@ __global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm
     }
 }
 
+
+
+template <int WM, int WN, bool GENERAL, int BK>
+__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
+                                                            const float *__restrict__ w, float *__restrict__ y,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            const float *__restrict__ add, const float *__restrict__ mask,
+                                                            const float *__restrict__ add2) {
+    conv_igemm_tile<WM, WN, GENERAL, BK>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch: the workgroup looks up which problem its tile belongs to (wave-uniform compare chain, static
+// indices into the by-value table) and runs the same tile code with that problem's descriptor and pointers.
+template <int WM, int WN, int BK>
+__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_grouped_kernel(const rn_conv_group g,
+                                                            const float *__restrict__ w, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift) {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    rn_conv_desc d = g.d[0];
+    const float *x = g.x[0], *add = g.add[0], *mask = g.mask[0];
+    float *y = g.y[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
+    conv_igemm_tile<WM, WN, true, BK>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Barrier-free variant: wave-private operand slabs (see the K loop).  Same tile, same epilogue.
@@ -550,6 +579,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_wp_kernel(const rn_conv_des
     }
 }
 
+static int check_desc(const rn_conv_desc *d);
+
+extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_packed, const float *scale, const float *shift,
+                                     void *stream) {
+    if (g->n < 1 || g->n > RN_MAX_GROUP) return RN_EINVAL;
+    const rn_conv_desc &d0 = g->d[0];
+    const bool narrow = d0.Cout <= 64;
+    int prev = 0;
+    for (int i = 0; i < g->n; ++i) {
+        const rn_conv_desc &d = g->d[i];
+        const int rc = check_desc(&d);
+        if (rc) return rc;
+        if (d.Cin != d0.Cin || d.Cout != d0.Cout || d.kh != d0.kh || d.kw != d0.kw || d.add2_mode != 0) return RN_EINVAL;
+        if ((d.add_mode != 0) != (g->add[i] != nullptr) || (d.mask_mode != 0) != (g->mask[i] != nullptr)) return RN_EINVAL;
+        const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+        const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d.Cout + 127) / 128);
+        if (g->tile_end[i] - prev != tiles) return RN_EINVAL;
+        prev = g->tile_end[i];
+    }
+    const dim3 grid((unsigned)prev), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool bk16 = d0.kh * d0.kw * d0.Cin <= 256;
+    if (narrow) hipLaunchKernelGGL((conv_igemm_grouped_kernel<4, 1, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
+    else if (bk16) hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
+    else hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 32>), grid, block, 0, s, *g, w_packed, scale, shift);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 static int check_desc(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 4 || (d->Cin & 3)) return RN_EINVAL;                     // 16-byte chunks must not straddle taps
@@ -590,8 +648,8 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
             hipLaunchKernelGGL((conv_igemm_wp_kernel<2, 2, false>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
         else
             hipLaunchKernelGGL((conv_igemm_wp_kernel<2, 2, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
-    } else if (narrow) {
-        if (dense) RN_LAUNCH_IGEMM(4, 1, false, 32); else RN_LAUNCH_IGEMM(4, 1, true, 32);
+    } else if (narrow) {                                                  // K-step 16: 51 KB of LDS, two workgroups per CU
+        if (dense) RN_LAUNCH_IGEMM(4, 1, false, 16); else RN_LAUNCH_IGEMM(4, 1, true, 16);
     } else if (bk16) {
         if (dense) RN_LAUNCH_IGEMM(2, 2, false, 16); else RN_LAUNCH_IGEMM(2, 2, true, 16);
     } else {

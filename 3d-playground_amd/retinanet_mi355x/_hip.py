@@ -55,7 +55,18 @@ class ConvDesc(ctypes.Structure):
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64)]
 
 
+RN_MAX_GROUP = 5
+
+
+class ConvGroup(ctypes.Structure):
+    """rn_conv_group of include/retinanet_mi355x.h."""
+    _fields_ = [("n", c_i32), ("tile_end", c_i32 * RN_MAX_GROUP), ("d", ConvDesc * RN_MAX_GROUP),
+                ("x", c_vp * RN_MAX_GROUP), ("y", c_vp * RN_MAX_GROUP), ("add", c_vp * RN_MAX_GROUP),
+                ("mask", c_vp * RN_MAX_GROUP)]
+
+
 SIGNATURES.update({
+    "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 12 + [c_vp]),
     "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp] + [c_i32] * 4 + [c_vp]),

@@ -69,6 +69,42 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
     return y
 
 
+def _make_desc(x, geom, act, add_mode, add_hw, mask_mode, in_relu, out_map, y_batch_stride, add_batch_stride, add2):
+    N, Hi, Wi, Cin = x.shape
+    Ho, Wo, Cout, kh, kw, a, b, p, ds = geom
+    p_h, p_w = p if isinstance(p, tuple) else (p, p)
+    os_, oo_h, oo_w, Hy, Wy = (1, 0, 0, Ho, Wo) if out_map is None else out_map
+    ybs = Hy * Wy * Cout if y_batch_stride is None else y_batch_stride
+    if add_batch_stride is None:
+        add_batch_stride = ybs if add_mode == 1 else add_hw[0] * add_hw[1] * Cout
+    a2 = (0, 0, 0, 0) if add2 is None else (3, add2.shape[1], add2.shape[2], add2.shape[1] * add2.shape[2] * Cout)
+    return ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p_h, p_w, ds, act, add_mode, add_hw[0], add_hw[1],
+                    mask_mode, int(in_relu), os_, oo_h, oo_w, Hy, Wy, a2[0], a2[1], a2[2], a2[3],
+                    Hi * Wi * Cin, ybs, add_batch_stride)
+
+
+def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):
+    """One launch for up to 5 problems sharing weights / epilogue scalars (the pyramid levels of a head tower).
+    problems: list of dicts with x, y, geom and optional add, mask, mask_mode, y_batch_stride."""
+    lib = _hip.load()
+    g = _hip.ConvGroup()
+    g.n = len(problems)
+    total = 0
+    for i, pr in enumerate(problems):
+        x, geom = pr["x"], pr["geom"]
+        add, mask = pr.get("add"), pr.get("mask")
+        d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), (pr.get("mask_mode", 2) if mask is not None else 0),
+                       False, None, pr.get("y_batch_stride"), None, None)
+        g.d[i] = d
+        M = d.N * d.Ho * d.Wo
+        total += (M + 255) // 256 if d.Cout <= 64 else ((M + 127) // 128) * ((d.Cout + 127) // 128)
+        g.tile_end[i] = total
+        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
+    rc = prof.timed("conv_igemm_4x1" if problems[0]["geom"][2] <= 64 else "conv_igemm_2x2", flops, lambda: lib.rn_conv_igemm_grouped(
+        ctypes.byref(g), w_packed.data_ptr(), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
+    _hip.check(rc, "rn_conv_igemm_grouped")
+
+
 def fprop(x, w_packed, cout, k, stride, pad, kw_pad=None, **kw):
     """Forward convolution, NHWC in -> new NHWC out."""
     N, Hi, Wi, _ = x.shape

@@ -76,6 +76,38 @@ class Layer:
                       y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo))
         return out
 
+    def fwd_group(self, xs, act=cv.ACT_NONE, outs=None, y_batch_stride=None):
+        """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
+        (with y_batch_stride) or None for fresh dense outputs."""
+        s = self.spec
+        probs, ys, fl = [], [], 0.0
+        for i, x in enumerate(xs):
+            N, Hi, Wi, _ = x.shape
+            Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
+            y = outs[i] if outs is not None else torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
+            ys.append(y)
+            fl += self.flops(N, Ho, Wo)
+            probs.append({"x": x, "y": y, "geom": (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
+                          "y_batch_stride": y_batch_stride})
+        cv.conv_igemm_grouped(probs, self.wf, scale=self.scale, shift=self.shift, act=act, flops=fl)
+        return ys
+
+    def bwd_data_group(self, gs, in_hws, adds=None, masks=None):
+        """Stride-1 data gradient of several problems in one launch; adds / masks: per-problem tensors or None."""
+        s = self.spec
+        assert s.stride == 1
+        probs, outs, fl = [], [], 0.0
+        for i, g in enumerate(gs):
+            N = g.shape[0]
+            Hi, Wi = in_hws[i]
+            dx = torch.empty((N, Hi, Wi, s.cin), dtype=torch.float32, device=g.device)
+            outs.append(dx)
+            fl += self.flops(N, g.shape[1], g.shape[2])
+            probs.append({"x": g, "y": dx, "geom": (Hi, Wi, s.cin, s.k, s.k, 1, -1, s.pad, 0),
+                          "add": None if adds is None else adds[i], "mask": None if masks is None else masks[i]})
+        cv.conv_igemm_grouped(probs, self.dgrad_weights(), flops=fl)
+        return outs
+
     def flops(self, N, Ho, Wo):
         """Algorithmic FLOPs of this convolution on N images (2*MACs; the same count prices fprop, dgrad, wgrad)."""
         s = self.spec
@@ -237,18 +269,18 @@ class Engine:
             S["counts"] = counts
         for prefix, out, width, act in (("regressionModel", reg, self.n_reg, cv.ACT_NONE),
                                         ("classificationModel", cls, self.num_classes, cv.ACT_SIGMOID)):
-            off = 0
-            for f, cnt in zip(pyramid, counts):
-                t = f
-                acts = []
-                for i in range(1, 5):
-                    t = Ls["%s.conv%d" % (prefix, i)].fwd(t, act=cv.ACT_RELU)
-                    acts.append(t)
-                view = out.view(B, -1)[:, off * width:]
-                Ls[prefix + ".output"].fwd(t, act=act, out=view, y_batch_stride=A * width)
+            ts = pyramid
+            acts = []                                                     # acts[i][level]
+            for i in range(1, 5):                                         # one launch per tower conv, all 5 levels
+                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU)
+                acts.append(ts)
+            views, off = [], 0
+            for cnt in counts:
+                views.append(out.view(B, -1)[:, off * width:])
                 off += cnt
-                if save:
-                    S["towers"][prefix].append(acts)
+            Ls[prefix + ".output"].fwd_group(ts, act=act, outs=views, y_batch_stride=A * width)
+            if save:
+                S["towers"][prefix] = [[acts[i][li] for i in range(4)] for li in range(5)]
         return reg, cls, S
 
     # ------------------------------------------------------------------------------------------- backward
@@ -268,27 +300,31 @@ class Engine:
         A = dreg.shape[1]
         dpyr = [None] * 5
         # ---- heads
+        hws = [(f.shape[1], f.shape[2]) for f in pyramid]
         for prefix, dout, width, sig in (("regressionModel", dreg, self.n_reg, None),
                                          ("classificationModel", dcls, self.num_classes, cls)):
             Lout = Ls[prefix + ".output"]
             tower = [Ls["%s.conv%d" % (prefix, i)] for i in range(1, 5)]
-            off = 0
-            for li, (f, cnt) in enumerate(zip(pyramid, counts)):
-                acts = S["towers"][prefix][li]
-                Hh, Ww = f.shape[1], f.shape[2]
+            acts = S["towers"][prefix]                                    # acts[level][i]
+            gs, off = [], 0
+            for (Hh, Ww), cnt in zip(hws, counts):                        # head-output gradient slices -> dense, padded
                 byte_off = 4 * off * width
                 g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
                                        B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device)
-                g = g.view(B, Hh, Ww, Lout.cout_pad)
-                Lout.bwd_params(g, acts[3])
-                g = Lout.bwd_data(g, (Hh, Ww), mask=acts[3])
-                for i in (3, 2, 1):
-                    tower[i].bwd_params(g, acts[i - 1])
-                    g = tower[i].bwd_data(g, (Hh, Ww), mask=acts[i - 1])
-                tower[0].bwd_params(g, f)
-                dpyr[li] = tower[0].bwd_data(g, (Hh, Ww), add=dpyr[li])
+                gs.append(g.view(B, Hh, Ww, Lout.cout_pad))
                 off += cnt
-                acts.clear()
+            for li in range(5):                                           # wgrad: split-K already fills the GPU per level
+                Lout.bwd_params(gs[li], acts[li][3])
+            gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
+            for i in (3, 2, 1):
+                for li in range(5):
+                    tower[i].bwd_params(gs[li], acts[li][i - 1])
+                gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)])
+            for li in range(5):
+                tower[0].bwd_params(gs[li], pyramid[li])
+            first = dpyr[0] is None
+            dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr)
+            S["towers"][prefix] = None
             done(Lout)
             for L in reversed(tower):
                 done(L)

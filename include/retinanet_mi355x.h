@@ -172,6 +172,24 @@ int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, 
                   const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
                   void *stream);
 
+/* Grouped launch: up to RN_MAX_GROUP problems that share the weights and every scalar of the descriptor except the
+ * geometry (N, Hi, Wi, Ho, Wo, output map, batch strides) run as ONE grid -- the five pyramid levels of a head tower
+ * (D/model.py:302-304 loops over them): the small levels no longer occupy a fraction of the GPU for a full
+ * workgroup round each.  tile_end[i] = exclusive prefix sum of the problems' tile counts (tile = 128x128 outputs,
+ * 256x64 when Cout <= 64); add2 is not available in grouped launches. */
+#define RN_MAX_GROUP 5
+typedef struct rn_conv_group {
+    int n;
+    int tile_end[RN_MAX_GROUP];
+    rn_conv_desc d[RN_MAX_GROUP];
+    const float *x[RN_MAX_GROUP];
+    float *y[RN_MAX_GROUP];
+    const float *add[RN_MAX_GROUP];
+    const float *mask[RN_MAX_GROUP];
+} rn_conv_group;
+int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_packed, const float *scale, const float *shift,
+                          void *stream);
+
 /* Weight gradient: dw[co][r][s][ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*st + r - pd, ow*st + s - pd, ci]
  * (fp32 atomics into a zeroed or previously accumulated [Cout][Kpad] buffer, same layout as the packed forward
  * weights; heads accumulate their five pyramid levels into one buffer).  dy: [N,Ho,Wo,Cout] with channel
