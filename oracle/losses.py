@@ -142,7 +142,7 @@ def focal_loss_dir(cls, reg, anchors, ann):
         lab = lab[lab[:, 20] != -1]
         if lab.shape[0] == 0:
             cls_terms.append(_empty_image_cls(p))
-            reg_terms.append(torch.zeros((), dtype=cls.dtype))
+            reg_terms.append(torch.zeros((), dtype=cls.dtype, device=cls.device))
             continue
         _, arg, state = assign(anc, envelope_boxes(lab[:, :16]))
         pos = state == 1
@@ -151,8 +151,8 @@ def focal_loss_dir(cls, reg, anchors, ann):
         tgt = _cls_targets(p, state, picked[:, 20].long())
         cls_terms.append(_focal_terms(p, tgt).sum() / npos.float().clamp(min=1.0))
         if npos == 0:
-            reg_terms.append(torch.zeros((), dtype=cls.dtype))
-            vp_terms.append(torch.zeros((), dtype=cls.dtype))
+            reg_terms.append(torch.zeros((), dtype=cls.dtype, device=cls.device))
+            vp_terms.append(torch.zeros((), dtype=cls.dtype, device=cls.device))
             continue
         t = picked[pos, :20]
         r = reg[j][pos]
@@ -169,7 +169,7 @@ def focal_loss_dir(cls, reg, anchors, ann):
         tn[:, 0::2] = (t[:, 0::2] - acx[pos, None]) / aw[pos, None]
         tn[:, 1::2] = (t[:, 1::2] - acy[pos, None]) / ah[pos, None]
         diff = (tn - pred).abs()
-        wts = torch.ones(20, dtype=diff.dtype)
+        wts = torch.ones(20, dtype=diff.dtype, device=diff.device)
         wts[8:16] = TOP_WEIGHT
         reg_terms.append(_smooth_l1(diff * wts).mean())
     return (torch.stack(cls_terms).mean(0, keepdim=True),
@@ -189,7 +189,7 @@ def focal_loss_2d(cls, reg, anchors, ann):
         lab = lab[lab[:, 4] != -1]
         if lab.shape[0] == 0:
             cls_terms.append(_empty_image_cls(p))
-            reg_terms.append(torch.zeros((), dtype=cls.dtype))
+            reg_terms.append(torch.zeros((), dtype=cls.dtype, device=cls.device))
             continue
         _, arg, state = assign(anc, lab[:, :4])
         pos = state == 1
@@ -198,7 +198,7 @@ def focal_loss_2d(cls, reg, anchors, ann):
         tgt = _cls_targets(p, state, picked[:, 4].long())
         cls_terms.append(_focal_terms(p, tgt).sum() / npos.float().clamp(min=1.0))
         if npos == 0:
-            reg_terms.append(torch.zeros((), dtype=cls.dtype))
+            reg_terms.append(torch.zeros((), dtype=cls.dtype, device=cls.device))
             continue
         g = picked[pos]
         gw = g[:, 2] - g[:, 0]
@@ -209,7 +209,7 @@ def focal_loss_2d(cls, reg, anchors, ann):
         gh = gh.clamp(min=1)
         tgt4 = torch.stack(((gcx - acx[pos]) / aw[pos], (gcy - acy[pos]) / ah[pos],
                             torch.log(gw / aw[pos]), torch.log(gh / ah[pos])), dim=1)
-        tgt4 = tgt4 / torch.tensor([[0.1, 0.1, 0.2, 0.2]], dtype=tgt4.dtype)
+        tgt4 = tgt4 / torch.tensor([[0.1, 0.1, 0.2, 0.2]], dtype=tgt4.dtype, device=tgt4.device)
         reg_terms.append(_smooth_l1((tgt4 - reg[j][pos]).abs()).mean())
     return (torch.stack(cls_terms).mean(0, keepdim=True),
             torch.stack(reg_terms).mean(0, keepdim=True))

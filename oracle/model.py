@@ -105,7 +105,7 @@ def forward_heads(img, sd, arch):
     feats = pyramid(*backbone(img, sd, arch), sd)
     reg = torch.cat([head_tower(f, sd, "regressionModel", n_reg, False) for f in feats], dim=1)
     cls = torch.cat([head_tower(f, sd, "classificationModel", n_cls, True) for f in feats], dim=1)
-    anc = torch.from_numpy(oanchors.anchors_for_image(img.shape[2], img.shape[3]))
+    anc = torch.from_numpy(oanchors.anchors_for_image(img.shape[2], img.shape[3])).to(img.device)
     return reg, cls, anc
 
 
