@@ -32,6 +32,36 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// Bounding-box reduction of a wave on the DPP crossbar (no LDS round trips): x1,y1 -> min, x2,y2 -> max over the 64
+// lanes.  One v_min/v_max_f32_dpp per step: row_shr 1/2/4/8 scan inside each 16-lane row, then row_bcast:15 into rows
+// 1,3 and row_bcast:31 into rows 2,3; lane 63 holds the result, returned wave-uniform.  Lanes without a DPP source are
+// not written and keep their own value (neutral for min / max).  The four chains are interleaved, so every dependent
+// DPP read is >= 2 instructions behind the write it needs (the gfx9 VALU-write -> DPP-read hazard); the s_nop guard
+// the block against its neighbours, which the compiler cannot see into.
+#define RN_DPP4(ctrl)                                      \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n"                  \
+    "v_min_f32_dpp %1, %1, %1 " ctrl "\n"                  \
+    "v_max_f32_dpp %2, %2, %2 " ctrl "\n"                  \
+    "v_max_f32_dpp %3, %3, %3 " ctrl "\n"
+__device__ __forceinline__ void wave_bbox_dpp(float &x1, float &y1, float &x2, float &y2) {
+    asm volatile("s_nop 1\n"
+                 RN_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 RN_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 RN_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 RN_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 RN_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RN_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));
+    x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), 63));
+    y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), 63));
+    x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x2), 63));
+    y2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2), 63));
+}
+__device__ __forceinline__ float rn_readlane_f(float v, int lane_uniform) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
 // Block-wide sum of up to 4 values per thread for a block of NW waves.  `red` needs NW*4 floats of LDS.
 // Result valid in thread 0.
 template <int NW>

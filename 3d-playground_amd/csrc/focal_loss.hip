@@ -5,33 +5,56 @@
 // loop and runs ~40 small torch kernels per image, materialising an [A,N] IoU matrix, an [A,C] target matrix
 // and several [A,C] temporaries (348 ms forward at B=8 on 8 CPU threads).
 //
-// One launch covers the whole batch.  A workgroup owns a tile of 1024 consecutive anchors of one image:
-//   phase 0  the image's label rows are reduced to (box, area, class) in LDS; for the directional variant the
-//            box is the min/max envelope of the 8 corners (D/losses.py:93-107), NOT label cols 16:20;
-//   phase 1  one lane per anchor; labels whose box misses the bounding box of the wave's 64 consecutive anchors are
-//            skipped by a scalar branch (their IoU is exactly 0), the others get the full IoU (fp32, one rounding per operation in the
-//            reference's order -- this file is compiled with -ffp-contract=off so the 0.4 / 0.5 band
-//            comparisons and the first-maximum argmax are bit-identical to torch CPU), state into LDS;
-//            positive anchors (~0.07 %) evaluate the regression / VP terms (forward) or their gradient
-//            (backward) on the spot;
-//   phase 2  the tile's TILE*C classification values are streamed as float4 (16 B per lane, consecutive lanes
-//            consecutive addresses) against the states in LDS; forward accumulates the focal sum, backward
-//            writes dcls.
-// Sums leave the workgroup as one 4-float partial per (image, tile); a finalize kernel (one wave per image) adds
-// them in fp64 in a fixed order (no float atomics anywhere; the classification sum is bit-reproducible, the
-// positives' terms up to the order in which a tile queues its handful of positive anchors).
+// One launch covers the whole batch, forward (including the batch reduction) and backward alike.  The grid is
+// persistent: B*G workgroups, all resident; workgroup g of image j stages the image's label rows in LDS once and each
+// of its waves walks 128-anchor units, software-pipelined (the next unit's anchors and classification values are
+// requested before the current unit is processed).  Per unit:
+//   assignment  one lane per anchor; the wave reduces the bounding box of its 128 consecutive anchors (DPP), lane r
+//               tests label r against it, a ballot leaves the labels that can overlap at all (the others have IoU
+//               exactly 0); those get the full IoU -- fp32, one rounding per operation in the reference's order (this
+//               file is compiled with -ffp-contract=off, so the 0.4 / 0.5 band comparisons and the first-maximum
+//               argmax are bit-identical to torch CPU).  For the directional variant the label box is the min/max
+//               envelope of the 8 corners (D/losses.py:93-107), NOT label cols 16:20;
+//   stream      the unit's 128*C classification values as float4 (16 B per lane, consecutive lanes consecutive
+//               addresses); ~95 % of the units hold only negative anchors and take a packed-fp32 path without any
+//               per-value select; forward accumulates the focal sum, backward writes dcls;
+//   positives   (~0.07 % of anchors) are queued per wave in anchor order and evaluated when no prefetch is in flight.
+// Sums leave a workgroup as one 4-float partial, published with agent-scope atomics; the last workgroup to finish
+// adds them per image in fp64 in a fixed order and forms the batch means.  No float atomics, no order-dependent sums:
+// the losses are bit-reproducible run to run.
 //
-// Roofline: HBM.  Forward algorithmic bytes = B*A*C*4 (cls) + A*16 (anchors, L2/MALL-resident after the first
-// image) + B*N*cols*4 = 105.9 MB at B=8, A=389 205, C=8.  Backward adds the dcls and dreg
-// writes (99.6 + 149.5 MB).
+// Roofline: HBM.  Forward algorithmic bytes = B*A*C*4 (cls) + A*16 (anchors; read once per XCD, L2-resident for the other
+// images) + B*N*cols*4 = 105.9 MB at B=8, A=389 205, C=8; measured HBM reads 104 MB.  Backward adds
+// the dcls and dreg writes (99.6 + 149.5 MB).  What bounds it in practice (profiles/r01_loss_analysis.txt): a bare
+// 100 MB streaming read in the same launch shape takes 17 us; the launch, the dependent-latency prologue (labels ->
+// LDS -> first unit) and the completion/epilogue chain add ~15 us that no amount of VALU trimming removes.
 #include <math.h>
 
 #include "common.h"
 
 #define NTHR 256          // threads per workgroup
-#define APT 4             // anchors per thread
-#define TILE (NTHR * APT) // 1024 anchors per workgroup: label setup amortised, 8 float4 in flight per lane in phase 2
+#define APT 4             // anchors per thread of rn_assign
+#define TILE (NTHR * APT) // rn_assign: 1024 anchors per workgroup
 #define NWAVES (NTHR / 64)
+#define UAPT 2            // fused loss: anchors per lane per unit
+#define UNIT (64 * UAPT)  // fused loss: a wave's work item = 128 consecutive anchors of one image
+#define QCAP 256          // fused loss: capacity of a wave's queue of positive anchors (>= 2 * UNIT)
+#define RN_FOCAL_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs: no spills)
+#define RN_FOCAL_RESIDENT 768   // workgroups of the persistent grid (3 per CU).  Measured at B=8, A=389 205: 512..768 is
+                                // the optimum; more workgroups lengthen the same-address completion-counter queue
+                                // (~8 ns each) faster than they add memory-level parallelism
+
+// Workgroups per image of the persistent loss kernel: all B*G workgroups are resident in one round; G is a multiple
+// of 8 so that workgroup g of every image lands on XCD g%8 (ids are dealt round-robin) and the images share the
+// anchors of "their" units in that XCD's L2.
+static inline int focal_groups(int B, int64_t A) {
+    const int64_t units = (A + UNIT - 1) / UNIT;
+    int64_t G = (RN_FOCAL_RESIDENT / B) & ~7;
+    if (G < 8) G = 8;
+    const int64_t need = (units + NWAVES - 1) / NWAVES;          // more workgroups than units/4 would idle
+    if (G > need) G = need >= 8 ? ((need + 7) & ~7LL) : need;
+    return (int)(G < 1 ? 1 : G);
+}
 
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
@@ -58,10 +81,13 @@ struct ImageStats {       // one per image, written by finalize, read by backwar
 
 static_assert(sizeof(ImageStats) == 32, "layout");
 
+// Workspace layout: [64 B] completion counter (must be ZERO on entry to rn_focal_loss_fwd; left zero on exit)
+//                   | [B] ImageStats | [B][4] double per-image loss terms | [B][G] float4 partial sums
+#define RN_WS_HEAD 64
 extern "C" int64_t rn_focal_workspace_bytes(int B, int64_t A) {
-    const int64_t tiles = (A + TILE - 1) / TILE;
-    // [B] statistics | [B] statistics scaled by the incoming gradients (bwd) | [B][tiles] float4 partial sums
-    return 2 * (int64_t)B * sizeof(ImageStats) + (int64_t)B * tiles * 4 * sizeof(float);
+    if (B <= 0 || A <= 0) return 0;
+    return RN_WS_HEAD + (int64_t)B * sizeof(ImageStats) + (int64_t)B * 4 * sizeof(double) +
+           (int64_t)B * focal_groups(B, A) * 4 * sizeof(float);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -71,35 +97,72 @@ struct LabelLds {
     int count;
 };
 
-// Collect valid rows (class column != -1) in their original order.  Serial over N <= 256 rows by thread 0
-// would do, but a ballot-free ordered compaction by one wave keeps it short: wave 0 scans rows in chunks of 64.
+// One label row reduced to its matching box: valid iff the class column != -1 (D/losses.py:54, R/losses.py:47);
+// the directional box is the min/max envelope of the 8 corners (D/losses.py:93-107).
 template <bool DIR>
-__device__ __forceinline__ void load_labels(const float *__restrict__ ann_j, int N, LabelLds &L) {
+__device__ __forceinline__ void load_label_row(const float *__restrict__ ann_j, int N, int r, float &bx1, float &by1,
+                                               float &bx2, float &by2, bool &valid) {
     constexpr int COLS = DIR ? 27 : 5;
     constexpr int CLS_COL = DIR ? 20 : 4;
+    valid = false;
+    bx1 = by1 = bx2 = by2 = 0.f;
+    if (r < N) {
+        const float *p = ann_j + (int64_t)r * COLS;
+        valid = p[CLS_COL] != -1.0f;
+        if (DIR) {
+            bx1 = bx2 = p[0];
+            by1 = by2 = p[1];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                bx1 = fminf(bx1, p[2 * k]);
+                bx2 = fmaxf(bx2, p[2 * k]);
+                by1 = fminf(by1, p[2 * k + 1]);
+                by2 = fmaxf(by2, p[2 * k + 1]);
+            }
+        } else {
+            bx1 = p[0]; by1 = p[1]; bx2 = p[2]; by2 = p[3];
+        }
+    }
+}
+
+// The same from a raw row staged in LDS (row stride COLS words is odd: conflict-free across lanes).
+template <bool DIR>
+__device__ __forceinline__ void label_row_from_lds(const float *__restrict__ raw, int n_rows, int r, float &bx1, float &by1,
+                                                   float &bx2, float &by2, bool &valid) {
+    constexpr int COLS = DIR ? 27 : 5;
+    constexpr int CLS_COL = DIR ? 20 : 4;
+    valid = false;
+    bx1 = by1 = bx2 = by2 = 0.f;
+    if (r < n_rows) {
+        const float *p = raw + r * COLS;
+        valid = p[CLS_COL] != -1.0f;
+        if (DIR) {
+            bx1 = bx2 = p[0];
+            by1 = by2 = p[1];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                bx1 = fminf(bx1, p[2 * k]);
+                bx2 = fmaxf(bx2, p[2 * k]);
+                by1 = fminf(by1, p[2 * k + 1]);
+                by2 = fmaxf(by2, p[2 * k + 1]);
+            }
+        } else {
+            bx1 = p[0]; by1 = p[1]; bx2 = p[2]; by2 = p[3];
+        }
+    }
+}
+
+// Collect valid rows in their original order into LDS (rn_assign): wave 0 scans rows in chunks of 64, ordered
+// compaction by ballot.
+template <bool DIR>
+__device__ __forceinline__ void load_labels(const float *__restrict__ ann_j, int N, LabelLds &L) {
     if (threadIdx.x < 64) {
         int base = 0;
         for (int r0 = 0; r0 < N; r0 += 64) {
             const int r = r0 + threadIdx.x;
-            bool valid = false;
-            float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
-            if (r < N) {
-                const float *p = ann_j + (int64_t)r * COLS;
-                valid = p[CLS_COL] != -1.0f;                                   // D/losses.py:54, R/losses.py:47
-                if (DIR) {                                                     // D/losses.py:93-107
-                    bx1 = bx2 = p[0];
-                    by1 = by2 = p[1];
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) {
-                        bx1 = fminf(bx1, p[2 * k]);
-                        bx2 = fmaxf(bx2, p[2 * k]);
-                        by1 = fminf(by1, p[2 * k + 1]);
-                        by2 = fmaxf(by2, p[2 * k + 1]);
-                    }
-                } else {
-                    bx1 = p[0]; by1 = p[1]; bx2 = p[2]; by2 = p[3];
-                }
-            }
+            bool valid;
+            float bx1, by1, bx2, by2;
+            load_label_row<DIR>(ann_j, N, r, bx1, by1, bx2, by2, valid);
             const unsigned long long m = __ballot(valid);
             if (valid) {
                 const int pos = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
@@ -263,6 +326,7 @@ __device__ __forceinline__ void positive_2d(const float4 a, const float *__restr
 // `wl` carries the weight: forward  w*ln2 (0 for an ignored anchor) since ln a = ln2 * log2 a (v_log_f32, ~1 ulp);
 //                          backward +-w*scale (0 for an ignored anchor).  v_rcp_f32 (~1 ulp) replaces the divide.
 #define RN_LN2 0.69314718055994530942f
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool BWD>
 __device__ __forceinline__ float focal_elem(float x, bool pos, float wl) {
     const float p = __builtin_amdgcn_fmed3f(x, 1e-4f, 1.0f - 1e-4f);          // clamp, D/losses.py:56
@@ -274,227 +338,52 @@ __device__ __forceinline__ float focal_elem(float x, bool pos, float wl) {
     return (x < 1e-4f || x > 1.0f - 1e-4f) ? 0.f : g;                         // clamp passes no gradient outside
 }
 
-// ----------------------------------------------------------------------------------------------------------
-template <bool DIR, bool BWD>
-__global__ __launch_bounds__(NTHR) void focal_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
-                                                     const float4 *__restrict__ anchors, const float *__restrict__ ann,
-                                                     int64_t A, int C, int N, float *__restrict__ partials,
-                                                     const ImageStats *__restrict__ stats, float *__restrict__ dcls,
-                                                     float *__restrict__ dreg) {
+// Epilogue of the forward, run by the LAST workgroup to finish (completion counter): wave w adds the partials of images
+// w, w+4, ... in fp64 in a fixed lane / group order (bit-reproducible), checks whether the image has any label row,
+// derives the per-image loss terms and gradient scales; thread 0 then forms the batch means
+// (D/losses.py:152, 350, 304, 359-362).  `s_part` is 4*4*64 doubles of LDS that the caller no longer needs.
+template <bool DIR>
+__device__ __forceinline__ void focal_finalize_last(const float4 *__restrict__ partials, int G, int B,
+                                                    const float *__restrict__ ann, int N, ImageStats *__restrict__ stats,
+                                                    double *__restrict__ terms, float *__restrict__ losses,
+                                                    double *s_part) {
     constexpr int COLS = DIR ? 27 : 5;
     constexpr int CLS_COL = DIR ? 20 : 4;
-    constexpr int NREG = DIR ? 12 : 4;
-    __shared__ LabelLds L;
-    __shared__ int s_state[TILE];     // -1 ignore, 0 negative, 1 + class for a positive
-    __shared__ int s_pos[TILE];       // queue of positive anchors of the tile: local index | label row << 16
-    __shared__ int s_npos;
-    __shared__ float s_red[NWAVES * 4];
-
-    const int j = blockIdx.y;
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    const float *ann_j = ann + (int64_t)j * N * COLS;
-    if (threadIdx.x == 0) s_npos = 0;
-    // Streaming-phase loads are issued first: their HBM latency hides behind label setup and assignment.
-    const int64_t nA = (A - tile0 < TILE) ? (A - tile0) : TILE;               // anchors in this tile
-    const int64_t elems = nA * C;
-    const int64_t base = ((int64_t)j * A + tile0) * C;
-    const float *src = cls + base;
-    constexpr int PRE = 8;                                                     // float4 per lane held in registers
-    const bool pre = (C & 3) == 0 && C <= PRE;                                 // then a tile is <= PRE*NTHR float4
-    float4 xv[PRE];
-    if (pre) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(src);
-        const int n4 = (int)(elems >> 2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < B; j += NWAVES) {
+        double v[4] = {0, 0, 0, 0};
+        for (int t0 = 0; t0 < G; t0 += 64 * 4) {                             // 4 independent loads in flight per lane
+            float4 p[4];
 #pragma unroll
-        for (int k = 0; k < PRE; ++k) {                                        // unconditional (clamped) so all 8 stay in flight
-            const int v = k * NTHR + threadIdx.x;
-            xv[k] = src4[v < n4 ? v : n4 - 1];
-        }
-    }
-    load_labels<DIR>(ann_j, N, L);
-
-    float cls_scale = 0.f, reg_scale = 0.f, vp_scale = 0.f;
-    if (BWD) {
-        const ImageStats st = stats[j];
-        cls_scale = st.cls_scale; reg_scale = st.reg_scale; vp_scale = st.vp_scale;
-    }
-
-    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // focal, smooth-L1, vp, npos
-    // ---- phase 1: assignment (+ positives), one lane per anchor, APT anchors per lane.  The 256 consecutive anchors of
-    // a wave lie in a small window of the image; their bounding box is reduced across the wave once, and a label
-    // whose box misses it has IoU exactly 0 with all 64 (skipping it cannot change the max or the first argmax:
-    // IoU >= 0 and ties keep the earlier label).  The test is wave-uniform -- a scalar branch, no divergence -- and
-    // removes ~95 % of the IoU evaluations whatever the anchor order (it is merely conservative for odd layouts).
-    if (BWD) {                                                // dense dreg: zero the tile, positives overwrite below
-        const int64_t nA0 = (A - tile0 < TILE) ? (A - tile0) : TILE;
-        float4 *z = reinterpret_cast<float4 *>(dreg + ((int64_t)j * A + tile0) * NREG);
-        const int nz = (int)(nA0 * (NREG / 4));
-        for (int v = threadIdx.x; v < nz; v += NTHR) z[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-    }
-    // wave w owns anchors [w*256, w*256+256) of the tile; lane l takes w*256 + u*64 + l in round u (coalesced)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4 av[APT];
-    float lx1 = INFINITY, ly1 = INFINITY, lx2 = -INFINITY, ly2 = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < APT; ++u) {
-        const int64_t ai = tile0 + wv * (64 * APT) + u * 64 + lane;
-        av[u] = ai < A ? anchors[ai] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
-        lx1 = fminf(lx1, av[u].x); ly1 = fminf(ly1, av[u].y);
-        lx2 = fmaxf(lx2, av[u].z); ly2 = fmaxf(ly2, av[u].w);
-    }
-    // one set of four independent reductions per wave: bounding box of its 256 consecutive anchors
-    const float wx1 = uniform_f(wave_min_f(lx1)), wy1 = uniform_f(wave_min_f(ly1));
-    const float wx2 = uniform_f(wave_max_f(lx2)), wy2 = uniform_f(wave_max_f(ly2));
-    float best[APT];
-    int arg[APT];
-#pragma unroll
-    for (int u = 0; u < APT; ++u) { best[u] = 0.f; arg[u] = 0; }
-    for (int n = 0; n < L.count; ++n) {
-        const float gx1 = uniform_f(L.x1[n]), gy1 = uniform_f(L.y1[n]);
-        const float gx2 = uniform_f(L.x2[n]), gy2 = uniform_f(L.y2[n]);
-        if (!(wx2 > gx1 && gx2 > wx1 && wy2 > gy1 && gy2 > wy1)) continue;       // every iw or ih <= 0: all IoU = 0
-        const float garea = L.area[n];
-#pragma unroll
-        for (int u = 0; u < APT; ++u) {
-            const float4 a = av[u];
-            float iw = fminf(a.z, gx2) - fmaxf(a.x, gx1);                          // calc_iou's order (D/losses.py:5-22)
-            float ih = fminf(a.w, gy2) - fmaxf(a.y, gy1);
-            iw = fmaxf(iw, 0.f);
-            ih = fmaxf(ih, 0.f);
-            const float inter = iw * ih;
-            if (inter > 0.f) {                                                     // else 0 / max(ua, 1e-8) == 0
-                float ua = ((a.z - a.x) * (a.w - a.y) + garea) - inter;
-                ua = fmaxf(ua, 1e-8f);
-                const float iou = inter / ua;
-                if (iou > best[u]) { best[u] = iou; arg[u] = n; }
+            for (int k = 0; k < 4; ++k) {                                      // agent-scope loads: see the publishing side
+                const int t = t0 + k * 64 + lane;
+                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(partials) +
+                                              2 * ((int64_t)j * G + (t < G ? t : G - 1));
+                const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p[k] = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                                   __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
             }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < APT; ++u) {
-        const int al = wv * (64 * APT) + u * 64 + lane;
-        const int64_t ai = tile0 + al;
-        int state = -1;
-        if (ai < A) {
-            if (L.count == 0) {
-                state = 0;                                                    // empty image: all negative (D/losses.py:58-87)
-            } else {
-                if (best[u] < 0.4f) state = 0;                                // D/losses.py:121
-                if (best[u] >= 0.5f) {                                        // D/losses.py:124
-                    const int row = L.row[arg[u]];
-                    state = 1 + (int)ann_j[(int64_t)row * COLS + CLS_COL];    // .long() truncation, D/losses.py:131
-                    s_pos[atomicAdd(&s_npos, 1)] = al | (row << 16);          // ~0.07 % of anchors: handled below, once
-                }
-            }
-        }
-        s_state[al] = state;
-    }
-    __syncthreads();
-    // positives: regression / VP terms (forward) or their gradient rows (backward), one queued anchor per lane.
-    // Queue order varies run to run, so the fp32 partial sums of these few terms may differ in the last bit.
-    for (int q = threadIdx.x; q < s_npos; q += NTHR) {
-        const int e = s_pos[q];
-        const int al = e & 0xffff, row = e >> 16;
-        const int64_t ai = tile0 + al;
-        const float *g = ann_j + (int64_t)row * COLS;
-        const float *r = reg + ((int64_t)j * A + ai) * NREG;
-        float *dr = BWD ? dreg + ((int64_t)j * A + ai) * NREG : nullptr;
-        sums[3] += 1.f;
-        if (DIR) positive_dir<BWD>(anchors[ai], g, r, sums[1], sums[2], reg_scale, vp_scale, dr);
-        else positive_2d<BWD>(anchors[ai], g, r, sums[1], reg_scale, dr);
-    }
-
-    // ---- phase 2: stream the tile's classification values
-    float *dst = BWD ? dcls + base : nullptr;
-    if ((C & 3) == 0) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(src);
-        float4 *dst4 = reinterpret_cast<float4 *>(dst);
-        const int n4 = (int)(elems >> 2);
-        const int cq = C >> 2;                                                // float4 per anchor
-        const int cq_shift = cq == 1 ? 0 : (cq == 2 ? 1 : -1);                // C = 4 / 8: shifts instead of a division
-        auto one = [&](int v, const float4 x) {
-            const int al = cq_shift >= 0 ? (v >> cq_shift) : v / cq;
-            const int c0 = (v - al * cq) << 2;
-            const int st = s_state[al];
-            const int tc = st - 1 - c0;                                       // lane-local index of the positive class, if any
-            // per-anchor weights: negatives 0.75, the positive class 0.25, nothing for an ignored anchor (st < 0)
-            const float wn = st < 0 ? 0.f : (BWD ? -0.75f * cls_scale : 0.75f * RN_LN2);
-            const float wp = BWD ? 0.25f * cls_scale : 0.25f * RN_LN2;
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-            float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const bool pos = k == tc;                                     // st <= 0 makes tc negative
-                o[k] = focal_elem<BWD>(xs[k], pos, pos ? wp : wn);
+                if (t0 + k * 64 + lane < G) { v[0] += p[k].x; v[1] += p[k].y; v[2] += p[k].z; v[3] += p[k].w; }
             }
-            if (BWD) dst4[v] = make_float4(o[0], o[1], o[2], o[3]);
-            else sums[0] += (o[0] + o[1]) + (o[2] + o[3]);
-        };
-        if (pre) {
-#pragma unroll
-            for (int k = 0; k < PRE; ++k) {
-                const int v = k * NTHR + threadIdx.x;
-                if (v < n4) one(v, xv[k]);
-            }
-        } else {
-#pragma unroll 4
-            for (int v = threadIdx.x; v < n4; v += NTHR) one(v, src4[v]);
-        }
-    } else {
-        for (int e = threadIdx.x; e < (int)elems; e += NTHR) {
-            const int al = e / C;
-            const int c = e - al * C;
-            const int st = s_state[al];
-            const bool pos = st > 0 && c == st - 1;
-            const float wn = st < 0 ? 0.f : (BWD ? -0.75f * cls_scale : 0.75f * RN_LN2);
-            const float wp = BWD ? 0.25f * cls_scale : 0.25f * RN_LN2;
-            const float o = focal_elem<BWD>(src[e], pos, pos ? wp : wn);
-            if (BWD) dst[e] = o;
-            else sums[0] += o;
-        }
-    }
-    if (!BWD) {
-        block_sum4<NWAVES>(sums, s_red);
-        if (threadIdx.x == 0) {
-            float4 *p = reinterpret_cast<float4 *>(partials) + ((int64_t)j * gridDim.x + blockIdx.x);
-            *p = make_float4(sums[0], sums[1], sums[2], sums[3]);
-        }
-    }
-}
-
-// One workgroup, one wave per image (images beyond 16 loop): the wave adds its image's tile partials in fp64 in a
-// fixed lane/tile order (bit-reproducible), checks whether the image has any label row, and derives the per-image
-// loss terms and gradient scales; thread 0 then forms the batch means (D/losses.py:152, 350, 304, 359-362).
-template <bool DIR>
-__global__ __launch_bounds__(1024) void focal_finalize(const float4 *__restrict__ partials, int tiles, int B,
-                                                       const float *__restrict__ ann, int N,
-                                                       ImageStats *__restrict__ stats, float *__restrict__ losses) {
-    constexpr int COLS = DIR ? 27 : 5;
-    constexpr int CLS_COL = DIR ? 20 : 4;
-    __shared__ double s_l[3][1024];          // per-image loss terms (B <= 1024)
-    __shared__ float s_has[1024];
-    __shared__ double s_part[16][4][64];     // per wave: lane partials, summed in lane order by 4 lanes
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < B; j += 16) {
-        double v[4] = {0, 0, 0, 0};
-        for (int t = lane; t < tiles; t += 64) {
-            const float4 p = partials[(int64_t)j * tiles + t];
-            v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_part[wave][i][lane] = v[i];
+        for (int i = 0; i < 4; ++i) s_part[(wave * 4 + i) * 64 + lane] = v[i];
         bool any = false;
         for (int r = lane; r < N; r += 64) any |= ann[((int64_t)j * N + r) * COLS + CLS_COL] != -1.0f;
         const bool has = __ballot(any) != 0ull;
+        __builtin_amdgcn_wave_barrier();
         if (lane < 4) {                                      // same-wave LDS traffic: program order suffices
             double t = 0.0;
-            for (int k = 0; k < 64; ++k) t += s_part[wave][lane][k];
-            s_part[wave][lane][0] = t;
+            for (int k = 0; k < 64; ++k) t += s_part[(wave * 4 + lane) * 64 + k];
+            s_part[(wave * 4 + lane) * 64] = t;
         }
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = s_part[wave][i][0];
+            for (int i = 0; i < 4; ++i) v[i] = s_part[(wave * 4 + i) * 64];
             const double npos = v[3];
             ImageStats st;
             st.npos = (float)npos;
@@ -518,39 +407,363 @@ __global__ __launch_bounds__(1024) void focal_finalize(const float4 *__restrict_
                     st.reg_scale = 0.f; st.vp_scale = 0.f;
                 }
             }
-            s_l[0][j] = lc; s_l[1][j] = lr; s_l[2][j] = lv;
-            s_has[j] = st.has_labels;
+            terms[j * 4 + 0] = lc; terms[j * 4 + 1] = lr; terms[j * 4 + 2] = lv; terms[j * 4 + 3] = has ? 1.0 : 0.0;
             stats[j] = st;
         }
     }
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
         double sum[3] = {0, 0, 0};
         int vp_images = 0;
-        for (int j = 0; j < B; ++j) {
-            sum[0] += s_l[0][j]; sum[1] += s_l[1][j]; sum[2] += s_l[2][j];
-            vp_images += s_has[j] != 0.f;
+        for (int j = 0; j < B; ++j) {                                          // plain loads: independent, issued together
+            const double *t = terms + j * 4;
+            sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2];
+            vp_images += t[3] != 0.0;
         }
         losses[0] = (float)(sum[0] / B);
         losses[1] = (float)(sum[1] / B);
         // vp: mean over images that have labels; none -> 0/0 = NaN (the reference raises, D/losses.py:362)
         losses[2] = DIR ? (float)(sum[2] / (double)vp_images) : 0.f;
         for (int j = 0; j < B; ++j) {                                          // fold the batch means into the scales
-            stats[j].cls_scale /= (float)B;
-            stats[j].reg_scale /= (float)B;
-            stats[j].vp_scale = vp_images > 0 ? stats[j].vp_scale / (float)vp_images : 0.f;
+            ImageStats *st = stats + j;
+            st->cls_scale = st->cls_scale / (float)B;
+            st->reg_scale = st->reg_scale / (float)B;
+            st->vp_scale = vp_images > 0 ? st->vp_scale / (float)vp_images : 0.f;
         }
     }
 }
 
-// Multiply the per-image scales by the incoming loss gradients (device scalars: no host sync).
-__global__ void scale_kernel(const ImageStats *__restrict__ in, const float *__restrict__ g, int B,
-                             ImageStats *__restrict__ out) {
-    const int j = threadIdx.x;
-    if (j < B) {
-        ImageStats s = in[j];
-        s.cls_scale *= g[0]; s.reg_scale *= g[1]; s.vp_scale *= g[2];
-        out[j] = s;
+// ----------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined fused loss.  Grid = B*G workgroups, all resident at once; workgroup g of image j
+// stages the image's label rows in LDS once, then each of its 4 waves walks units u = g*4 + w, += G*4 (a unit =
+// 128 consecutive anchors).  Per unit a wave
+//   (0) has already requested the NEXT unit's anchors and classification values (register double buffer), so HBM
+//       latency and the VALU work of the current unit overlap inside every wave;
+//   (1) assigns its 2 anchors per lane (window test by ballot, exact IoU for the few labels that can overlap);
+//   (2) hands states to the streaming lanes through a wave-private LDS row (no workgroup barrier in the loop) and
+//       streams the unit's classification values;
+//   (3) evaluates its positives, compacted in (anchor) order by ballot prefix -- deterministic, so the whole loss is
+//       bit-reproducible run to run.
+// CQ = C/4 when C is 4 or 8 (values prefetched into registers), 0 for any other C (streamed without prefetch).
+// A template parameter, not a runtime test: loads inside conditional blocks make the compiler's s_waitcnt
+// accounting pessimistic.
+template <bool DIR, bool BWD, int CQ>
+__global__ __launch_bounds__(NTHR, RN_FOCAL_WAVES) void focal_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
+                                                     const float4 *__restrict__ anchors, const float *__restrict__ ann,
+                                                     int64_t A, int C, int N, float *__restrict__ partials,
+                                                     ImageStats *__restrict__ stats, float *__restrict__ dcls,
+                                                     float *__restrict__ dreg, int G, int units,
+                                                     unsigned *__restrict__ counter, double *__restrict__ terms,
+                                                     float *__restrict__ losses, const float *__restrict__ grad_losses) {
+    constexpr int COLS = DIR ? 27 : 5;
+    constexpr int CLS_COL = DIR ? 20 : 4;
+    constexpr int NREG = DIR ? 12 : 4;
+    constexpr int NX = CQ > 0 ? UAPT * CQ : 1;               // float4 per lane per unit held in registers
+    extern __shared__ float s_raw[];                         // the image's label rows, raw: N*COLS floats (dynamic)
+    __shared__ int s_wstate[NWAVES][UNIT];                   // per wave: -1 ignore, 0 negative, 1 + class for a positive
+    __shared__ int s_q[2][NWAVES][QCAP];                     // per wave: queue of positives -- [0] anchor index, [1] label row
+    __shared__ float s_red[NWAVES * 4];
+    __shared__ int s_last;
+    static_assert(sizeof(int) * 2 * NWAVES * QCAP >= sizeof(double) * NWAVES * 4 * 64, "epilogue scratch reuses the queues");
+
+    const int j = blockIdx.x / G, g = blockIdx.x - j * G;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: unit ids and bases stay scalar
+    const float *ann_j = ann + (int64_t)j * N * COLS;
+    float cls_scale = 0.f, reg_scale = 0.f, vp_scale = 0.f;
+    if (BWD) {                                              // per-image scales x incoming loss gradients (device scalars)
+        const ImageStats st = stats[j];
+        cls_scale = st.cls_scale * grad_losses[0];
+        reg_scale = st.reg_scale * grad_losses[1];
+        vp_scale = st.vp_scale * grad_losses[2];
+    }
+    float sums[4] = {0.f, 0.f, 0.f, 0.f};   // focal, smooth-L1, vp, npos
+    f32x2 neg2 = {0.f, 0.f};                // fast path: sum of p^2 * log2(1-p) over plain negatives
+
+    // ---- (0) request a unit: anchors first, classification values behind them (vmcnt retires in order)
+    auto issue = [&](int u, float4 (&av)[UAPT], float4 (&xv)[NX]) {
+        const int64_t a0 = (int64_t)u * UNIT;                                  // scalar: u is wave-uniform
+        const unsigned nA = (unsigned)(A - a0 < UNIT ? A - a0 : UNIT);
+        const float4 *ab = anchors + a0;
+#pragma unroll
+        for (int uu = 0; uu < UAPT; ++uu) {
+            const unsigned o = uu * 64 + lane;
+            av[uu] = ab[o < nA ? o : nA - 1];
+        }
+        if (CQ > 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(cls + ((int64_t)j * A + a0) * C);
+            const unsigned n4 = nA * CQ;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {                                     // unconditional (clamped): all stay in flight
+                const unsigned v = k * 64 + lane;
+                xv[k] = src4[v < n4 ? v : n4 - 1];
+            }
+        }
+    };
+
+    // the first unit is requested before anything else: its latency overlaps the label staging
+    const int stride = G * NWAVES;
+    int u = g * NWAVES + wv;
+    float4 avA[UAPT], avB[UAPT], xvA[NX], xvB[NX];                             // register double buffer (ping-pong: no copies)
+    if (u < units) issue(u, avA, xvA);
+
+    // labels: N*COLS contiguous floats, fetched coalesced once per workgroup (per-lane row gathers from global would
+    // cost more L2 requests than the classification stream itself)
+    for (int i = threadIdx.x; i < N * COLS; i += NTHR) s_raw[i] = ann_j[i];
+    __syncthreads();
+    // rows 0..63 live in registers for the whole kernel, one row per lane; rows beyond 64 are re-read from LDS per unit
+    const int n0 = N < 64 ? N : 64;
+    float bx1, by1, bx2, by2;
+    bool bvalid;
+    label_row_from_lds<DIR>(s_raw, n0, lane, bx1, by1, bx2, by2, bvalid);
+    const float bcls = lane < n0 ? s_raw[lane * COLS + CLS_COL] : 0.f;
+    const float barea = (bx2 - bx1) * (by2 - by1);                             // D/losses.py:6
+    bool any_valid = __ballot(bvalid) != 0ull;
+    for (int c0 = 64; c0 < N; c0 += 64)
+        any_valid |= __ballot(c0 + lane < N && s_raw[(c0 + lane) * COLS + CLS_COL] != -1.0f) != 0ull;
+
+
+    // one label against the wave's anchors; rows arrive in increasing order, so a strict > keeps the first maximum
+    auto match_one = [&](const float4 (&av)[UAPT], float (&best)[UAPT], int (&arg)[UAPT], float (&cbest)[UAPT], int row,
+                         float gx1, float gy1, float gx2, float gy2, float garea, float gcls) {
+#pragma unroll
+        for (int uu = 0; uu < UAPT; ++uu) {
+            const float4 a = av[uu];
+            float iw = fminf(a.z, gx2) - fmaxf(a.x, gx1);                          // calc_iou's order (D/losses.py:5-22)
+            float ih = fminf(a.w, gy2) - fmaxf(a.y, gy1);
+            iw = fmaxf(iw, 0.f);
+            ih = fmaxf(ih, 0.f);
+            const float inter = iw * ih;
+            if (inter > 0.f) {                                                     // else 0 / max(ua, 1e-8) == 0
+                float ua = ((a.z - a.x) * (a.w - a.y) + garea) - inter;
+                ua = fmaxf(ua, 1e-8f);
+                const float iou = inter / ua;
+                if (iou > best[uu]) { best[uu] = iou; arg[uu] = row; cbest[uu] = gcls; }
+            }
+        }
+    };
+
+    int qn = 0;                                                                // queued positives of this wave (uniform)
+    auto process = [&](int u, float4 (&av)[UAPT], const float4 (&xv)[NX]) {
+        const int64_t a0 = (int64_t)u * UNIT;
+        const int nA = (int)(A - a0 < UNIT ? A - a0 : UNIT);
+        // ---- (1) assignment.  The wave's 128 consecutive anchors lie in a small window of the image; its bounding box
+        // is reduced once (DPP), lane r tests label r against it, and one ballot yields the labels that can overlap any
+        // of them.  A label outside the window has IoU exactly 0 with all of them (skipping it cannot change the max or
+        // the first argmax: IoU >= 0 and ties keep the earlier row).
+        float lx1 = INFINITY, ly1 = INFINITY, lx2 = -INFINITY, ly2 = -INFINITY;
+#pragma unroll
+        for (int uu = 0; uu < UAPT; ++uu) {
+            if (uu * 64 + lane >= nA) av[uu] = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);   // neutral, IoU 0
+            lx1 = fminf(lx1, av[uu].x); ly1 = fminf(ly1, av[uu].y);
+            lx2 = fmaxf(lx2, av[uu].z); ly2 = fmaxf(ly2, av[uu].w);
+        }
+        wave_bbox_dpp(lx1, ly1, lx2, ly2);
+        const float wx1 = lx1, wy1 = ly1, wx2 = lx2, wy2 = ly2;
+        float best[UAPT], cbest[UAPT];
+        int arg[UAPT];
+#pragma unroll
+        for (int uu = 0; uu < UAPT; ++uu) { best[uu] = 0.f; arg[uu] = 0; cbest[uu] = 0.f; }
+        unsigned long long m = __ballot(bvalid && wx2 > bx1 && bx2 > wx1 && wy2 > by1 && by2 > wy1);
+        while (m) {                                                            // wave-uniform: scalar loop over set bits
+            const int n = __builtin_ctzll(m);
+            m &= m - 1;
+            match_one(av, best, arg, cbest, n, rn_readlane_f(bx1, n), rn_readlane_f(by1, n), rn_readlane_f(bx2, n),
+                      rn_readlane_f(by2, n), rn_readlane_f(barea, n), rn_readlane_f(bcls, n));
+        }
+        for (int c0 = 64; c0 < N; c0 += 64) {                                  // N > 64: further rows straight from LDS
+            const int nrow = N - c0 < 64 ? N - c0 : 64;
+            float cx1, cy1, cx2, cy2;
+            bool cvalid;
+            label_row_from_lds<DIR>(s_raw + c0 * COLS, nrow, lane, cx1, cy1, cx2, cy2, cvalid);
+            const float ccls = lane < nrow ? s_raw[(c0 + lane) * COLS + CLS_COL] : 0.f;
+            const float carea = (cx2 - cx1) * (cy2 - cy1);
+            unsigned long long mc = __ballot(cvalid && wx2 > cx1 && cx2 > wx1 && wy2 > cy1 && cy2 > wy1);
+            while (mc) {
+                const int n = __builtin_ctzll(mc);
+                mc &= mc - 1;
+                match_one(av, best, arg, cbest, c0 + n, rn_readlane_f(cx1, n), rn_readlane_f(cy1, n), rn_readlane_f(cx2, n),
+                          rn_readlane_f(cy2, n), rn_readlane_f(carea, n), rn_readlane_f(ccls, n));
+            }
+        }
+        int state[UAPT];
+        bool pos[UAPT];
+        bool plain = true;                                                     // lane's anchors are plain negatives (or past the end)
+#pragma unroll
+        for (int uu = 0; uu < UAPT; ++uu) {
+            const int al = uu * 64 + lane;
+            state[uu] = -1;
+            pos[uu] = false;
+            if (al < nA) {
+                if (!any_valid) {
+                    state[uu] = 0;                                            // empty image: all negative (D/losses.py:58-87)
+                } else {
+                    if (best[uu] < 0.4f) state[uu] = 0;                       // D/losses.py:121
+                    if (best[uu] >= 0.5f) {                                   // D/losses.py:124
+                        state[uu] = 1 + (int)cbest[uu];                       // .long() truncation, D/losses.py:131
+                        pos[uu] = true;
+                    }
+                }
+                plain = plain && state[uu] == 0;
+            }
+        }
+        const int64_t base = ((int64_t)j * A + a0) * C;
+        const float *src = cls + base;
+        float *dst = BWD ? dcls + base : nullptr;
+        const int n4 = nA * CQ;
+        // ---- (2) stream the unit's classification values.  Nearly every unit (~95 %) holds nothing but negative
+        // anchors: a = 1-p, m = p for every value -- packed fp32 math, no per-value selects, no state exchange; the
+        // forward keeps the common weight 0.75*ln2 out of the sum (applied once per lane at the end).
+        if (CQ > 0 && __ballot(!plain) == 0ull) {
+            float4 *dst4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const int v = k * 64 + lane;
+                if (v < n4) {
+                    const float4 x = xv[k];
+                    const f32x2 p01 = {__builtin_amdgcn_fmed3f(x.x, 1e-4f, 1.0f - 1e-4f), __builtin_amdgcn_fmed3f(x.y, 1e-4f, 1.0f - 1e-4f)};
+                    const f32x2 p23 = {__builtin_amdgcn_fmed3f(x.z, 1e-4f, 1.0f - 1e-4f), __builtin_amdgcn_fmed3f(x.w, 1e-4f, 1.0f - 1e-4f)};
+                    const f32x2 q01 = 1.0f - p01, q23 = 1.0f - p23;
+                    const f32x2 l01 = {__builtin_amdgcn_logf(q01.x), __builtin_amdgcn_logf(q01.y)};
+                    const f32x2 l23 = {__builtin_amdgcn_logf(q23.x), __builtin_amdgcn_logf(q23.y)};
+                    if (!BWD) {
+                        neg2 += (p01 * p01) * l01;
+                        neg2 += (p23 * p23) * l23;
+                    } else {
+                        const f32x2 r01 = {__builtin_amdgcn_rcpf(q01.x), __builtin_amdgcn_rcpf(q01.y)};
+                        const f32x2 r23 = {__builtin_amdgcn_rcpf(q23.x), __builtin_amdgcn_rcpf(q23.y)};
+                        const float wl = -0.75f * cls_scale;
+                        const f32x2 g01 = wl * ((2.0f * RN_LN2) * (p01 * l01) - (p01 * p01) * r01);
+                        const f32x2 g23 = wl * ((2.0f * RN_LN2) * (p23 * l23) - (p23 * p23) * r23);
+                        // p == x exactly when x lies inside the clamp range; outside it the clamp passes no gradient
+                        dst4[v] = make_float4(p01.x == x.x ? g01.x : 0.f, p01.y == x.y ? g01.y : 0.f,
+                                              p23.x == x.z ? g23.x : 0.f, p23.y == x.w ? g23.y : 0.f);
+                    }
+                }
+            }
+        } else {
+            // general unit: states go to the streaming lanes through the wave-private LDS row, positives are queued in
+            // anchor order (ballot prefix: deterministic)
+#pragma unroll
+            for (int uu = 0; uu < UAPT; ++uu) {
+                const int al = uu * 64 + lane;
+                s_wstate[wv][al] = state[uu];
+                const unsigned long long pm = __ballot(pos[uu]);               // ~0.07 % of anchors
+                if (pos[uu]) {
+                    const int q = qn + __popcll(pm & ((1ull << lane) - 1ull));
+                    s_q[0][wv][q] = (int)(a0 + al);
+                    s_q[1][wv][q] = arg[uu];
+                }
+                qn += __popcll(pm);
+            }
+            __builtin_amdgcn_wave_barrier();                                   // wave-private LDS rows: program order suffices
+            if (CQ > 0) {
+                float4 *dst4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) {
+                    const int v = k * 64 + lane;
+                    if (v < n4) {
+                        const float4 x = xv[k];
+                        const int al = CQ == 2 ? (v >> 1) : v;
+                        const int c0 = CQ == 2 ? ((v & 1) << 2) : 0;
+                        const int st = s_wstate[wv][al];
+                        const int tc = st - 1 - c0;                           // lane-local index of the positive class, if any
+                        // per-anchor weights: negatives 0.75, the positive class 0.25, nothing for an ignored anchor
+                        const float wn = st < 0 ? 0.f : (BWD ? -0.75f * cls_scale : 0.75f * RN_LN2);
+                        const float wp = BWD ? 0.25f * cls_scale : 0.25f * RN_LN2;
+                        const float xs[4] = {x.x, x.y, x.z, x.w};
+                        float o[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool isp = q == tc;                         // st <= 0 makes tc negative
+                            o[q] = focal_elem<BWD>(xs[q], isp, isp ? wp : wn);
+                        }
+                        if (BWD) dst4[v] = make_float4(o[0], o[1], o[2], o[3]);
+                        else sums[0] += (o[0] + o[1]) + (o[2] + o[3]);
+                    }
+                }
+            } else {
+                for (int e = lane; e < nA * C; e += 64) {                      // any C: no prefetch, one value per lane
+                    const int al = e / C;
+                    const int c = e - al * C;
+                    const int st = s_wstate[wv][al];
+                    const bool isp = st > 0 && c == st - 1;
+                    const float wn = st < 0 ? 0.f : (BWD ? -0.75f * cls_scale : 0.75f * RN_LN2);
+                    const float wp = BWD ? 0.25f * cls_scale : 0.25f * RN_LN2;
+                    const float o = focal_elem<BWD>(src[e], isp, isp ? wp : wn);
+                    if (BWD) dst[e] = o;
+                    else sums[0] += o;
+                }
+            }
+        }
+
+        // backward: zero the unit's dense dreg rows now; the rows of its positives are written when the queue is
+        // drained, by the same wave (same-wave stores to one address stay in order)
+        if (BWD) {
+            float4 *z = reinterpret_cast<float4 *>(dreg + ((int64_t)j * A + a0) * NREG);
+            const int nz = nA * (NREG / 4);
+            for (int v = lane; v < nz; v += 64) z[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();                                       // the state row is reused by the next unit
+    };
+
+    // ---- (3) positives: regression / VP terms (forward) or their gradient rows (backward), one queued anchor per
+    // lane.  Runs when no prefetch is in flight (these terms are register-hungry), on the positives of several units
+    // at once.
+    auto drain = [&]() {
+        for (int q = lane; q < qn; q += 64) {
+            const int64_t ai = s_q[0][wv][q];
+            const float *gl = s_raw + s_q[1][wv][q] * COLS;
+            const float *r = reg + ((int64_t)j * A + ai) * NREG;
+            float *dr = BWD ? dreg + ((int64_t)j * A + ai) * NREG : nullptr;
+            sums[3] += 1.f;
+            if (DIR) positive_dir<BWD>(anchors[ai], gl, r, sums[1], sums[2], reg_scale, vp_scale, dr);
+            else positive_2d<BWD>(anchors[ai], gl, r, sums[1], reg_scale, dr);
+        }
+        __builtin_amdgcn_wave_barrier();
+        qn = 0;
+    };
+
+    bool primed = true;
+    while (u < units) {                                                        // wave-uniform; normally a single pass
+        if (!primed) issue(u, avA, xvA);
+        primed = false;
+        while (true) {                                                         // invariant: qn <= QCAP - UNIT
+            int un = u + stride;
+            issue(un < units ? un : u, avB, xvB);                              // past the end: re-request the current unit (L2-hot)
+            process(u, avA, xvA);
+            u = un;
+            if (u >= units || qn > QCAP - UNIT) break;                         // queue nearly full: drop the prefetch, drain, resume
+            un = u + stride;
+            issue(un < units ? un : u, avA, xvA);
+            process(u, avB, xvB);
+            u = un;
+            if (u >= units || qn > QCAP - UNIT) break;
+        }
+        drain();
+    }
+    if (!BWD) {
+        sums[0] += (-0.75f * RN_LN2) * (neg2.x + neg2.y);
+        block_sum4<NWAVES>(sums, s_red);
+        if (threadIdx.x == 0) {
+            // Publish the partial with agent-scope atomic exchanges: they are performed at the memory-side coherence
+            // point, visible to every XCD, without an L2 writeback (a __threadfence() per workgroup is a full L2 flush
+            // on this multi-XCD part and costs more than the whole kernel).  The count goes out once they are done.
+            unsigned long long *p64 = reinterpret_cast<unsigned long long *>(partials) + 2 * ((int64_t)j * G + g);
+            const unsigned long long lo = ((unsigned long long)__float_as_uint(sums[1]) << 32) | __float_as_uint(sums[0]);
+            const unsigned long long hi = ((unsigned long long)__float_as_uint(sums[3]) << 32) | __float_as_uint(sums[2]);
+            (void)__hip_atomic_exchange(p64, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_exchange(p64 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (s_last) {                                                          // every partial is in: finish the losses here
+            focal_finalize_last<DIR>(reinterpret_cast<const float4 *>(partials), G, (int)(gridDim.x / G), ann, N, stats,
+                                     terms, losses, reinterpret_cast<double *>(&s_q[0][0][0]));
+            if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+        }
     }
 }
 
@@ -558,8 +771,24 @@ static int check_args(int B, int64_t A, int C, int N) {
     if (B <= 0 || A <= 0 || C <= 0 || N < 0) return RN_EINVAL;
     if (N > RN_MAX_GT) return RN_ETOOMANY;
     if (B > 1024) return RN_EINVAL;
-    if ((A + TILE - 1) / TILE > 0x7fffffffLL || B > 65535) return RN_EINVAL;
+    if (A > 0x7fffffffLL) return RN_EINVAL;                                      // anchor / unit ids are ints; grid = B*G <= 1024*160
     return RN_OK;
+}
+
+struct FocalWs {
+    unsigned *counter;
+    ImageStats *stats;
+    double *terms;
+    float *partials;
+};
+static inline FocalWs focal_ws(void *workspace, int B) {
+    char *w = reinterpret_cast<char *>(workspace);
+    FocalWs r;
+    r.counter = reinterpret_cast<unsigned *>(w);
+    r.stats = reinterpret_cast<ImageStats *>(w + RN_WS_HEAD);
+    r.terms = reinterpret_cast<double *>(w + RN_WS_HEAD + (size_t)B * sizeof(ImageStats));
+    r.partials = reinterpret_cast<float *>(w + RN_WS_HEAD + (size_t)B * sizeof(ImageStats) + (size_t)B * 4 * sizeof(double));
+    return r;
 }
 
 extern "C" int rn_focal_loss_fwd(const float *cls, const float *reg, const float *anchors, const float *ann, int B,
@@ -568,22 +797,23 @@ extern "C" int rn_focal_loss_fwd(const float *cls, const float *reg, const float
     const int rc = check_args(B, A, C, N);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int tiles = (int)((A + TILE - 1) / TILE);
-    ImageStats *stats = reinterpret_cast<ImageStats *>(workspace);
-    float *partials = reinterpret_cast<float *>(stats + 2 * B);
-    const dim3 grid(tiles, B), block(NTHR);
+    const int G = focal_groups(B, A);
+    const int units = (int)((A + UNIT - 1) / UNIT);
+    const FocalWs ws = focal_ws(workspace, B);
+    const dim3 grid((unsigned)(B * G)), block(NTHR);
     const float4 *anc = reinterpret_cast<const float4 *>(anchors);
+    const int cq = C == 4 ? 1 : (C == 8 ? 2 : 0);
+    const size_t raw_bytes = (size_t)(N > 0 ? N : 1) * (directional ? 27 : 5) * sizeof(float);   // label rows in LDS
+#define RN_FOCAL_FWD(DIR_, CQ_)                                                                                        \
+    hipLaunchKernelGGL((focal_kernel<DIR_, false, CQ_>), grid, block, raw_bytes, s, cls, reg, anc, ann, A, C, N,        \
+                       ws.partials, ws.stats, (float *)nullptr, (float *)nullptr, G, units, ws.counter, ws.terms, losses, \
+                       (const float *)nullptr)
     if (directional) {
-        hipLaunchKernelGGL((focal_kernel<true, false>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, partials,
-                           (const ImageStats *)nullptr, (float *)nullptr, (float *)nullptr);
-        hipLaunchKernelGGL(focal_finalize<true>, dim3(1), dim3(1024), 0, s, (const float4 *)partials, tiles, B, ann, N,
-                           stats, losses);
+        if (cq == 2) RN_FOCAL_FWD(true, 2); else if (cq == 1) RN_FOCAL_FWD(true, 1); else RN_FOCAL_FWD(true, 0);
     } else {
-        hipLaunchKernelGGL((focal_kernel<false, false>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, partials,
-                           (const ImageStats *)nullptr, (float *)nullptr, (float *)nullptr);
-        hipLaunchKernelGGL(focal_finalize<false>, dim3(1), dim3(1024), 0, s, (const float4 *)partials, tiles, B, ann, N,
-                           stats, losses);
+        if (cq == 2) RN_FOCAL_FWD(false, 2); else if (cq == 1) RN_FOCAL_FWD(false, 1); else RN_FOCAL_FWD(false, 0);
     }
+#undef RN_FOCAL_FWD
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -594,18 +824,23 @@ extern "C" int rn_focal_loss_bwd(const float *cls, const float *reg, const float
     const int rc = check_args(B, A, C, N);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int tiles = (int)((A + TILE - 1) / TILE);
-    const ImageStats *stats = reinterpret_cast<const ImageStats *>(workspace);
-    ImageStats *scaled = const_cast<ImageStats *>(stats) + B;                  // second block of the workspace
-    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1024), 0, s, stats, grad_losses, B, scaled);
-    const dim3 grid(tiles, B), block(NTHR);
+    const int G = focal_groups(B, A);
+    const int units = (int)((A + UNIT - 1) / UNIT);
+    const FocalWs ws = focal_ws(const_cast<void *>(workspace), B);
+    const dim3 grid((unsigned)(B * G)), block(NTHR);
     const float4 *anc = reinterpret_cast<const float4 *>(anchors);
-    if (directional)
-        hipLaunchKernelGGL((focal_kernel<true, true>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, (float *)nullptr,
-                           (const ImageStats *)scaled, dcls, dreg);
-    else
-        hipLaunchKernelGGL((focal_kernel<false, true>), grid, block, 0, s, cls, reg, anc, ann, A, C, N, (float *)nullptr,
-                           (const ImageStats *)scaled, dcls, dreg);
+    const int cq = C == 4 ? 1 : (C == 8 ? 2 : 0);
+    const size_t raw_bytes = (size_t)(N > 0 ? N : 1) * (directional ? 27 : 5) * sizeof(float);   // label rows in LDS
+#define RN_FOCAL_BWD(DIR_, CQ_)                                                                                      \
+    hipLaunchKernelGGL((focal_kernel<DIR_, true, CQ_>), grid, block, raw_bytes, s, cls, reg, anc, ann, A, C, N,       \
+                       (float *)nullptr, ws.stats, dcls, dreg, G, units, (unsigned *)nullptr, (double *)nullptr,      \
+                       (float *)nullptr, grad_losses)
+    if (directional) {
+        if (cq == 2) RN_FOCAL_BWD(true, 2); else if (cq == 1) RN_FOCAL_BWD(true, 1); else RN_FOCAL_BWD(true, 0);
+    } else {
+        if (cq == 2) RN_FOCAL_BWD(false, 2); else if (cq == 1) RN_FOCAL_BWD(false, 1); else RN_FOCAL_BWD(false, 0);
+    }
+#undef RN_FOCAL_BWD
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

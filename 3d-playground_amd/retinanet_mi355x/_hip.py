@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libretinanet_mi355x.so")
+LIB_PATH = os.environ.get("RN_LIB_PATH") or os.path.join(_HERE, "lib", "libretinanet_mi355x.so")   # env: kernel A/B builds
 _lib = None
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p

@@ -154,7 +154,7 @@ class _NetFn(torch.autograd.Function):
         lib = _hip.load()
         ann_c = _hip.f32c(ann)
         B, A, C = cls.shape
-        ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=img.device)
+        ws = ops.focal_workspace(B, A, img.device)
         losses = torch.empty(3, dtype=torch.float32, device=img.device)
         _hip.check(lib.rn_focal_loss_fwd(cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c), B, A, C,
                                          ann_c.shape[1], int(net.directional), ws.data_ptr(), losses.data_ptr(),

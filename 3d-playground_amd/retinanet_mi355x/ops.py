@@ -62,6 +62,14 @@ def assign(anchor_boxes, ann, directional=True):
 
 
 # ------------------------------------------------------------------------------------------------ loss
+def focal_workspace(B, A, device):
+    """Workspace of rn_focal_loss_fwd / _bwd.  The first 64 bytes are the forward's completion counter and must be zero
+    on entry (the kernel leaves them zero); the rest needs no initialisation."""
+    ws = torch.empty(_hip.load().rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=device)
+    ws[:64].zero_()
+    return ws
+
+
 class _FocalLossFn(torch.autograd.Function):
     """FocalLoss.forward (D/losses.py:27-362 / R/losses.py:27-177) with a hand-written backward."""
 
@@ -79,7 +87,7 @@ class _FocalLossFn(torch.autograd.Function):
             raise RuntimeError("focal loss: shapes cls %s reg %s anchors %s ann %s do not fit the %s variant"
                                % (tuple(cls.shape), tuple(reg.shape), tuple(anchor_boxes.shape), tuple(ann.shape),
                                   "directional" if directional else "2D"))
-        ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=cls_c.device)
+        ws = focal_workspace(B, A, cls_c.device)
         losses = torch.empty(3, dtype=torch.float32, device=cls_c.device)
         with torch.cuda.device(cls_c.device):
             _hip.check(lib.rn_focal_loss_fwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),

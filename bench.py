@@ -50,8 +50,9 @@ def parse():
 
 
 def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
-    """Fused IoU + assignment + focal / smooth-L1 / VP forward at the benchmark shape, against the HBM roof.
-    Algorithmic bytes: cls B*A*C*4 + anchors A*16 + labels B*N*27*4."""
+    """Fused IoU + assignment + focal / smooth-L1 / VP loss at the benchmark shape, against the HBM roof: forward (one
+    launch incl. the batch reduction) and backward.  Algorithmic bytes: forward reads cls B*A*C*4 +
+    anchors A*16 + labels B*N*27*4; backward re-reads those and writes dcls B*A*C*4 + dreg B*A*12*4."""
     from retinanet_mi355x import _hip, ops, synth
     lib = _hip.load()
     A = ops.anchor_count(H, W)
@@ -60,27 +61,41 @@ def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
     reg = reg.to(dev).expand(B, A, 12).contiguous()
     ann = synth.labels_dir(B, N, H, W, C, seed=1).to(dev)
     anc = ops.anchors(H, W, dev)
-    ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=dev)   # counter zero on entry
     out = torch.empty(3, device=dev)
+    g = torch.ones(3, device=dev)
+    dcls, dreg = torch.empty_like(cls), torch.empty_like(reg)
 
-    def run():
+    def fwd():
         _hip.check(lib.rn_focal_loss_fwd(cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), B, A, C, N, 1,
                                          ws.data_ptr(), out.data_ptr(), _hip.stream()), "rn_focal_loss_fwd")
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    nbytes = B * A * C * 4 + A * 16 + B * N * 27 * 4
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "focal_kernel<dir,fwd> + focal_finalize", "bound": "hbm", "achieved": round(gbs, 1),
-            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "ms": round(ms, 4),
-            "algorithmic_bytes": nbytes}
+
+    def bwd():
+        _hip.check(lib.rn_focal_loss_bwd(cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), B, A, C, N, 1,
+                                         ws.data_ptr(), g.data_ptr(), dcls.data_ptr(), dreg.data_ptr(), _hip.stream()),
+                   "rn_focal_loss_bwd")
+
+    def timeit(run):
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    fbytes = B * A * C * 4 + A * 16 + B * N * 27 * 4
+    bbytes = fbytes + B * A * C * 4 + B * A * 12 * 4
+    res = {}
+    for name, run, nbytes in (("focal_loss_fwd", fwd, fbytes), ("focal_loss_bwd", bwd, bbytes)):
+        ms = timeit(run)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        res[name] = {"kernel": "focal_kernel<dir,%s>" % name[-3:], "bound": "hbm", "achieved": round(gbs, 1),
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "ms": round(ms, 4),
+                     "algorithmic_bytes": nbytes}
+    return res
 
 
 def pmc_traffic(kind):
@@ -194,7 +209,20 @@ def main():
             r["kernel"] = dom
             r["traffic"] = pmc_traffic(dom)
             line["roofline"] = r
-            kernels["focal_loss_fwd"] = loss_kernel_roofline(dev, B, H, W)
+            kernels.update(loss_kernel_roofline(dev, B, H, W))
+            # north_star target "MFMA roofline on the ResNet-50-FPN forward": conv kernels of forward-only passes
+            ftimer = prof.ACTIVE = prof.KernelTimer()
+            with torch.no_grad():
+                for _ in range(3):
+                    net([img, ann])
+            torch.cuda.synchronize()
+            prof.ACTIVE = None
+            fs = ftimer.summary().values()
+            fwork, fms = sum(a["work_total"] for a in fs), sum(a["ms_total"] for a in fs)
+            ftf = fwork / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+            kernels["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": PEAK_F32_MFMA_TF,
+                                        "unit": "TFLOP/s", "frac": round(ftf / PEAK_F32_MFMA_TF, 4),
+                                        "ms_per_pass": round(fms / 3, 2), "gflop_per_image": round(fwork / 3 / B / 1e9, 1)}
             line["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, H, W)

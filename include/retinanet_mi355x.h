@@ -44,13 +44,16 @@ int rn_pairwise_iou(const float *a, const float *b, float *iou, int64_t A, int N
 
 /* ---------------------------------------------------------------- focal / smooth-L1 / VP loss -------------
  * Replaces FocalLoss.forward, directional (D/losses.py:27-362, label_cols = 27, n_reg = 12) and 2D
- * (R/losses.py:27-177, label_cols = 5, n_reg = 4) in one fused pass per image tile: corner-envelope /
+ * (R/losses.py:27-177, label_cols = 5, n_reg = 4) in ONE launch each way (forward incl. the batch reduction): corner-envelope /
  * box IoU against every valid label row, max + first-argmax, 0.4/0.5 bands, alpha=.25 gamma=2 focal BCE on
  * clamp(cls,1e-4,1-1e-4), and for positives the smooth-L1 (beta 1/9; 20 values with the 0.5 top-corner
  * weight, or 4 std-scaled deltas) and the vanishing-point cosine term.
  *
  *   cls [B,A,C] post-sigmoid, reg [B,A,n_reg], anchors [A,4], ann [B,N,label_cols] (padding rows: class -1)
- *   workspace: rn_focal_workspace_bytes(B, A) bytes, written by fwd, read by bwd (per-image statistics)
+ *   workspace: rn_focal_workspace_bytes(B, A) bytes, written by fwd, read by bwd (per-image statistics).  Its first
+ *           64 bytes hold the forward's completion counter and must be ZERO when rn_focal_loss_fwd is called; the
+ *           kernel leaves them zero, so a workspace can be reused call after call without clearing it again
+ *           (re-zero it after an aborted launch).  One workspace serves one stream at a time.
  *   losses: 3 floats  (cls, reg, vp; vp = 0 for the 2D variant).  An all-empty batch yields vp = NaN
  *           (the reference raises there, D/losses.py:362; the Python binding raises before launching).
  *   bwd: grad_losses = 3 device floats (dL/dcls_loss, dL/dreg_loss, dL/dvp_loss); writes dense

@@ -25,7 +25,7 @@ def main():
         sets.append((cls, reg))
     ann = synth.labels_dir(B, N, H, W, C, seed=1).to(dev)
     anc = ops.anchors(H, W, dev)
-    ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=dev)   # counter zero on entry
     out = torch.empty(3, device=dev)
     g = torch.ones(3, device=dev)
     dcls, dreg = torch.empty_like(sets[0][0]), torch.empty_like(sets[0][1])
