@@ -99,3 +99,39 @@ def homography_inputs():
     state = synth.vehicle_states(90, seed=6)
     cam_index = np.arange(90) % 18
     return names, state, cam_index, (Ps, Hs), (Ps2, Hs2)
+
+
+def tracker_post_inputs(n_obj=120, seed=21):
+    """Detector output as the tracker receives it (MC3D_crop_tracker.py:1074): scores [d], class labels [d] i64,
+    boxes [d,20] (16 image corner coords + 2D box) and camera index [d], d = 4 * n_obj + low-score clutter.  Each
+    vehicle is seen by its own camera three times (pixel jitter: im_nms fodder) and once by a neighbouring camera
+    (space_nms fodder); clutter sits below sigma_d.  Built from the portable generators + the fixture's matrices."""
+    from oracle import homography as ohg        # only to build inputs; tests and the golden script both run on CPU
+    names, _, _, (Ps, Hs), (Ps2, Hs2) = homography_inputs()
+    n_cam = len(names)
+    state = synth.vehicle_states(n_obj, seed=seed).numpy()
+    cam = (synth.uniform((n_obj,), seed + 1) * n_cam).astype(np.int64) % n_cam
+    dets, cams, scores = [], [], []
+    u = synth.uniform((n_obj, 4, 16), seed + 2).astype(np.float64)
+    sc = synth.uniform((n_obj, 4), seed + 3)
+    for k in range(4):
+        c = cam if k < 3 else (cam + 1) % n_cam
+        im = ohg.wrapper_space_to_im(ohg.state_to_space(state), Ps[c], Ps2[c]).reshape(n_obj, 16)
+        dets.append(im + (u[:, k] - 0.5) * (6.0 if k < 3 else 2.0))
+        cams.append(c)
+        scores.append(0.15 + 0.84 * sc[:, k])
+    det = np.concatenate(dets).astype(np.float32)
+    cams = np.concatenate(cams)
+    scores = np.concatenate(scores).astype(np.float32)
+    n_cl = n_obj // 2                                                        # clutter below the confidence cutoff
+    det = np.concatenate((det, det[:n_cl] + 40.0))
+    cams = np.concatenate((cams, cams[:n_cl]))
+    scores = np.concatenate((scores, (0.09 * synth.uniform((n_cl,), seed + 4)).astype(np.float32)))
+    perm = np.argsort(synth.uniform((len(scores),), seed + 5), kind="stable")   # detector order is not grouped
+    det, cams, scores = det[perm], cams[perm], scores[perm]
+    xs, ys = det[:, 0:16:2], det[:, 1:16:2]
+    box2d = np.stack((xs.min(1), ys.min(1), xs.max(1), ys.max(1)), 1)
+    boxes = np.concatenate((det, box2d), 1).astype(np.float32)
+    labels = (synth.uniform((len(scores),), seed + 6) * 8).astype(np.int64) % 8
+    return (torch.from_numpy(scores), torch.from_numpy(labels), torch.from_numpy(boxes), torch.from_numpy(cams),
+            names, (Ps, Hs), (Ps2, Hs2))

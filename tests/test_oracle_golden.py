@@ -211,3 +211,35 @@ def test_homography_golden(golden):
     assert np.allclose(ohg.wrapper_space_to_im(space, P[9], P2[9]), z["wr_im_one"], rtol=1e-12, atol=1e-9)
     wr_back = ohg.space_to_state(ohg.wrapper_im_to_space(z["wr_im_list"], H[cam], H2[cam], h))
     assert np.allclose(wr_back, z["wr_back_state_list"], rtol=1e-6, atol=1e-5)
+
+
+# ------------------------------------------------------------------ tracker detection parsing
+def test_tracker_post_golden(golden):
+    """oracle/tracker_post.py against MC_Crop_Tracker.parse_detections / im_nms / space_nms / md_iou run in the
+    reference (tools/make_golden.py gen_tracker_post).  Index outputs exact; states within fp32 round-off."""
+    from oracle import tracker_post as otp
+    z = golden("tracker_post")
+    scores, labels, boxes, cams, names, (P, H), (P2, H2) = gc.tracker_post_inputs()
+    keep = scores > 0.1
+    det = boxes[keep].reshape(-1, 10, 2)[:, :8, :]
+    idx = otp.im_nms(det, scores[keep], threshold=0.3, groups=cams[keep])
+    assert np.array_equal(idx.numpy(), z["im_nms_idx"])
+    assert np.array_equal(otp.im_nms(det, scores[keep], threshold=0.3).numpy(), z["im_nms_idx_nogroups"])
+    # the quirk: the camera id does not keep boxes of different cameras apart
+    assert len(set(cams[keep][idx].tolist())) > 1 and len(idx) < int(keep.sum())
+    for tag, kw in (("nms", dict(perform_nms=True, refine_height=False)),
+                    ("nms_refine", dict(perform_nms=True, refine_height=True)),
+                    ("plain", dict(perform_nms=False, refine_height=False))):
+        st, lb, sc, cm = otp.parse_detections(scores, labels, boxes, cams, H, H2, P, P2, **kw)
+        assert np.array_equal(lb.numpy(), z[tag + "_labels"]), tag
+        assert np.array_equal(cm.numpy(), z[tag + "_cams"]), tag
+        assert np.array_equal(sc.numpy(), z[tag + "_scores"]), tag
+        assert np.allclose(st.numpy(), z[tag + "_state"], rtol=1e-5, atol=1e-4), tag
+    st = torch.from_numpy(z["plain_state"])
+    assert np.array_equal(otp.space_nms(st, torch.from_numpy(z["plain_scores"]), threshold=0.2).numpy(), z["space_nms_idx"])
+    b4 = boxes[:64, 16:20].double()
+    assert np.allclose(otp.md_iou(b4[None].repeat(64, 1, 1), b4[:, None].repeat(1, 64, 1)).numpy(), z["md_iou"],
+                       rtol=1e-12, equal_nan=True)
+    assert z["empty_is_lists"].all()
+    assert otp.parse_detections(scores[:0], labels[:0], boxes[:0], cams[:0], H, H2, P, P2) == ([], [], [], [])
+    assert otp.parse_detections(scores * 0.01, labels, boxes, cams, H, H2, P, P2) == ([], [], [], [])

@@ -319,6 +319,63 @@ def gen_csv_kat():
                         columns=np.array(["cam_code"] + keep))
 
 
+def gen_tracker_post():
+    """MC_Crop_Tracker.parse_detections / im_nms / space_nms / md_iou (MC3D_crop_tracker.py:319-383, 592-636,
+    1030-1049) run UNBOUND on a stand-in ``self`` that carries only the attributes those methods read (sigma_d,
+    phi_nms_*, cameras, est_ts, hg = the reference's own Homography_Wrapper filled with the fixture's matrices).
+    The module imports behind two more stub attributes (torchvision.transforms.functional, torchvision.ops.roi_align);
+    constructing the tracker itself needs videos and checkpoints the reference does not ship."""
+    tv = sys.modules["torchvision"]
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvt.functional = tvf
+    tv.transforms = tvt
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.functional"] = tvf
+
+    def _no_roi_align(*a, **k):
+        raise NotImplementedError("roi_align is not on this path")
+    sys.modules["torchvision.ops"].roi_align = _no_roi_align
+    sys.path.insert(0, REF)
+    try:
+        trk = importlib.import_module("MC3D_crop_tracker")
+        hgmod = importlib.import_module("homography")
+    finally:
+        sys.path.remove(REF)
+    T = trk.MC_Crop_Tracker
+    scores, labels, boxes, cams, names, (Ps, Hs), (Ps2, Hs2) = gc.tracker_post_inputs()
+
+    def make_hg(P, H):
+        hg = hgmod.Homography()
+        hg.correspondence = {n: {"P": P[i], "H": H[i], "H_inv": np.linalg.inv(H[i])} for i, n in enumerate(names)}
+        hg.default_correspondence = names[0]
+        return hg
+    me = types.SimpleNamespace(sigma_d=0.1, phi_nms_im=0.3, phi_nms_space=0.2, cameras=list(names), est_ts=False,
+                               hg=hgmod.Homography_Wrapper(hg1=make_hg(Ps, Hs), hg2=make_hg(Ps2, Hs2)))
+    me.im_nms = types.MethodType(T.im_nms, me)
+    me.space_nms = types.MethodType(T.space_nms, me)
+    out = {}
+    for tag, kw in (("nms", dict(perform_nms=True, refine_height=False)),
+                    ("nms_refine", dict(perform_nms=True, refine_height=True)),
+                    ("plain", dict(perform_nms=False, refine_height=False))):
+        st, lb, sc, cm = T.parse_detections(me, scores.clone(), labels.clone(), boxes.clone(), cams.clone(), **kw)
+        out[tag + "_state"], out[tag + "_labels"] = t2n(st), t2n(lb)
+        out[tag + "_scores"], out[tag + "_cams"] = t2n(sc), t2n(cm)
+    keep = scores > 0.1
+    det = boxes[keep].reshape(-1, 10, 2)[:, :8, :]
+    out["im_nms_idx"] = t2n(T.im_nms(me, det, scores[keep], groups=cams[keep], threshold=0.3))
+    out["im_nms_idx_nogroups"] = t2n(T.im_nms(me, det, scores[keep], threshold=0.3))
+    st_plain = torch.from_numpy(out["plain_state"])
+    out["space_nms_idx"] = t2n(T.space_nms(me, st_plain, torch.from_numpy(out["plain_scores"]), threshold=0.2))
+    b4 = boxes[:64, 16:20].double()
+    out["md_iou"] = t2n(T.md_iou(me, b4[None].repeat(64, 1, 1), b4[:, None].repeat(1, 64, 1)))
+    empty = T.parse_detections(me, scores[:0], labels[:0], boxes[:0], cams[:0])
+    low = T.parse_detections(me, scores * 0.01, labels, boxes, cams)
+    out["empty_is_lists"] = np.array([all(isinstance(e, list) and len(e) == 0 for e in empty),
+                                      all(isinstance(e, list) and len(e) == 0 for e in low)])
+    np.savez_compressed(os.path.join(OUT, "tracker_post.npz"), **out)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
@@ -329,7 +386,7 @@ def main():
     m_dir, l_dir, u_dir, a_dir = import_variant("dir")
     dir_mods = (m_dir, l_dir, u_dir, a_dir)
     m_2d, l_2d, u_2d, a_2d = import_variant("2d")
-    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv"}
+    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv", "tracker_post"}
     if "anchors" in which:
         gen_anchors(a_dir)
     if "losses" in which:
@@ -342,6 +399,8 @@ def main():
         gen_homography()
     if "csv" in which:
         gen_csv_kat()
+    if "tracker_post" in which:
+        gen_tracker_post()
     for fn in sorted(os.listdir(OUT)):
         print("%-20s %8.1f KiB" % (fn, os.path.getsize(os.path.join(OUT, fn)) / 1024))
     del dir_mods
