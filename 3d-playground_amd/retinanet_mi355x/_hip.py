@@ -40,6 +40,10 @@ SIGNATURES = {
     "rn_space_to_im": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rn_im_to_space": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rn_im_to_state": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rn_parse_workspace_bytes": (c_i64, [c_i64]),
+    "rn_parse_detections": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_f32, c_f32,
+                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rn_md_iou": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 
 class ConvDesc(ctypes.Structure):

@@ -370,3 +370,56 @@ def hg_from_im(im, heights, H, H2=None, mat_index=None, to_state=True):
             _hip.check(fn(im.data_ptr(), hts.data_ptr(), H.data_ptr(), _hip.ptr(H2), _hip.ptr(mat_index),
                           out.data_ptr(), d, _hip.stream()), "rn_im_to_state")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ tracker: detection parsing
+PARSE_MAX = 16384
+NMS_IM, NMS_SPACE = 1, 2
+
+
+def parse_detections(scores, labels, boxes20, camera_idxs, H1, H2, P1, P2, sigma_d, phi_nms_im, phi_nms_space,
+                     nms_flags=NMS_IM | NMS_SPACE, refine_height=False, heights=None):
+    """MC_Crop_Tracker.parse_detections (MC3D_crop_tracker.py:319-383) on device, see include/retinanet_mi355x.h.
+    H*/P*: device fp64 [n_cam,3,3] / [n_cam,3,4] (index = camera index).  Returns device tensors sized for the input
+    plus the device count: (state [d,6], labels [d], scores [d], cams [d], count int32[1]); the caller slices."""
+    lib = _hip.load()
+    _hip.need_gpu(scores, labels, boxes20, camera_idxs, H1, H2, P1, P2, heights)
+    d = scores.shape[0]
+    if d > PARSE_MAX:
+        raise RuntimeError("detection parsing orders its NMS candidates in LDS and takes at most %d detections, got %d"
+                           % (PARSE_MAX, d))
+    if boxes20.shape != (d, 20) or labels.shape[0] != d or camera_idxs.shape[0] != d:
+        raise RuntimeError("parse_detections: scores %s labels %s boxes %s cameras %s do not line up"
+                           % (tuple(scores.shape), tuple(labels.shape), tuple(boxes20.shape), tuple(camera_idxs.shape)))
+    dev = scores.device
+    scores, boxes20 = _hip.f32c(scores), _hip.f32c(boxes20)
+    labels, camera_idxs = labels.long().contiguous(), camera_idxs.long().contiguous()
+    hts = None if heights is None else _hip.f32c(heights)
+    ws = torch.empty(lib.rn_parse_workspace_bytes(d), dtype=torch.uint8, device=dev)
+    out_state = torch.empty((d, 6), dtype=torch.float32, device=dev)
+    out_labels = torch.empty(d, dtype=torch.int64, device=dev)
+    out_scores = torch.empty(d, dtype=torch.float32, device=dev)
+    out_cams = torch.empty(d, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.rn_parse_detections(scores.data_ptr(), labels.data_ptr(), boxes20.data_ptr(), camera_idxs.data_ptr(), d,
+                                           H1.data_ptr(), _hip.ptr(H2), _hip.ptr(P1), _hip.ptr(P2), H1.shape[0],
+                                           _hip.ptr(hts), float(sigma_d), float(phi_nms_im), float(phi_nms_space),
+                                           int(nms_flags), int(bool(refine_height)), ws.data_ptr(), out_state.data_ptr(),
+                                           out_labels.data_ptr(), out_scores.data_ptr(), out_cams.data_ptr(),
+                                           count.data_ptr(), _hip.stream()), "rn_parse_detections")
+    return out_state, out_labels, out_scores, out_cams, count
+
+
+def md_iou(a, b):
+    """MC_Crop_Tracker.md_iou (MC3D_crop_tracker.py:1030-1049): [B,N,4] x [B,N,4] -> [B,N] fp64."""
+    lib = _hip.load()
+    _hip.need_gpu(a, b)
+    if a.shape != b.shape or a.shape[-1] != 4:
+        raise RuntimeError("md_iou: shapes %s and %s" % (tuple(a.shape), tuple(b.shape)))
+    a, b = a.double().contiguous(), b.double().contiguous()
+    out = torch.empty(a.shape[:-1], dtype=torch.float64, device=a.device)
+    if out.numel():
+        with torch.cuda.device(a.device):
+            _hip.check(lib.rn_md_iou(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), _hip.stream()), "rn_md_iou")
+    return out

@@ -124,6 +124,32 @@ int rn_im_to_space(const double *im, const float *heights, const double *H, cons
 int rn_im_to_state(const double *im, const float *heights, const double *H, const double *H2,
                    const int32_t *mat_index, float *state, int64_t d, void *stream);
 
+/* ---------------------------------------------------------------- tracker: detection parsing ---------------
+ * Replaces MC_Crop_Tracker.parse_detections with im_nms / space_nms (MC3D_crop_tracker.py:319-383, 592-636), the
+ * step right after the MULTI_FRAME detector, without leaving the device or synchronising:
+ *   keep scores > sigma_d (input order) -> NMS(phi_nms_im) on the image envelopes of the 8 corners, every box
+ *   shifted by the constant 10 000 exactly as the reference does (its per-camera offset is computed and dropped,
+ *   :610-613) -> image -> state through the camera's H of both wrapper homographies (switch at y > 60); with
+ *   refine_height, state -> image through P, height_from_template, image -> state again (:366-370)
+ *   -> NMS(phi_nms_space) on the road-plane footprints -> survivors in NMS order.
+ *   scores [d] f32, labels [d] i64, boxes20 [d,20] f32 (16 corner coords + 2D box), camera_idxs [d] i64;
+ *   H1,H2 [n_cam,3,3] / P1,P2 [n_cam,3,4] fp64 row-major, index = camera index (H2/P2 may be NULL: one homography;
+ *   P1 is only read with refine_height); heights [d] f32 per input detection or NULL = 5 ft, which is what
+ *   guess_heights returns for the integer labels the tracker passes (homography.py:502-517).
+ *   Outputs sized for d rows; out_count[0] = rows valid.  d <= RN_PARSE_MAX.  perform_nms: bit 0 = image NMS, bit 1 =
+ *   space NMS (3 = the reference's perform_nms=True, 0 = filter + transforms only, 1 = stop before the space NMS, where
+ *   the tracker's estimate_ts_bias (tracker state, :373-374; not part of this call) looks at the boxes).
+ * rn_md_iou: MC_Crop_Tracker.md_iou (:1030-1049), element-wise fp64 IoU of a[n,4], b[n,4] (union not clamped). */
+#define RN_PARSE_MAX 16384
+int64_t rn_parse_workspace_bytes(int64_t d);
+int rn_parse_detections(const float *scores, const int64_t *labels, const float *boxes20, const int64_t *camera_idxs,
+                        int64_t d, const double *H1, const double *H2, const double *P1, const double *P2, int n_cam,
+                        const float *heights, float sigma_d, float phi_nms_im, float phi_nms_space,
+                        int perform_nms, int refine_height, void *workspace,
+                        float *out_state, int64_t *out_labels, float *out_scores, int64_t *out_cams,
+                        int32_t *out_count, void *stream);
+int rn_md_iou(const double *a, const double *b, double *out, int64_t n, void *stream);
+
 /* ---------------------------------------------------------------- convolution engine ----------------------
  * fp32 implicit-GEMM convolutions on the matrix cores (v_mfma_f32_32x32x2_f32).  Replaces nn.Conv2d +
  * BatchNorm2d(eval) + ReLU + residual add (D/utils.py:25-43, 60-80), PyramidFeatures (D/model.py:84-117) and
