@@ -5,11 +5,11 @@
 // tap][ci], i.e.  M = Cout,  N = kh*kw*Cin (the packed-weight row, so a tile may span several taps of a
 // narrow layer),  K = N*Ho*Wo pixels.
 //
-// Both operands are "K-major" in memory already (NHWC: one pixel = one contiguous channel vector), so tiles are
-// staged into LDS exactly as they lie: [32 pixels][64*WM channels] and [32 pixels][64*WN flattened (tap,ci)].
-// The v_mfma_f32_32x32x2_f32 fragment A[m = lane&31][k = lane>>5] is then one ds_read_b32 with lanes 0-31 on
-// consecutive words (conflict-free), one read per MFMA operand tile; 64 reads against 64 MFMAs (64 cycles each)
-// per wave per K-step.
+// Both operands are pixel-major in memory (NHWC: one pixel = one contiguous channel vector) while the MFMA wants
+// each lane's k operands -- pixels -- of one channel row.  A thread therefore stages 4x4 blocks (4 pixels x 4
+// channels: four 16-byte global loads), transposes them in registers for free and writes four 16-byte LDS rows into
+// a [channel][32 pixels] tile (XOR-swizzled, conflict-free both ways); a fragment is then one ds_read_b128 = the k
+// operands of 4 MFMAs: 16 LDS reads against 64 MFMAs (64 cycles each) per wave per K-step.
 //
 // K is split over gridDim.y; partial tiles are added with fp32 atomics (two 128-byte row segments per wave
 // instruction, the full-rate shape) into a buffer the caller zeroes -- the five pyramid levels of a shared head
@@ -35,12 +35,17 @@ struct WgradArgs {
     int64_t pixels, per_split;   // K extent and K per grid.y slice (multiple of WK)
 };
 
+// LDS tile layout: [channel row][32 pixels], pixel-contiguous, no padding; the 16-byte slot (4 pixels) of a row is
+// XOR-swizzled with s(row) = (row & 7) ^ ((row >> 3) & 7).  Both access patterns then touch 8 distinct slots per 8
+// consecutive lanes: the staging writes (lane -> rows 4*ca + j, fixed slot) and the fragment reads (lane -> 32
+// consecutive rows, fixed slot).
+__device__ __forceinline__ int wg_swz(int row) { return (row & 7) ^ ((row >> 3) & 7); }
+
 template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int CA = BM / 4, CB = BN / 4;                  // 16-byte chunks per staged row
-    constexpr int PA = CA / 8, PB = CB / 8;                  // passes (rows per pass = 256 / chunks)
-    constexpr int RA = 256 / CA, RB = 256 / CB;
+    constexpr int CA = BM / 4, CB = BN / 4;                  // 4-channel chunks per tile
+    constexpr int NA = (CA * 8 + 255) / 256, NB = (CB * 8 + 255) / 256;   // 4x4 (pixel x channel) blocks per thread
     __shared__ float lds[2][WK * (BM + BN)];
     __shared__ int4 pixtab[2][WK];                           // per K-step: (n*Hi, oh*st - pad, ow*st - pad, valid)
 
@@ -52,11 +57,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int nks = (int)((kend - kbeg + WK - 1) / WK);
     const int HoWo = p.Ho * p.Wo;
 
-    // A staging: chunk ca of the co range, rows (tid / CA) + RA*i
-    const int ca = tid % CA, ra0 = tid / CA;
+    // Staging.  A thread owns 4x4 blocks: 4 consecutive channels (one 16-byte global load per pixel) x 4 consecutive
+    // pixels; the block is transposed in registers (free: it is only a renaming) and leaves as four 16-byte LDS
+    // writes, one per channel row, 4 pixels each.  Block b of a tile: chunk = b % chunks, pixel group = b / chunks.
+    const int ca = tid % CA, pga0 = tid / CA;                // A: block i -> pixel group pga0 + (256 / CA) * i
+    const bool a_active = (CA * 8 >= 256) || tid < CA * 8;
     const bool a_col_ok = (m0 + 4 * ca) < p.ldy;
-    // B staging: chunk cb -> fixed (tap, ci0)
-    const int cb = tid % CB, rb0 = tid / CB;
+    const int cb = tid % CB, pgb0 = tid / CB;                // B: chunk cb -> fixed (tap, ci0)
     const int jcol = n0 + 4 * cb;
     const int tap = jcol / p.Cin;
     const int ci0 = jcol - tap * p.Cin;
@@ -80,37 +87,82 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     };
     const bool do_cs = p.colsum != nullptr && (blockIdx.x % p.tiles_n) == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 va[PA], vb[PB];
+    float4 va[NA][4], vb[NB][4];
+    unsigned okmask = 0;                                     // validity of the staged blocks: bit i*4+q for A, 16 + i*4+q for B
+    // Loads are unconditional, from clamped (always mapped) addresses; what must read as zero (image padding, rows
+    // past the end of the K range, columns past the tile) is zeroed in store_step, after the MFMAs.  A select or a
+    // branch right behind a load would make the compiler wait for it here, one round trip per load.
+    const int64_t a_col = a_col_ok ? (int64_t)(m0 + 4 * ca) : 0;
+    const int ci_safe = b_col_ok ? ci0 : 0;
+    const int fr_safe = b_col_ok ? fr : 0, fs_safe = b_col_ok ? fs : 0;
     auto load_step = [&](int ks) {
         const int64_t kb = kbeg + (int64_t)ks * WK;
+        okmask = 0;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int64_t pix = kb + ra0 + RA * i;
-            va[i] = (a_col_ok && pix < kend) ? *reinterpret_cast<const float4 *>(p.dy + pix * p.ldy + m0 + 4 * ca)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NA; ++i) {
+            const int pg = pga0 + (256 / CA) * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t pix = kb + 4 * pg + q;
+                const bool ok = a_active && a_col_ok && pix < kend;
+                okmask |= ok ? (1u << (i * 4 + q)) : 0u;
+                const int64_t pc = pix < p.pixels ? pix : p.pixels - 1;
+                va[i][q] = *reinterpret_cast<const float4 *>(p.dy + pc * p.ldy + a_col);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int4 e = pixtab[ks & 1][rb0 + RB * i];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int ih = e.y + fr, iw = e.z + fs;
-            if (b_col_ok && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
-                v = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(e.x + ih) * p.Wi + iw) * p.Cin + ci0);
-                if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        for (int i = 0; i < NB; ++i) {
+            const int pg = pgb0 + (256 / CB) * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 e = pixtab[ks & 1][4 * pg + q];
+                const int ih = e.y + fr_safe, iw = e.z + fs_safe;
+                const bool ok = b_col_ok && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                okmask |= ok ? (1u << (16 + i * 4 + q)) : 0u;
+                const int ihc = ih < 0 ? 0 : (ih >= p.Hi ? p.Hi - 1 : ih);
+                const int iwc = iw < 0 ? 0 : (iw >= p.Wi ? p.Wi - 1 : iw);
+                vb[i][q] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(e.x + ihc) * p.Wi + iwc) * p.Cin + ci_safe);
             }
-            vb[i] = v;
         }
     };
     auto store_step = [&](int buf) {
         float *A = lds[buf], *B = lds[buf] + WK * BM;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            *reinterpret_cast<float4 *>(A + (ra0 + RA * i) * BM + 4 * ca) = va[i];
+        for (int i = 0; i < NA; ++i) {
+            if (!a_active) break;
+            const int pg = pga0 + (256 / CA) * i;
+            float4 *v = va[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (!(okmask & (1u << (i * 4 + q)))) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = 4 * ca;                                        // rows r..r+3 share (r >> 3) only pairwise: swizzle per row
+            *reinterpret_cast<float4 *>(A + (r + 0) * WK + 4 * (pg ^ wg_swz(r + 0))) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *reinterpret_cast<float4 *>(A + (r + 1) * WK + 4 * (pg ^ wg_swz(r + 1))) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *reinterpret_cast<float4 *>(A + (r + 2) * WK + 4 * (pg ^ wg_swz(r + 2))) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            *reinterpret_cast<float4 *>(A + (r + 3) * WK + 4 * (pg ^ wg_swz(r + 3))) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
             // column sums ride on the staged dY; accumulated here, after the MFMAs, so the loads stay in flight
-            if (do_cs) { cs.x += va[i].x; cs.y += va[i].y; cs.z += va[i].z; cs.w += va[i].w; }
+            if (do_cs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w; }
+            }
         }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4 *>(B + (rb0 + RB * i) * BN + 4 * cb) = vb[i];
+        for (int i = 0; i < NB; ++i) {
+            const int pg = pgb0 + (256 / CB) * i;
+            float4 *v = vb[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (!(okmask & (1u << (16 + i * 4 + q)))) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.in_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f); }
+            }
+            const int r = 4 * cb;
+            *reinterpret_cast<float4 *>(B + (r + 0) * WK + 4 * (pg ^ wg_swz(r + 0))) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *reinterpret_cast<float4 *>(B + (r + 1) * WK + 4 * (pg ^ wg_swz(r + 1))) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *reinterpret_cast<float4 *>(B + (r + 2) * WK + 4 * (pg ^ wg_swz(r + 2))) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            *reinterpret_cast<float4 *>(B + (r + 3) * WK + 4 * (pg ^ wg_swz(r + 3))) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
     };
 
     f32x16 acc[2][2];
@@ -129,35 +181,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         store_step(0);
     }
     __syncthreads();
-    const int fa = (lane >> 5) * BM + wm * 64 + (lane & 31);
-    const int fb = (lane >> 5) * BN + wn * 64 + (lane & 31);
+    // fragment rows of this lane: A tiles tm = 0,1 and B tiles tn = 0,1; v_mfma_f32_32x32x2_f32 wants A[m = lane&31][k = lane>>5]:
+    // one ds_read_b128 gives 4 consecutive pixels of the row = the k operands of 4 MFMAs (lanes 0-31 take pixel group 2t,
+    // lanes 32-63 group 2t+1; A and B use the same assignment, so the products pair up the same pixels)
+    const int hi = lane >> 5;
+    int rowA[2], rowB[2], swA[2], swB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowA[t] = wm * 64 + t * 32 + (lane & 31);
+        rowB[t] = wn * 64 + t * 32 + (lane & 31);
+        swA[t] = wg_swz(rowA[t]);
+        swB[t] = wg_swz(rowB[t]);
+    }
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nks) load_step(ks + 1);                 // reads pixtab[(ks+1)&1], published by an earlier barrier
-        const float *A = lds[buf] + fa;
-        const float *B = lds[buf] + WK * BM + fb;
-        // fragment reads run two k-pairs ahead of the MFMAs that consume them (distinct registers per slot), so an
-        // MFMA group never waits on a read issued one instruction earlier
-        float fa[3][2], fb[3][2];
+        const float *A = lds[buf];
+        const float *B = lds[buf] + WK * BM;
+        float4 fa[2][2], fb[2][2];                            // [slot][tile]: reads run one group of 16 MFMAs ahead
+        auto read_frag = [&](int t, float4 (&a)[2], float4 (&b)[2]) {
+            const int kg = 2 * t + hi;
 #pragma unroll
-        for (int pre = 0; pre < 2; ++pre) {
-            fa[pre][0] = A[2 * pre * BM]; fa[pre][1] = A[2 * pre * BM + 32];
-            fb[pre][0] = B[2 * pre * BN]; fb[pre][1] = B[2 * pre * BN + 32];
-        }
-#pragma unroll
-        for (int kp = 0; kp < WK / 2; ++kp) {
-            const int cur = kp % 3, nxt = (kp + 2) % 3;
-            if (kp + 2 < WK / 2) {
-                fa[nxt][0] = A[2 * (kp + 2) * BM]; fa[nxt][1] = A[2 * (kp + 2) * BM + 32];
-                fb[nxt][0] = B[2 * (kp + 2) * BN]; fb[nxt][1] = B[2 * (kp + 2) * BN + 32];
+            for (int q = 0; q < 2; ++q) {
+                a[q] = *reinterpret_cast<const float4 *>(A + rowA[q] * WK + 4 * (kg ^ swA[q]));
+                b[q] = *reinterpret_cast<const float4 *>(B + rowB[q] * WK + 4 * (kg ^ swB[q]));
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
-            // keep that order: (2 LDS reads for k-pair kp+2) then (4 MFMAs of k-pair kp)
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        };
+        read_frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int t = 0; t < WK / 8; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < WK / 8) read_frag(t + 1, fa[cur ^ 1], fb[cur ^ 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = j == 0 ? fa[cur][0].x : j == 1 ? fa[cur][0].y : j == 2 ? fa[cur][0].z : fa[cur][0].w;
+                const float a1 = j == 0 ? fa[cur][1].x : j == 1 ? fa[cur][1].y : j == 2 ? fa[cur][1].z : fa[cur][1].w;
+                const float b0 = j == 0 ? fb[cur][0].x : j == 1 ? fb[cur][0].y : j == 2 ? fb[cur][0].z : fb[cur][0].w;
+                const float b1 = j == 0 ? fb[cur][1].x : j == 1 ? fb[cur][1].y : j == 2 ? fb[cur][1].z : fb[cur][1].w;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         if (ks + 2 < nks) fill_table(ks + 2);                 // slot [ks&1] was last read by load_step(ks), before the previous barrier
         if (ks + 1 < nks) store_step(buf ^ 1);
@@ -166,13 +231,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     if (nks == 0) return;
     if (do_cs) {                                              // the last barrier of the loop freed the staging LDS
         float4 *red = reinterpret_cast<float4 *>(lds[0]);
-        red[ra0 * CA + ca] = cs;
+        constexpr int GA = (CA * 8 >= 256) ? 256 / CA : 8;    // pixel groups that carried A blocks (x NA passes, already summed)
+        if (a_active) red[pga0 * CA + ca] = cs;
         __syncthreads();
-        if (ra0 == 0) {
-            float4 t = red[ca];
+        if (tid < CA) {
+            float4 t = red[tid];
 #pragma unroll
-            for (int j = 1; j < RA; ++j) { const float4 u = red[j * CA + ca]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-            const int c = m0 + 4 * ca;
+            for (int j = 1; j < GA; ++j) { const float4 u = red[j * CA + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            const int c = m0 + 4 * tid;
             if (c + 0 < p.Cout) atomicAdd(p.colsum + c + 0, t.x);
             if (c + 1 < p.Cout) atomicAdd(p.colsum + c + 1, t.y);
             if (c + 2 < p.Cout) atomicAdd(p.colsum + c + 2, t.z);
