@@ -101,8 +101,12 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // are recomputed only when the tap changes (every Cin/BK steps); in between a step is one add per row.
     const bool fast = (d.Cin % BK) == 0;
     int a_pix[AR];                                         // fast path: in-image offset of the row's pixel for the tap, <0 = zero
+    unsigned a_ok = 0;                                     // rows of the step in flight that hold real data (bit i)
     int f_r = 0, f_s = 0, f_c = 0;                         // tap (r,s) and channel offset of the NEXT step to load
     auto load_step = [&](int ks) {
+        // weights first: their addresses need no arithmetic, and every load of the step is then in flight together
+#pragma unroll
+        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const float4 *>(b_base[i] + ks * BK);   // row clamped above
         if (fast) {
             if (f_c == 0) {                                // new tap (wave-uniform)
                 const bool tap_ok = f_r < d.kh;
@@ -116,12 +120,11 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                 }
             }
             const int c = f_c + 4 * q;
+            a_ok = 0;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                float4 v = a_pix[i] >= 0 ? *reinterpret_cast<const float4 *>(a_base[i] + (a_pix[i] + c))
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                ra[i] = v;
+            for (int i = 0; i < AR; ++i) {                  // unconditional, from a clamped offset; zeroed in store_step
+                a_ok |= a_pix[i] >= 0 ? (1u << i) : 0u;
+                ra[i] = *reinterpret_cast<const float4 *>(a_base[i] + ((a_pix[i] >= 0 ? a_pix[i] : 0) + c));
             }
             f_c += BK;
             if (f_c >= d.Cin) { f_c = 0; if (++f_s == d.kw) { f_s = 0; ++f_r; } }
@@ -132,28 +135,32 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             const int r = tap / d.kw, s = tap - r * d.kw;
             const bool tap_ok = r < d.kh;
             const int hoff = r * d.b, woff = s * d.b;
+            a_ok = 0;
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
                 const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
                 const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
                 // offsets inside one image fit 32 bits (x_batch_stride < 2^31 floats is checked by the launcher)
-                float4 v = ok ? *reinterpret_cast<const float4 *>(a_base[i] + ((ih * d.Wi + iw) * d.Cin + c0))
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                ra[i] = v;
+                a_ok |= ok ? (1u << i) : 0u;
+                ra[i] = *reinterpret_cast<const float4 *>(a_base[i] + (ok ? (ih * d.Wi + iw) * d.Cin + c0 : 0));
             }
         }
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4 *>(b_base[i] + ks * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
+    // Nothing in load_step may depend on a loaded value: a select, a clamp or a branch right behind a global load makes
+    // the compiler wait for it on the spot -- one memory round trip per load instead of one per K-step.  Padding /
+    // out-of-range rows are zeroed and the input ReLU applied here, on the way into LDS, after the MFMAs.
     auto store_step = [&](int buf) {
         float *A = lds[buf], *B = lds[buf] + BM * LDK;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<float4 *>(A + (srow + RPS * i) * LDK + 4 * q) = ra[i];
+        for (int i = 0; i < AR; ++i) {
+            float4 v = (a_ok & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(A + (srow + RPS * i) * LDK + 4 * q) = v;
+        }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<float4 *>(B + (srow + RPS * i) * LDK + 4 * q) = rb[i];
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<float4 *>(B + (srow + RPS * i) * LDK + 4 * q) = b_ok[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     f32x16 acc[2][2];
