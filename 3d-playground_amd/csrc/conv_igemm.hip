@@ -95,15 +95,24 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         b_base[i] = w + (int64_t)(b_ok[i] ? n : 0) * Kpad + 4 * q;
     }
 
-    float4 ra[AR], rb[BR];
+    // two register sets: the loads of K-step ks+2 are issued while step ks is multiplied and step ks+1 waits in the
+    // other set -- two K-steps (~4 us) of prefetch distance, enough for an HBM miss on inputs that fit neither L2 nor
+    // the Infinity Cache (the 135x240 and larger levels)
+    struct Stage { float4 ra[AR], rb[BR]; unsigned a_ok; };
+    Stage sA, sB;
     // Fast path (Cin a multiple of the K-step, i.e. every layer but the 4-channel stem and channel-padded head
     // gradients): a K-step lies inside one filter tap, so the per-row input coordinate, bounds test and pixel offset
     // are recomputed only when the tap changes (every Cin/BK steps); in between a step is one add per row.
     const bool fast = (d.Cin % BK) == 0;
     int a_pix[AR];                                         // fast path: in-image offset of the row's pixel for the tap, <0 = zero
-    unsigned a_ok = 0;                                     // rows of the step in flight that hold real data (bit i)
     int f_r = 0, f_s = 0, f_c = 0;                         // tap (r,s) and channel offset of the NEXT step to load
-    auto load_step = [&](int ks) {
+    auto load_step = [&](int ks_raw, Stage &S) {
+        // always executed (a step index past the end is clamped and its data never read): loads inside conditional
+        // blocks make the compiler's s_waitcnt accounting fall back to vmcnt(0)
+        const int ks = ks_raw < nks ? ks_raw : nks - 1;
+        float4 (&ra)[AR] = S.ra;
+        float4 (&rb)[BR] = S.rb;
+        unsigned &a_ok = S.a_ok;
         // weights first: their addresses need no arithmetic, and every load of the step is then in flight together
 #pragma unroll
         for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const float4 *>(b_base[i] + ks * BK);   // row clamped above
@@ -150,8 +159,11 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // Nothing in load_step may depend on a loaded value: a select, a clamp or a branch right behind a global load makes
     // the compiler wait for it on the spot -- one memory round trip per load instead of one per K-step.  Padding /
     // out-of-range rows are zeroed and the input ReLU applied here, on the way into LDS, after the MFMAs.
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf, Stage &S) {
         float *A = lds[buf], *B = lds[buf] + BM * LDK;
+        float4 (&ra)[AR] = S.ra;
+        float4 (&rb)[BR] = S.rb;
+        const unsigned a_ok = S.a_ok;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             float4 v = (a_ok & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -171,14 +183,13 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_step(0);
-    store_step(0);
+    load_step(0, sA);
+    store_step(0, sA);
     __syncthreads();
+    load_step(1, sA);
 
     const int frag = (lane & 31) * LDK + (lane >> 5) * 4;   // [row = lane&31][k = 4*(lane>>5)]
-    for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) load_step(ks + 1);
+    auto multiply = [&](int buf) {
         const float *A = lds[buf] + (wm * 64) * LDK + frag;
         const float *B = lds[buf] + BM * LDK + (wn * 64) * LDK + frag;
 #pragma unroll
@@ -197,8 +208,27 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                     for (int tn = 0; tn < 2; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
         }
-        if (ks + 1 < nks) store_step(buf ^ 1);
-        __syncthreads();
+    };
+    if constexpr (BK >= 32) {
+        for (int ks = 0; ks < nks; ks += 2) {
+            load_step(ks + 2, sB);
+            multiply(0);
+            store_step(1, sA);                              // step ks+1 (past the end: clamped data into the idle buffer)
+            __syncthreads();
+            if (ks + 1 >= nks) break;
+            load_step(ks + 3, sA);
+            multiply(1);
+            store_step(0, sB);
+            __syncthreads();
+        }
+    } else {
+        // K-step 16 (small K, three workgroups per CU): one register set -- a second one would not fit 168 VGPRs
+        for (int ks = 0; ks < nks; ++ks) {
+            multiply(ks & 1);
+            store_step((ks & 1) ^ 1, sA);
+            __syncthreads();
+            load_step(ks + 2, sA);
+        }
     }
 
     // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add (+ add2); act; [mask after]
