@@ -44,6 +44,7 @@ SIGNATURES = {
     "rn_parse_detections": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_f32, c_f32,
                                     c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_md_iou": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rn_frame_ingest": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32] + [c_f32] * 6 + [c_i32, c_vp, c_vp]),
 }
 
 class ConvDesc(ctypes.Structure):

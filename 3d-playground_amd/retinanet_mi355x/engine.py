@@ -215,14 +215,18 @@ class Engine:
             L.prepare(P, self.cache)
 
     # ------------------------------------------------------------------------------------------- forward
-    def forward(self, P, img, save):
-        """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None)."""
-        _hip.need_gpu(img)
+    def forward(self, P, img, save, x4=None):
+        """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None).  x4: the input already
+        in the stem's layout ([B,H,W,4] fp32, e.g. from ops.frame_ingest(nhwc4=True)); img is then ignored."""
         Ls = self.layers
         self._prepare(P)
-        B, _, H, W = img.shape
+        if x4 is None:
+            _hip.need_gpu(img)
+            x4 = cv.nchw_to_nhwc4(img)
+        else:
+            _hip.need_gpu(x4)
+        B, H, W, _ = x4.shape
         S = {} if save else None
-        x4 = cv.nchw_to_nhwc4(img)
         stem = Ls["conv1"].fwd(x4, act=cv.ACT_RELU)
         if save:
             x, pool_arg = cv.maxpool_fwd(stem, want_argmax=True)
@@ -262,8 +266,8 @@ class Engine:
         # ---- heads: towers share weights across levels; outputs land in their slice of [B, A, n]
         counts = [f.shape[1] * f.shape[2] * arch.NUM_ANCHORS for f in pyramid]
         A = sum(counts)
-        reg = torch.empty((B, A, self.n_reg), dtype=torch.float32, device=img.device)
-        cls = torch.empty((B, A, self.num_classes), dtype=torch.float32, device=img.device)
+        reg = torch.empty((B, A, self.n_reg), dtype=torch.float32, device=x4.device)
+        cls = torch.empty((B, A, self.num_classes), dtype=torch.float32, device=x4.device)
         if save:
             S["towers"] = {"regressionModel": [], "classificationModel": []}
             S["counts"] = counts

@@ -189,6 +189,8 @@ class ResNet(nn.Module):
         self.inplanes = 64
         super().__init__()
         self.directional = directional
+        self.ingest_swap_rb = False                 # uint8 frame input: BGR->RGB swap of perform_3D_detection...py:52
+        self.ingest_mean, self.ingest_std = ops.IMAGENET_MEAN, ops.IMAGENET_STD
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -268,8 +270,17 @@ class ResNet(nn.Module):
         if MULTI_FRAME and not self.directional:
             raise TypeError("forward() got an unexpected keyword argument 'MULTI_FRAME'")   # R/model.py:243
         with torch.no_grad():
-            reg, cls, _ = eng.forward(self._tensor_dict(), img_batch, save=False)
-            anc = eng.anchors(img_batch.shape[2], img_batch.shape[3], img_batch.device)
+            if img_batch.dtype == torch.uint8:
+                # Extension (the reference's model cannot take it): raw uint8 [B,H,W,3] frames.  to_tensor + normalize
+                # of the loaders (util_track/mp_loader.py:239-243) run fused on device, straight into the stem's layout.
+                x4 = ops.frame_ingest(img_batch, swap_rb=self.ingest_swap_rb, mean=self.ingest_mean, std=self.ingest_std,
+                                      nhwc4=True)
+                H_in, W_in = x4.shape[1], x4.shape[2]
+                reg, cls, _ = eng.forward(self._tensor_dict(), None, save=False, x4=x4)
+            else:
+                H_in, W_in = img_batch.shape[2], img_batch.shape[3]
+                reg, cls, _ = eng.forward(self._tensor_dict(), img_batch, save=False)
+            anc = eng.anchors(H_in, W_in, reg.device)
             if self.directional:
                 boxes = ops.decode_dir(anc, reg)
                 if MULTI_FRAME:                                            # D/model.py:311-344
@@ -277,7 +288,7 @@ class ResNet(nn.Module):
                 if LOCALIZE:                                               # D/model.py:362-363
                     return boxes, cls
                 return ops.postprocess_single(cls, boxes)                  # D/model.py:365-397
-            boxes = ops.decode_2d(anc, reg, clip_hw=(img_batch.shape[2], img_batch.shape[3]))   # R/model.py:270-271
+            boxes = ops.decode_2d(anc, reg, clip_hw=(H_in, W_in))          # R/model.py:270-271
             if LOCALIZE:
                 return boxes, cls
             return ops.postprocess_2d(cls, boxes)                          # R/model.py:285-311

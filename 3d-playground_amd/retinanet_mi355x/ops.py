@@ -423,3 +423,27 @@ def md_iou(a, b):
         with torch.cuda.device(a.device):
             _hip.check(lib.rn_md_iou(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), _hip.stream()), "rn_md_iou")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ frame ingest
+IMAGENET_MEAN = (0.485, 0.456, 0.406)     # util_track/mp_loader.py:241
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def frame_ingest(frames_u8, swap_rb=False, mean=IMAGENET_MEAN, std=IMAGENET_STD, nhwc4=False):
+    """F.to_tensor + F.normalize of the reference's loaders on device (include/retinanet_mi355x.h, rn_frame_ingest).
+    frames_u8: uint8 [B,H,W,3] (or [H,W,3]) -> float32 [B,3,H,W], or [B,H,W,4] with nhwc4=True."""
+    lib = _hip.load()
+    _hip.need_gpu(frames_u8)
+    if frames_u8.dim() == 3:
+        frames_u8 = frames_u8.unsqueeze(0)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3:
+        raise RuntimeError("frame_ingest takes uint8 [B,H,W,3] frames, got %s %s" % (frames_u8.dtype, tuple(frames_u8.shape)))
+    f = frames_u8.contiguous()
+    B, H, W, _ = f.shape
+    out = torch.empty((B, H, W, 4) if nhwc4 else (B, 3, H, W), dtype=torch.float32, device=f.device)
+    with torch.cuda.device(f.device):
+        _hip.check(lib.rn_frame_ingest(f.data_ptr(), B, H, W, int(bool(swap_rb)), *[float(m) for m in mean],
+                                       *[float(s) for s in std], int(bool(nhwc4)), out.data_ptr(), _hip.stream()),
+                   "rn_frame_ingest")
+    return out

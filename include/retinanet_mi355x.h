@@ -150,6 +150,16 @@ int rn_parse_detections(const float *scores, const int64_t *labels, const float 
                         int32_t *out_count, void *stream);
 int rn_md_iou(const double *a, const double *b, double *out, int64_t n, void *stream);
 
+/* ---------------------------------------------------------------- frame ingest ----------------------------
+ * Replaces F.to_tensor + F.normalize of the reference's loaders (util_track/mp_loader.py:239-243,
+ * perform_3D_detection_on_video_sequences.py:51-58) on device: frames uint8 [B,H,W,3] (as the decoder / cv2.resize
+ * leaves them) -> fp32 (u8/255 - mean[c]) / std[c], three separate fp32 operations as torchvision performs them
+ * (bit-identical to the CPU).  swap_rb != 0 applies the second caller's BGR->RGB swap.
+ * layout 0: out = NCHW [B,3,H,W], the tensor the reference hands to the model;
+ * layout 1: out = NHWC4 [B,H,W,4] (4th channel 0), the stem convolution's input layout. */
+int rn_frame_ingest(const uint8_t *frames, int B, int H, int W, int swap_rb, float mean0, float mean1, float mean2,
+                    float std0, float std1, float std2, int layout, float *out, void *stream);
+
 /* ---------------------------------------------------------------- convolution engine ----------------------
  * fp32 implicit-GEMM convolutions on the matrix cores (v_mfma_f32_32x32x2_f32).  Replaces nn.Conv2d +
  * BatchNorm2d(eval) + ReLU + residual add (D/utils.py:25-43, 60-80), PyramidFeatures (D/model.py:84-117) and
