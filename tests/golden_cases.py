@@ -135,3 +135,32 @@ def tracker_post_inputs(n_obj=120, seed=21):
     labels = (synth.uniform((len(scores),), seed + 6) * 8).astype(np.int64) % 8
     return (torch.from_numpy(scores), torch.from_numpy(labels), torch.from_numpy(boxes), torch.from_numpy(cams),
             names, (Ps, Hs), (Ps2, Hs2))
+
+
+def crop_refine_inputs(n_obj=24, n_det=64, seed=41, cs=112):
+    """Inputs of the tracker's crop-refinement path (MC3D_crop_tracker.py:1172-1226): priors pre_loc [n,6] in state
+    space with their cameras, the image corners of the priors (state_to_im), and a stand-in for the LOCALIZE
+    detector's output inside each crop: reg_boxes [n,d,20] (crop pixels: the prior's own box plus jitter) and class
+    scores cls [n,d,8]."""
+    from oracle import homography as ohg
+    names, _, _, (Ps, Hs), (Ps2, Hs2) = homography_inputs()
+    n_cam = len(names)
+    pre_loc = synth.vehicle_states(n_obj, seed=seed)
+    cam = torch.from_numpy((synth.uniform((n_obj,), seed + 1) * n_cam).astype(np.int64) % n_cam)
+    im_objs = torch.from_numpy(ohg.wrapper_space_to_im(ohg.state_to_space(pre_loc.numpy()), Ps[cam.numpy()], Ps2[cam.numpy()]))
+    return pre_loc, cam, im_objs, names, (Ps, Hs), (Ps2, Hs2)
+
+
+def crop_detections(im_objs, crop_boxes, n_det=64, seed=43, cs=112):
+    """Synthetic LOCALIZE output for each crop: the object's own corners mapped into crop pixels, jittered per detection."""
+    n = im_objs.shape[0]
+    scale = (crop_boxes[:, 2] - crop_boxes[:, 0]).double()
+    local = (im_objs.double() - crop_boxes[:, None, 0:2].double()) / scale[:, None, None] * cs        # [n,8,2]
+    jit = torch.from_numpy(synth.uniform((n, n_det, 8, 2), seed).astype(np.float64) - 0.5) * 10.0
+    det = (local[:, None] + jit).float()                                                              # [n,d,8,2]
+    xs, ys = det[..., 0], det[..., 1]
+    box2d = torch.stack((xs.min(2).values, ys.min(2).values, xs.max(2).values, ys.max(2).values), dim=2)
+    reg_boxes = torch.cat((det.reshape(n, n_det, 16), box2d), dim=2).contiguous()                       # [n,d,20]
+    cls = torch.from_numpy(synth.uniform((n, n_det, 8), seed + 1).astype(np.float32))
+    cls = cls * cls                                                                                    # skewed scores, few ties
+    return reg_boxes, cls

@@ -243,3 +243,42 @@ def test_tracker_post_golden(golden):
     assert z["empty_is_lists"].all()
     assert otp.parse_detections(scores[:0], labels[:0], boxes[:0], cams[:0], H, H2, P, P2) == ([], [], [], [])
     assert otp.parse_detections(scores * 0.01, labels, boxes, cams, H, H2, P, P2) == ([], [], [], [])
+
+
+# ------------------------------------------------------------------ tracker crop refinement
+def test_crop_refine_golden(golden):
+    """oracle/crop_refine.py against MC_Crop_Tracker.get_crop_boxes / local_to_global / select_best_box and the
+    reference's own candidate pipeline (tools/make_golden.py gen_crop_refine)."""
+    from oracle import crop_refine as ocr
+    z = golden("crop_refine")
+    pre_loc, cam, im_objs, names, (P, H), (P2, H2) = gc.crop_refine_inputs()
+    crop_boxes = ocr.get_crop_boxes(im_objs)
+    assert crop_boxes.dtype == torch.float64
+    assert np.array_equal(crop_boxes.numpy(), z["crop_boxes"])
+    reg_boxes, cls = gc.crop_detections(im_objs, crop_boxes.float())
+    glob = ocr.local_to_global(reg_boxes, crop_boxes.float())
+    assert np.array_equal(glob.numpy(), z["local_to_global"])
+    best, bcls, bconf = ocr.refine_from_detections(reg_boxes, cls, crop_boxes.float(), cam, pre_loc, H, H2, P, P2)
+    assert np.array_equal(bcls.numpy(), z["best_classes"])
+    assert np.array_equal(bconf.numpy(), z["best_confs"])
+    assert np.allclose(best.numpy(), z["best_state"], rtol=1e-5, atol=1e-4)
+    # select_best_box alone on the reference's candidates
+    b2, c2, f2 = ocr.select_best_box(pre_loc, torch.from_numpy(z["cand_state"]), torch.from_numpy(z["cand_confs"]),
+                                     torch.from_numpy(z["cand_classes"]), pre_loc.shape[0])
+    assert np.array_equal(b2.numpy(), z["best_state"]) and np.array_equal(c2.numpy(), z["best_classes"])
+    assert np.array_equal(f2.numpy(), z["best_confs"])
+
+
+def test_roi_align_restatement_properties():
+    """torchvision.ops.roi_align is absent here (parity unpinned): check the restatement on cases with known answers --
+    a linear ramp is reproduced at the bin centres, a constant image stays constant, samples outside the image by
+    more than one pixel contribute zero."""
+    from oracle import crop_refine as ocr
+    H, W = 40, 60
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    img = np.stack([xx, yy, np.full_like(xx, 7.0)])[None]
+    out = ocr.roi_align(img, np.array([[0, 10.0, 5.0, 34.0, 29.0]], dtype=np.float32), (8, 8))
+    assert np.allclose(out[0, 0, 0], 11.5 + 3.0 * np.arange(8)) and np.allclose(out[0, 1, :, 0], 6.5 + 3.0 * np.arange(8))
+    assert np.allclose(out[0, 2], 7.0)
+    far = ocr.roi_align(img, np.array([[0, -50.0, -50.0, -10.0, -10.0]], dtype=np.float32), (4, 4))
+    assert np.all(far == 0)

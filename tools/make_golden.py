@@ -319,12 +319,8 @@ def gen_csv_kat():
                         columns=np.array(["cam_code"] + keep))
 
 
-def gen_tracker_post():
-    """MC_Crop_Tracker.parse_detections / im_nms / space_nms / md_iou (MC3D_crop_tracker.py:319-383, 592-636,
-    1030-1049) run UNBOUND on a stand-in ``self`` that carries only the attributes those methods read (sigma_d,
-    phi_nms_*, cameras, est_ts, hg = the reference's own Homography_Wrapper filled with the fixture's matrices).
-    The module imports behind two more stub attributes (torchvision.transforms.functional, torchvision.ops.roi_align);
-    constructing the tracker itself needs videos and checkpoints the reference does not ship."""
+def tracker_import_shims():
+    """Two more stub attributes the tracker module needs at import time."""
     tv = sys.modules["torchvision"]
     tvt = types.ModuleType("torchvision.transforms")
     tvf = types.ModuleType("torchvision.transforms.functional")
@@ -336,6 +332,14 @@ def gen_tracker_post():
     def _no_roi_align(*a, **k):
         raise NotImplementedError("roi_align is not on this path")
     sys.modules["torchvision.ops"].roi_align = _no_roi_align
+
+
+def gen_tracker_post():
+    """MC_Crop_Tracker.parse_detections / im_nms / space_nms / md_iou (MC3D_crop_tracker.py:319-383, 592-636,
+    1030-1049) run UNBOUND on a stand-in ``self`` that carries only the attributes those methods read (sigma_d,
+    phi_nms_*, cameras, est_ts, hg = the reference's own Homography_Wrapper filled with the fixture's matrices).
+    The module imports behind two more stub attributes (torchvision.transforms.functional, torchvision.ops.roi_align);
+    constructing the tracker itself needs videos and checkpoints the reference does not ship."""
     sys.path.insert(0, REF)
     try:
         trk = importlib.import_module("MC3D_crop_tracker")
@@ -376,6 +380,52 @@ def gen_tracker_post():
     np.savez_compressed(os.path.join(OUT, "tracker_post.npz"), **out)
 
 
+def gen_crop_refine():
+    """MC_Crop_Tracker.get_crop_boxes / local_to_global / select_best_box (MC3D_crop_tracker.py:920-1028) run unbound
+    on a stand-in ``self`` (b, cs, W, device, hg, md_iou); same import shims as gen_tracker_post."""
+    sys.path.insert(0, REF)
+    try:
+        trk = importlib.import_module("MC3D_crop_tracker")
+        hgmod = importlib.import_module("homography")
+    finally:
+        sys.path.remove(REF)
+    T = trk.MC_Crop_Tracker
+    from oracle import crop_refine as ocr          # only for the roi-free middle of the pipeline (top-k, homographies)
+    pre_loc, cam, im_objs, names, (Ps, Hs), (Ps2, Hs2) = gc.crop_refine_inputs()
+
+    def make_hg(P, H):
+        hg = hgmod.Homography()
+        hg.correspondence = {n: {"P": P[i], "H": H[i], "H_inv": np.linalg.inv(H[i])} for i, n in enumerate(names)}
+        hg.default_correspondence = names[0]
+        return hg
+    me = types.SimpleNamespace(b=1.25, cs=112, W=0.5, device=torch.device("cpu"),
+                               hg=hgmod.Homography_Wrapper(hg1=make_hg(Ps, Hs), hg2=make_hg(Ps2, Hs2)))
+    me.md_iou = types.MethodType(T.md_iou, me)
+    out = {}
+    crop_boxes = T.get_crop_boxes(me, im_objs)
+    out["crop_boxes"] = t2n(crop_boxes)
+    reg_boxes, cls = gc.crop_detections(im_objs, crop_boxes.float())
+    glob = T.local_to_global(me, reg_boxes.clone(), crop_boxes.float())
+    out["local_to_global"] = t2n(glob)
+    # the reference's own sequence between the detector and select_best_box (MC3D_crop_tracker.py:1188-1219), run with
+    # the reference's Homography_Wrapper
+    confs, classes = torch.max(cls, dim=2)
+    top = torch.topk(confs, 50, dim=1)[1]
+    rows = torch.arange(glob.shape[0]).unsqueeze(1).repeat(1, top.shape[1])
+    g, confs, classes = glob[rows, top, :, :], confs[rows, top], classes[rows, top]
+    n_objs = g.shape[0]
+    cam_rep = [names[int(c)] for c in cam for _ in range(g.shape[1])]
+    pts = g.reshape(-1, 8, 2)
+    heights = me.hg.guess_heights(classes.reshape(-1))
+    st = me.hg.im_to_state(pts, heights=heights, name=cam_rep)
+    repro = me.hg.state_to_im(st, name=cam_rep)
+    st = me.hg.im_to_state(pts, heights=me.hg.height_from_template(repro, heights, pts), name=cam_rep)
+    out["cand_state"], out["cand_confs"], out["cand_classes"] = t2n(st), t2n(confs), t2n(classes)
+    best, bcls, bconf = T.select_best_box(me, pre_loc.clone(), st.clone(), confs, classes, n_objs)
+    out["best_state"], out["best_classes"], out["best_confs"] = t2n(best), t2n(bcls), t2n(bconf)
+    np.savez_compressed(os.path.join(OUT, "crop_refine.npz"), **out)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
@@ -386,7 +436,7 @@ def main():
     m_dir, l_dir, u_dir, a_dir = import_variant("dir")
     dir_mods = (m_dir, l_dir, u_dir, a_dir)
     m_2d, l_2d, u_2d, a_2d = import_variant("2d")
-    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv", "tracker_post"}
+    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv", "tracker_post", "crop_refine"}
     if "anchors" in which:
         gen_anchors(a_dir)
     if "losses" in which:
@@ -399,8 +449,12 @@ def main():
         gen_homography()
     if "csv" in which:
         gen_csv_kat()
+    if "tracker_post" in which or "crop_refine" in which:
+        tracker_import_shims()
     if "tracker_post" in which:
         gen_tracker_post()
+    if "crop_refine" in which:
+        gen_crop_refine()
     for fn in sorted(os.listdir(OUT)):
         print("%-20s %8.1f KiB" % (fn, os.path.getsize(os.path.join(OUT, fn)) / 1024))
     del dir_mods
