@@ -75,3 +75,49 @@ __device__ __forceinline__ void hg_project_from_im(const double2 pt[8], double h
     project(H + (int64_t)m * 9);
     if (H2 != nullptr && y[0] > 60.0) project(H2 + (int64_t)m * 9);              // homography.py:845-846
 }
+
+// torch.mean over 4 rows of one coordinate: rows are accumulated in order, then divided.
+template <typename T>
+__device__ __forceinline__ T hg_mean4(T a, T b, T c, T d) { return (((a + b) + c) + d) / (T)4; }
+__device__ __forceinline__ float hg_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double hg_sqrt(double v) { return sqrt(v); }
+
+// Image corners -> state through the camera's homographies, with the tracker's optional height refinement
+// (MC3D_crop_tracker.py:366-370 and 1216-1219): state -> image through P (the reprojection), height_from_template
+// (homography.py:519-551) of the reprojection (float64) against the detection itself, image -> state again.
+// TB is the dtype in which height_from_template sees the detection: float32 in parse_detections (the detector's
+// boxes), float64 in the crop path (local_to_global promotes them).  h0 = guess_heights value (float32).
+template <typename TB>
+__device__ __forceinline__ void hg_im_to_state_refined(const double2 pt[8], const TB bx[8], const TB by[8], float h0,
+                                                       bool refine, const double *__restrict__ H1,
+                                                       const double *__restrict__ H2, const double *__restrict__ P1,
+                                                       const double *__restrict__ P2, int cam, float st[6]) {
+    double x[8], y[8], z[8];
+    hg_project_from_im(pt, (double)h0, H1, H2, cam, x, y, z);
+    corners_to_state<double>(x, y, z, st);
+    if (!refine) return;
+    float fx[8], fy[8], fz[8];
+    state_corners(st, fx, fy, fz);
+    double2 rp[8];
+    hg_project_to_im(fx, fy, fz, P1, P2, cam, rp);                           // repro_boxes = hg.state_to_im(boxes)
+    const double ttx = hg_mean4(rp[4].x, rp[5].x, rp[6].x, rp[7].x), tty = hg_mean4(rp[4].y, rp[5].y, rp[6].y, rp[7].y);
+    const double tbx = hg_mean4(rp[0].x, rp[1].x, rp[2].x, rp[3].x), tby = hg_mean4(rp[0].y, rp[1].y, rp[2].y, rp[3].y);
+    const double dtx = ttx - tbx, dty = tty - tby;
+    const double t_h = sqrt(dtx * dtx) + sqrt(dty * dty);
+    const double ratio = t_h / (double)h0;
+    const TB btx = hg_mean4(bx[4], bx[5], bx[6], bx[7]), bty = hg_mean4(by[4], by[5], by[6], by[7]);
+    const TB bbx = hg_mean4(bx[0], bx[1], bx[2], bx[3]), bby = hg_mean4(by[0], by[1], by[2], by[3]);
+    const TB dbx = btx - bbx, dby = bty - bby;
+    const TB b_h = hg_sqrt(dbx * dbx) + hg_sqrt(dby * dby);
+    const double h_ref = (double)b_h / ratio;
+    hg_project_from_im(pt, h_ref, H1, H2, cam, x, y, z);
+    corners_to_state<double>(x, y, z, st);
+}
+
+// road-plane footprint of a state: min / max of the four bottom corners, fp32 (MC3D_crop_tracker.py:626-633, 992-996)
+__device__ __forceinline__ float4 hg_footprint(const float st[6]) {
+    float sx[8], sy[8], sz[8];
+    state_corners(st, sx, sy, sz);
+    return make_float4(fminf(fminf(sx[0], sx[1]), fminf(sx[2], sx[3])), fminf(fminf(sy[0], sy[1]), fminf(sy[2], sy[3])),
+                       fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3])), fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3])));
+}

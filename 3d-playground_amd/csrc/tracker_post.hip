@@ -116,10 +116,6 @@ __global__ __launch_bounds__(1024) void tp_filter_kernel(const float *__restrict
     }
 }
 
-// torch.mean over 4 rows, one coordinate: rows are accumulated in order, then divided.
-template <typename T>
-__device__ __forceinline__ T mean4(T a, T b, T c, T d) { return (((a + b) + c) + d) / (T)4; }
-
 __global__ __launch_bounds__(256) void tp_state_kernel(const float *__restrict__ boxes20, const int64_t *__restrict__ camera_idxs,
                                                        const float *__restrict__ heights, const double *__restrict__ H1,
                                                        const double *__restrict__ H2, const double *__restrict__ P1,
@@ -138,40 +134,15 @@ __global__ __launch_bounds__(256) void tp_state_kernel(const float *__restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) { px[q] = b[2 * q]; py[q] = b[2 * q + 1]; pt[q] = make_double2((double)px[q], (double)py[q]); }
     const float h0 = heights ? heights[i] : 5.0f;                                // guess_heights: "other" (homography.py:514)
-    double x[8], y[8], z[8];
     float st[6];
-    hg_project_from_im(pt, (double)h0, H1, H2, cam, x, y, z);
-    corners_to_state<double>(x, y, z, st);
-    if (refine) {                                                                // MC3D_crop_tracker.py:366-370
-        float fx[8], fy[8], fz[8];
-        state_corners(st, fx, fy, fz);
-        double2 rp[8];
-        hg_project_to_im(fx, fy, fz, P1, P2, cam, rp);                           // repro_boxes = hg.state_to_im(boxes)
-        // height_from_template (homography.py:519-551): template = reprojection (fp64), boxes = detections (fp32)
-        const double ttx = mean4(rp[4].x, rp[5].x, rp[6].x, rp[7].x), tty = mean4(rp[4].y, rp[5].y, rp[6].y, rp[7].y);
-        const double tbx = mean4(rp[0].x, rp[1].x, rp[2].x, rp[3].x), tby = mean4(rp[0].y, rp[1].y, rp[2].y, rp[3].y);
-        const double dtx = ttx - tbx, dty = tty - tby;
-        const double t_h = sqrt(dtx * dtx) + sqrt(dty * dty);
-        const double ratio = t_h / (double)h0;
-        const float btx = mean4(px[4], px[5], px[6], px[7]), bty = mean4(py[4], py[5], py[6], py[7]);
-        const float bbx = mean4(px[0], px[1], px[2], px[3]), bby = mean4(py[0], py[1], py[2], py[3]);
-        const float dbx = btx - bbx, dby = bty - bby;
-        const float b_h = sqrtf(dbx * dbx) + sqrtf(dby * dby);
-        const double h_ref = (double)b_h / ratio;
-        hg_project_from_im(pt, h_ref, H1, H2, cam, x, y, z);
-        corners_to_state<double>(x, y, z, st);
-    }
+    hg_im_to_state_refined<float>(pt, px, py, h0, refine != 0, H1, H2, P1, P2, cam, st);   // MC3D_crop_tracker.py:364-370
     float *o = w.st2 + (int64_t)k * 6;
 #pragma unroll
     for (int q = 0; q < 6; ++q) o[q] = st[q];
     w.sc2[k] = w.sc1[j];
     w.src2[k] = i;
     w.iota[k] = k;                                                               // identity list for the second NMS
-    // footprint for space_nms: min / max of the four bottom corners (MC3D_crop_tracker.py:626-633)
-    float sx[8], sy[8], sz[8];
-    state_corners(st, sx, sy, sz);
-    w.foot2[k] = make_float4(fminf(fminf(sx[0], sx[1]), fminf(sx[2], sx[3])), fminf(fminf(sy[0], sy[1]), fminf(sy[2], sy[3])),
-                             fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3])), fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3])));
+    w.foot2[k] = hg_footprint(st);                                                // for space_nms (MC3D_crop_tracker.py:626-633)
 }
 
 __global__ __launch_bounds__(256) void tp_gather_kernel(const int64_t *__restrict__ labels, const int64_t *__restrict__ camera_idxs,

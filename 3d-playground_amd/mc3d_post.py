@@ -1,5 +1,7 @@
 """Drop-in for the detection-parsing methods of the reference's multi-camera tracker (``MC3D_crop_tracker.py``):
-``parse_detections`` (:319-383), ``im_nms`` (:592-616), ``space_nms`` (:618-636) and ``md_iou`` (:1030-1049).
+``parse_detections`` (:319-383), ``im_nms`` (:592-616), ``space_nms`` (:618-636) and ``md_iou`` (:1030-1049), and for
+its crop-refinement path: ``get_crop_boxes`` (:920-944), ``local_to_global`` (:946-969), ``select_best_box`` (:972-1028)
+plus ``crop_refine``, the whole measurement block of ``track`` (:1172-1226) fused on the device.
 
 The functions take ``self`` exactly like the methods they replace and read the same attributes (``sigma_d``,
 ``phi_nms_im``, ``phi_nms_space``, ``cameras``, ``hg`` = a ``Homography_Wrapper``, ``est_ts`` /
@@ -115,9 +117,70 @@ def parse_detections(self, scores, labels, boxes, camera_idxs, n_best=200, perfo
     return st, lb, sc, cm
 
 
+# ------------------------------------------------------------------------------------------- crop refinement
+def get_crop_boxes(self, objects):
+    """MC3D_crop_tracker.py:920-944: [n,8,2] image corners -> [n,4] square crops (x1,y1,x2,y2), on ``self.device``."""
+    dev = _device(self, objects)
+    return _ops.crop_boxes(objects.to(dev), b=self.b).to(objects.dtype)
+
+
+def local_to_global(self, preds, crop_boxes):
+    """MC3D_crop_tracker.py:946-969: [n,d,20] crop pixels -> [n,d,8,2] frame pixels (dtype promotion as in torch)."""
+    n, d = preds.shape[0], preds.shape[1]
+    p = preds.reshape(n, d, 10, 2)[:, :, :8, :]
+    scales = torch.max(torch.stack([crop_boxes[:, 2] - crop_boxes[:, 0], crop_boxes[:, 3] - crop_boxes[:, 1]]), dim=0)[0]
+    p = (p * scales[:, None, None, None] / self.cs).clone()
+    p[:, :, :, 0] += crop_boxes[:, 0][:, None, None]
+    p[:, :, :, 1] += crop_boxes[:, 1][:, None, None]
+    return p
+
+
+def select_best_box(self, a_priori, preds, confs, classes, n_objs):
+    """MC3D_crop_tracker.py:972-1028 from already transformed candidates: preds [n*d,6] state."""
+    dev = _device(self, preds, a_priori)
+
+    def foot(st):
+        sp = _ops.hg_state_to_space(st.to(dev))
+        return torch.stack((sp[:, 0:4, 0].min(1).values, sp[:, 0:4, 1].min(1).values,
+                            sp[:, 0:4, 0].max(1).values, sp[:, 0:4, 1].max(1).values), dim=1)
+    fp = foot(preds).reshape(n_objs, -1, 4)
+    d = fp.shape[1]
+    prior = foot(a_priori)[:, None, :].repeat(1, d, 1)
+    ious = _ops.md_iou(fp.double(), prior.double())
+    scores = (1 - self.W) * ious + self.W * confs.to(dev)
+    keep = torch.argmax(scores, dim=1)
+    idx = torch.arange(n_objs, device=dev)
+    out = (preds.to(dev).reshape(n_objs, -1, 6)[idx, keep, :], classes.to(dev)[idx, keep], confs.to(dev)[idx, keep])
+    return out if preds.is_cuda else tuple(t.cpu() for t in out)
+
+
+def crop_refine(self, frames, pre_loc, cam_idxs, detector=None):
+    """The measurement block of MC_Crop_Tracker.track (MC3D_crop_tracker.py:1172-1226) without leaving the device:
+    priors -> image -> crop boxes -> roi_align -> LOCALIZE detector -> best refined box per object.
+    frames [n_cam,3,H,W] float32 on the GPU, pre_loc [n,6], cam_idxs [n]; detector defaults to ``self.crop_detector``.
+    -> (detections [n,6], classes [n], confs [n], crop_boxes [n,4] float64) as device tensors."""
+    dev = frames.device
+    det = detector if detector is not None else self.crop_detector
+    H1, H2, P1, P2 = _camera_matrices(self, dev)
+    cam = cam_idxs.to(dev).long()
+    pre = pre_loc.to(dev).float()
+    im_objs = _ops.hg_to_im(pre, P1, P2, cam.int(), from_state=True)          # self.hg.state_to_im(pre_loc, name=cam_names)
+    boxes, rois = _ops.crop_boxes(im_objs, cam, b=self.b)
+    crops = _ops.roi_align(frames, rois, (self.cs, self.cs))
+    with torch.no_grad():
+        reg_boxes, classes = det(crops, LOCALIZE=True)
+    st, cl, cf = _ops.crop_select(reg_boxes, classes, boxes, cam, pre, H1, H2, P1, P2, cs=self.cs, cd_max=self.cd_max, W=self.W)
+    return st, cl, cf, boxes
+
+
 class DetectionParser:
-    """Mixin carrying the four methods; the host class provides the attributes listed in the module docstring."""
+    """Mixin carrying the methods; the host class provides the attributes listed in the module docstring (and, for the
+    crop path, ``b``, ``cs``, ``cd_max``, ``W``, ``crop_detector``)."""
     parse_detections = parse_detections
     im_nms = im_nms
     space_nms = space_nms
     md_iou = md_iou
+    get_crop_boxes = get_crop_boxes
+    local_to_global = local_to_global
+    select_best_box = select_best_box
+    crop_refine = crop_refine

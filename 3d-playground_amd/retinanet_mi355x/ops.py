@@ -447,3 +447,68 @@ def frame_ingest(frames_u8, swap_rb=False, mean=IMAGENET_MEAN, std=IMAGENET_STD,
                                        *[float(s) for s in std], int(bool(nhwc4)), out.data_ptr(), _hip.stream()),
                    "rn_frame_ingest")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ tracker: crop refinement
+CROP_MAX_A, CROP_MAX_K = 4096, 256
+
+
+def crop_boxes(im_objs, cam_idxs=None, b=1.25):
+    """MC_Crop_Tracker.get_crop_boxes (MC3D_crop_tracker.py:920-944): im_objs [n,8,2] -> crop boxes [n,4] float64; with
+    cam_idxs also the [n,5] float32 RoI rows (camera, box) that roi_align takes (:1183-1185)."""
+    lib = _hip.load()
+    _hip.need_gpu(im_objs, cam_idxs)
+    im = im_objs.double().contiguous()
+    n = im.shape[0]
+    boxes = torch.empty((n, 4), dtype=torch.float64, device=im.device)
+    rois = None if cam_idxs is None else torch.empty((n, 5), dtype=torch.float32, device=im.device)
+    cam = None if cam_idxs is None else cam_idxs.long().contiguous()
+    if n:
+        with torch.cuda.device(im.device):
+            _hip.check(lib.rn_crop_boxes(im.data_ptr(), _hip.ptr(cam), n, float(b), boxes.data_ptr(), _hip.ptr(rois),
+                                         _hip.stream()), "rn_crop_boxes")
+    return boxes if rois is None else (boxes, rois)
+
+
+def roi_align(frames, rois, output_size, nhwc4=False):
+    """torchvision.ops.roi_align(frames, rois, output_size) with its defaults, on device.  frames [N,C,H,W] float32,
+    rois [n,5] (batch index, x1, y1, x2, y2) -> [n,C,h,w], or [n,h,w,4] with nhwc4=True (C <= 4)."""
+    lib = _hip.load()
+    _hip.need_gpu(frames, rois)
+    f, r = _hip.f32c(frames), _hip.f32c(rois)
+    oh, ow = (output_size, output_size) if isinstance(output_size, int) else output_size
+    N, C, H, W = f.shape
+    n = r.shape[0]
+    out = torch.empty((n, oh, ow, 4) if nhwc4 else (n, C, oh, ow), dtype=torch.float32, device=f.device)
+    if n:
+        with torch.cuda.device(f.device):
+            _hip.check(lib.rn_roi_align(f.data_ptr(), N, C, H, W, r.data_ptr(), n, oh, ow, out.data_ptr(), int(bool(nhwc4)),
+                                        _hip.stream()), "rn_roi_align")
+    return out
+
+
+def crop_select(reg_boxes, cls, crop_bx, cam_idxs, pre_loc, H1, H2, P1, P2, cs=112, cd_max=50, W=0.5):
+    """Everything after the LOCALIZE detector in the tracker's crop path (MC3D_crop_tracker.py:1192-1226), one
+    workgroup per object: -> (state [n,6] f32, class [n] i64, confidence [n] f32)."""
+    lib = _hip.load()
+    _hip.need_gpu(reg_boxes, cls, crop_bx, cam_idxs, pre_loc, H1, H2, P1, P2)
+    n, A, C = cls.shape
+    if A > CROP_MAX_A or cd_max > CROP_MAX_K:
+        raise RuntimeError("crop_select sorts a crop's anchors in LDS: at most %d anchors and cd_max %d, got %d / %d"
+                           % (CROP_MAX_A, CROP_MAX_K, A, cd_max))
+    if reg_boxes.shape != (n, A, 20) or crop_bx.shape != (n, 4) or pre_loc.shape != (n, 6) or cam_idxs.shape[0] != n:
+        raise RuntimeError("crop_select: reg %s cls %s crops %s priors %s do not line up"
+                           % (tuple(reg_boxes.shape), tuple(cls.shape), tuple(crop_bx.shape), tuple(pre_loc.shape)))
+    dev = cls.device
+    reg_boxes, cls, pre_loc = _hip.f32c(reg_boxes), _hip.f32c(cls), _hip.f32c(pre_loc)
+    crop_bx, cam = crop_bx.double().contiguous(), cam_idxs.long().contiguous()
+    st = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    oc = torch.empty(n, dtype=torch.int64, device=dev)
+    of = torch.empty(n, dtype=torch.float32, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            _hip.check(lib.rn_crop_select(reg_boxes.data_ptr(), cls.data_ptr(), crop_bx.data_ptr(), cam.data_ptr(),
+                                          pre_loc.data_ptr(), H1.data_ptr(), _hip.ptr(H2), P1.data_ptr(), _hip.ptr(P2),
+                                          H1.shape[0], n, A, C, float(cs), int(cd_max), float(W), st.data_ptr(), oc.data_ptr(),
+                                          of.data_ptr(), _hip.stream()), "rn_crop_select")
+    return st, oc, of

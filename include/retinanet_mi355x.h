@@ -150,6 +150,28 @@ int rn_parse_detections(const float *scores, const int64_t *labels, const float 
                         int32_t *out_count, void *stream);
 int rn_md_iou(const double *a, const double *b, double *out, int64_t n, void *stream);
 
+/* ---------------------------------------------------------------- tracker: crop refinement ----------------
+ * The block of MC_Crop_Tracker.track around the LOCALIZE detector (MC3D_crop_tracker.py:1172-1226), device-resident.
+ * rn_crop_boxes: get_crop_boxes (:920-944): im_objs [n,8,2] fp64 (state_to_im of the priors) -> crop_boxes [n,4] fp64
+ *   (x1,y1,x2,y2), squares of side max(w,h)*b; rois (may be NULL) [n,5] fp32 = (camera index, box), the argument of
+ *   roi_align (:1183-1185).
+ * rn_roi_align: torchvision.ops.roi_align(frames [N,C,H,W] fp32, rois, (out_h,out_w)) with its defaults
+ *   (spatial_scale 1, sampling_ratio -1, aligned False), fp32, torchvision's operation order (third-party: restated,
+ *   "parity unpinned"); nhwc4 != 0 writes [n,out_h,out_w,4] (C <= 4, rest 0), the stem convolution's layout.
+ * rn_crop_select: everything after the detector (:1192-1226) for n objects: reg_boxes [n,A,20] / cls [n,A,C] (the
+ *   LOCALIZE outputs), crop_boxes, cam_idxs [n] i64, pre_loc [n,6] priors -> per object the best of the cd_max most
+ *   confident detections by (1-W)*IoU(footprint, prior footprint) + W*conf, as state [n,6] with the height refinement,
+ *   class [n] i64, confidence [n].  A <= 4096, cd_max <= 256.  Heights start at 5 ft ("other"): what guess_heights
+ *   returns for the integer classes the tracker passes. */
+int rn_crop_boxes(const double *im_objs, const int64_t *cam_idxs, int n, double b, double *crop_boxes, float *rois,
+                  void *stream);
+int rn_roi_align(const float *frames, int N, int C, int H, int W, const float *rois, int n, int out_h, int out_w,
+                 float *out, int nhwc4, void *stream);
+int rn_crop_select(const float *reg_boxes, const float *cls, const double *crop_boxes, const int64_t *cam_idxs,
+                   const float *pre_loc, const double *H1, const double *H2, const double *P1, const double *P2,
+                   int n_cam, int n, int A, int C, double cs, int cd_max, float W, float *out_state, int64_t *out_cls,
+                   float *out_conf, void *stream);
+
 /* ---------------------------------------------------------------- frame ingest ----------------------------
  * Replaces F.to_tensor + F.normalize of the reference's loaders (util_track/mp_loader.py:239-243,
  * perform_3D_detection_on_video_sequences.py:51-58) on device: frames uint8 [B,H,W,3] (as the decoder / cv2.resize

@@ -255,10 +255,11 @@ def test_crop_refine_golden(golden):
     crop_boxes = ocr.get_crop_boxes(im_objs)
     assert crop_boxes.dtype == torch.float64
     assert np.array_equal(crop_boxes.numpy(), z["crop_boxes"])
-    reg_boxes, cls = gc.crop_detections(im_objs, crop_boxes.float())
-    glob = ocr.local_to_global(reg_boxes, crop_boxes.float())
+    reg_boxes, cls = gc.crop_detections(im_objs, crop_boxes)
+    glob = ocr.local_to_global(reg_boxes, crop_boxes)            # float32 detections x float64 crop boxes -> float64
+    assert glob.dtype == torch.float64
     assert np.array_equal(glob.numpy(), z["local_to_global"])
-    best, bcls, bconf = ocr.refine_from_detections(reg_boxes, cls, crop_boxes.float(), cam, pre_loc, H, H2, P, P2)
+    best, bcls, bconf = ocr.refine_from_detections(reg_boxes, cls, crop_boxes, cam, pre_loc, H, H2, P, P2)
     assert np.array_equal(bcls.numpy(), z["best_classes"])
     assert np.array_equal(bconf.numpy(), z["best_confs"])
     assert np.allclose(best.numpy(), z["best_state"], rtol=1e-5, atol=1e-4)

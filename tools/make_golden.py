@@ -404,8 +404,10 @@ def gen_crop_refine():
     out = {}
     crop_boxes = T.get_crop_boxes(me, im_objs)
     out["crop_boxes"] = t2n(crop_boxes)
-    reg_boxes, cls = gc.crop_detections(im_objs, crop_boxes.float())
-    glob = T.local_to_global(me, reg_boxes.clone(), crop_boxes.float())
+    reg_boxes, cls = gc.crop_detections(im_objs, crop_boxes)
+    # as in track(): crop_boxes stays float64 (it comes from the float64 state_to_im), so the float32 detections are
+    # promoted and the frame coordinates are float64 (MC3D_crop_tracker.py:1198, 1204)
+    glob = T.local_to_global(me, reg_boxes.clone(), crop_boxes)
     out["local_to_global"] = t2n(glob)
     # the reference's own sequence between the detector and select_best_box (MC3D_crop_tracker.py:1188-1219), run with
     # the reference's Homography_Wrapper
