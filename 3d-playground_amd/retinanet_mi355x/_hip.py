@@ -76,6 +76,8 @@ class ConvGroup(ctypes.Structure):
 SIGNATURES.update({
     "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rn_conv_splitk_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "rn_conv_igemm_splitk": (c_i32, [ctypes.POINTER(ConvDesc)] + [c_vp] * 10),
     "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 12 + [c_vp]),
     "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp] + [c_i32] * 4 + [c_vp]),
     "rn_unpack_wgrad": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp] * 7),

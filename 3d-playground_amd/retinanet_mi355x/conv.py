@@ -62,7 +62,16 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
     d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p_h, p_w, ds, act, add_mode, add_hw[0], add_hw[1],
                  (mask_mode if mask is not None else 0), int(in_relu), os_, oo_h, oo_w, Hy, Wy,
                  a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride)
-    rc = prof.timed("conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2", flops, lambda: lib.rn_conv_igemm(
+    kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
+    ws_bytes = lib.rn_conv_splitk_workspace_bytes(ctypes.byref(d))           # > 0: few output tiles, long K -> split-K
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_splitk(
+            ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
+            _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), ws.data_ptr(), _hip.stream()))
+        _hip.check(rc, "rn_conv_igemm_splitk")
+        return y
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm(
         ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
         _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm")

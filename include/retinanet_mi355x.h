@@ -233,6 +233,15 @@ int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, 
                   const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
                   void *stream);
 
+/* Split-K form for problems with few output tiles and a long K loop (the P6 / P7 pyramid levels, the deep layers of
+ * the 112x112 crop detector): rn_conv_splitk_workspace_bytes returns 0 when splitting is not worthwhile, otherwise the
+ * scratch size; rn_conv_igemm_splitk then slices K over grid.y, each slice storing its raw partial tile in its own slab
+ * (no atomics: results are reproducible), and a finish kernel adds the slabs in order and applies the same epilogue. */
+int64_t rn_conv_splitk_workspace_bytes(const rn_conv_desc *d);
+int rn_conv_igemm_splitk(const rn_conv_desc *d, const float *x, const float *w_packed, float *y, const float *scale,
+                         const float *shift, const float *add, const float *mask, const float *add2, void *workspace,
+                         void *stream);
+
 /* Grouped launch: up to RN_MAX_GROUP problems that share the weights and every scalar of the descriptor except the
  * geometry (N, Hi, Wi, Ho, Wo, output map, batch strides) run as ONE grid -- the five pyramid levels of a head tower
  * (D/model.py:302-304 loops over them): the small levels no longer occupy a fraction of the GPU for a full

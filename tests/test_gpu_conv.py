@@ -290,3 +290,48 @@ def test_shortcut_1x1_stride2_gradient_added_at_even_positions(cv, dev):
     dx = cv.dgrad(nhwc(g1).to(dev), cv.pack_weights(w1.to(dev), 1), (H, W), C, 1, 1, 0, add=nhwc(lateral).to(dev),
                   add_mode=1, mask=nhwc(zmask).to(dev), add2=compact)
     close(nchw(dx), want)
+
+
+SPLITK_CASES = [  # cin, cout, k, stride, pad, N, H, W : few output tiles, long K -> rn_conv_igemm_splitk
+    (512, 256, 3, 2, 1, 2, 17, 15),      # the P6 shape class: 3x3 stride 2 on many channels
+    (256, 256, 3, 1, 1, 3, 4, 4),        # layer4-of-a-crop class: a handful of pixels
+    (512, 40, 3, 1, 1, 2, 5, 7),         # narrow Cout (256x64 tile), Cout not a multiple of 32
+    (1024, 256, 1, 1, 0, 1, 9, 11),      # 1x1 with long K
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_splitk_fprop_and_dgrad(cv, dev, case):
+    """The split-K path (chosen by rn_conv_splitk_workspace_bytes) with bias + residual add + ReLU against F.conv2d,
+    and the data gradient; results must be reproducible bit for bit (no atomics)."""
+    from retinanet_mi355x import _hip
+    cin, cout, k, stride, pad, N, H, W = case
+    x = rnd((N, cin, H, W), 1)
+    w = rnd((cout, cin, k, k), 2, (2.0 / (k * k * cin)) ** 0.5)
+    bias = rnd((cout,), 4)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, bias, stride, pad)
+    res = rnd(tuple(y_ref.shape), 5)
+    out_ref = F.relu(y_ref + res)
+    xg, wg = nhwc(x).to(dev), w.to(dev)
+    wp = cv.pack_weights(wg, 0)
+    Ho, Wo = y_ref.shape[2], y_ref.shape[3]
+    geom = (Ho, Wo, cout, k, k, stride, 1, -pad, 0)
+    d = cv._make_desc(xg, geom, cv.ACT_RELU, 1, (0, 0), 0, False, None, None, None, None)
+    import ctypes
+    assert _hip.load().rn_conv_splitk_workspace_bytes(ctypes.byref(d)) > 0, "case no longer takes the split-K path"
+    resg = nhwc(res).contiguous().to(dev)
+    y1 = cv.fprop(xg, wp, cout, k, stride, pad, shift=bias.to(dev), act=cv.ACT_RELU, add=resg, add_mode=1)
+    close(nchw(y1), out_ref.detach())
+    y2 = cv.fprop(xg, wp, cout, k, stride, pad, shift=bias.to(dev), act=cv.ACT_RELU, add=resg, add_mode=1)
+    assert torch.equal(y1, y2)
+    if stride == 1:
+        gy = rnd(tuple(y_ref.shape), 3)
+        (y_ref * gy).sum().backward()
+        cpad = (cout + 3) // 4 * 4
+        gyg = nhwc(gy).to(dev)
+        if cpad != cout:
+            gyg = F.pad(gyg, (0, cpad - cout))
+        wd = cv.pack_weights(wg, 1, c_pad=cpad)
+        dx = cv.dgrad(gyg.contiguous(), wd, (H, W), cin, k, stride, pad)
+        close(nchw(dx), xr.grad)

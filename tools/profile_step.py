@@ -46,7 +46,7 @@ def main():
         return orig_timed(kind + "|" + cur["tag"], work, fn)
     prof.timed = timed
     cv.prof = prof
-    for name in ("fwd", "bwd_params", "bwd_data"):
+    for name in ("fwd", "bwd_params", "bwd_data", "fwd_group", "bwd_data_group", "bwd_data_compact"):
         orig = getattr(engine.Layer, name)
 
         def wrap(orig=orig, name=name):
@@ -67,7 +67,7 @@ def main():
     print("step %.1f ms, conv kernels %.1f ms" % (total, conv_total))
     rows = sorted(summ.items(), key=lambda kv: -kv[1]["ms_total"])
     print("%-58s %4s %8s %7s" % ("kernel|layer:phase", "n", "ms", "TF/s"))
-    for k, a in rows[:70]:
+    for k, a in rows:
         tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12
         print("%-58s %4d %8.3f %7.1f" % (k, a["launches"], a["ms_total"], tf))
     # by phase
