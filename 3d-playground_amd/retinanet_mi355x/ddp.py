@@ -73,6 +73,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RN_REHEARSE_ONE_GPU"):
+        # Development only: rehearse the N > 1 code path on a box with ONE GPU -- every rank uses cuda:0 and the
+        # gradients travel over gloo (RCCL refuses two ranks on one device).  Never set by bench.py or the driver.
+        backend, local = "gloo", 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
