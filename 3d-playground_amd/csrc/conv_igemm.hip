@@ -16,8 +16,10 @@
 //             (row stride 144 B): ds_write_b128 by rows is conflict-free, and the fragment read
 //             ds_read_b128 at [row = lane&31][k = 8*step + 4*(lane>>5) .. +3] is conflict-free as well
 //             (16-lane groups hit 16 distinct 16-byte slots: 9*row mod 16 is a bijection on the group's rows);
-//             one b128 per operand tile feeds four MFMAs.  Global->register loads of K-step t+1 are issued before
-//             the 64 MFMAs of step t and written to the other LDS buffer after them: one barrier per K-step.
+//             one b128 per operand tile feeds four MFMAs.  Global->register loads run two K-steps ahead (two register
+//             stages at K-step 32): issued before the 64 MFMAs of step t, written to the idle LDS buffer one step later,
+//             after the MFMAs: one barrier per K-step.  They are unconditional, from clamped addresses; zero-fill and the
+//             input ReLU happen on the way into LDS (conv_igemm_tile.h).
 // Grid:       1-D, tile id remapped so that consecutive tiles (neighbouring pixel rows, both Cout halves) share
 //             an XCD's L2: halo rows and the 9 taps of a 3x3 filter are re-read from L2, not HBM.
 //
