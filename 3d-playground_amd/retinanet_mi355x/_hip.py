@@ -47,6 +47,9 @@ SIGNATURES = {
     "rn_crop_boxes": (c_i32, [c_vp, c_vp, c_i32, c_f64, c_vp, c_vp, c_vp]),
     "rn_roi_align": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "rn_crop_select": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "rn_kf_view": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "rn_kf_predict": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f64, c_i32, c_vp]),
+    "rn_kf_update": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "rn_frame_ingest": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32] + [c_f32] * 6 + [c_i32, c_vp, c_vp]),
 }
 

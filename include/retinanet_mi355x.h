@@ -172,6 +172,21 @@ int rn_crop_select(const float *reg_boxes, const float *cls, const double *crop_
                    int n_cam, int n, int A, int C, double cs, int cd_max, float W, float *out_state, int64_t *out_cls,
                    float *out_conf, void *stream);
 
+/* ---------------------------------------------------------------- tracker: Kalman filter -------------------
+ * The tensor algebra of Torch_KF (util_track/kf.py:264-403), one lane per object.  X [n,6] fp32 (x,y,l,w,h,v),
+ * P [n,6,6] fp32, D [n] fp32 travel direction, T [n] fp64 time stamps, F [6,6], Q [6,6], H [5,6], R [5,5], mu_R [5]
+ * fp32.  dt: one fp64 value (dt_is_tensor 0: the reference's Python-float path, all fp32) or [n] fp64 values
+ * (dt_is_tensor 1: Q*dt/dt_default is formed in fp64, kf.py:321-326).  F[0][5] is replaced by D*dt per object.
+ * rn_kf_view (dt may be NULL = no prediction): out [n,6], or [n,7] with the direction inserted before the speed.
+ * rn_kf_predict updates X, P, T in place.  rn_kf_update applies measurements z [m,5] fp64 to the objects rows[m]
+ * (distinct rows), innovation in fp64, S^-1 by fp32 Gauss-Jordan with partial pivoting. */
+int rn_kf_view(const float *X, const float *D, const float *F, const double *dt, int dt_is_tensor, int with_direction,
+               float *out, int n, void *stream);
+int rn_kf_predict(float *X, float *P, const float *D, double *T, const float *F, const float *Q, const double *dt,
+                  int dt_is_tensor, double dt_default, int n, void *stream);
+int rn_kf_update(float *X, float *P, const int32_t *rows, const double *z, const float *H, const float *R,
+                 const float *mu_R, int m, void *stream);
+
 /* ---------------------------------------------------------------- frame ingest ----------------------------
  * Replaces F.to_tensor + F.normalize of the reference's loaders (util_track/mp_loader.py:239-243,
  * perform_3D_detection_on_video_sequences.py:51-58) on device: frames uint8 [B,H,W,3] (as the decoder / cv2.resize

@@ -164,3 +164,26 @@ def crop_detections(im_objs, crop_boxes, n_det=64, seed=43, cs=112):
     cls = torch.from_numpy(synth.uniform((n, n_det, 8), seed + 1).astype(np.float32))
     cls = cls * cls                                                                                    # skewed scores, few ties
     return reg_boxes, cls
+
+
+def kf_inputs(n=40, seed=61):
+    """A populated tracker filter (util_track/kf.py): INIT matrices (F, H, SPD Q / R / P0, offsets), n objects with
+    direction and time stamps, a subset to update with measurements, per-object dt."""
+    def spd(k, sd, scale):
+        a = synth.uniform((k, k), sd).astype(np.float64) - 0.5
+        return torch.from_numpy((a @ a.T * scale + np.eye(k) * scale).astype(np.float32))
+    F = torch.eye(6)
+    H = torch.zeros(5, 6)
+    H[:5, :5] = torch.eye(5)
+    H[0, 5] = 0.03                                             # a measurement model that also sees the speed a little
+    INIT = {"P": spd(6, seed, 20.0), "F": F, "H": H, "Q": spd(6, seed + 1, 0.5), "R": spd(5, seed + 2, 2.0),
+            "mu_Q": torch.zeros(6), "mu_R": torch.from_numpy((synth.uniform((5,), seed + 3) - 0.5).astype(np.float32))}
+    st = synth.vehicle_states(n, seed=seed + 4)
+    det = st[:, :5].clone()                                    # x, y, l, w, h
+    directions = st[:, 5].clone()
+    times = torch.from_numpy(synth.uniform((n,), seed + 5).astype(np.float64) * 0.2 + 10.0)
+    speed = torch.from_numpy((60 + 60 * synth.uniform((n,), seed + 6)).astype(np.float32))
+    upd_ids = [i for i in range(n) if i % 3 != 1]
+    z = det[upd_ids] + torch.from_numpy((synth.uniform((len(upd_ids), 5), seed + 7) - 0.5).astype(np.float32)) * 3.0
+    dts = torch.from_numpy(synth.uniform((n,), seed + 8).astype(np.float64) * 0.08 + 0.01)
+    return INIT, det, directions, times, speed, upd_ids, z, dts

@@ -283,3 +283,26 @@ def test_roi_align_restatement_properties():
     assert np.allclose(out[0, 2], 7.0)
     far = ocr.roi_align(img, np.array([[0, -50.0, -50.0, -10.0, -10.0]], dtype=np.float32), (4, 4))
     assert np.all(far == 0)
+
+
+# ------------------------------------------------------------------ tracker Kalman filter
+def test_kf_golden(golden):
+    """oracle/kf.py against the reference's Torch_KF run step by step (tools/make_golden.py gen_kf)."""
+    from oracle import kf as okf
+    z = golden("kf")
+    INIT, det, directions, times, speed, upd_ids, meas, dts = gc.kf_inputs()
+    F, H, Q, R, mu_R = INIT["F"], INIT["H"], INIT["Q"].unsqueeze(0), INIT["R"].unsqueeze(0), INIT["mu_R"].unsqueeze(0)
+    X = torch.from_numpy(z["X0"])
+    P = torch.from_numpy(z["P0"])
+    T = torch.from_numpy(z["T0"])
+    D = directions
+    for tag, dt in (("1", 1 / 30.0), ("2", 0.05), ("3", dts)):
+        X, P, T = okf.predict(X, P, D, T, F, Q, dt)
+        assert np.array_equal(X.numpy(), z["X" + tag]) and np.array_equal(P.numpy(), z["P" + tag]), tag
+        assert np.array_equal(T.numpy(), z["T" + tag]) and P.dtype == torch.float32
+    assert np.array_equal(okf.view(X, D, F, dts, with_direction=True).numpy(), z["view_dir"])
+    assert np.array_equal(okf.view(X, D, F, 1 / 30.0).numpy(), z["view_plain"])
+    X4, P4 = okf.update(X, P, upd_ids, meas, H, R, mu_R)
+    assert np.allclose(X4.numpy(), z["X4"], rtol=1e-6, atol=1e-6) and np.allclose(P4.numpy(), z["P4"], rtol=1e-5, atol=1e-6)
+    untouched = [i for i in range(len(X)) if i not in upd_ids]
+    assert np.array_equal(X4[untouched].numpy(), X[untouched].numpy())

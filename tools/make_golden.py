@@ -428,6 +428,52 @@ def gen_crop_refine():
     np.savez_compressed(os.path.join(OUT, "crop_refine.npz"), **out)
 
 
+def gen_kf():
+    """Torch_KF (util_track/kf.py) itself: add, predict with the default dt / a float dt / a per-object dt tensor, view,
+    update.  The module imports matplotlib.pyplot at the top (unused by the class, absent here): stubbed."""
+    if "matplotlib" not in sys.modules:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, mpl.pyplot
+    sys.path.insert(0, REF)
+    try:
+        kfmod = importlib.import_module("util_track.kf")
+    finally:
+        sys.path.remove(REF)
+    INIT, det, directions, times, speed, upd_ids, z, dts = gc.kf_inputs()
+    out = {}
+
+    def snap(t):                                  # the class updates X, P and T in place: snapshots must be copies
+        return t2n(t.clone())
+    kf = kfmod.Torch_KF(torch.device("cpu"), INIT={k: v.clone() for k, v in INIT.items()}, ADD_MEAN_R=True)
+    ids = list(range(100, 100 + len(det)))
+    kf.add(det.clone(), ids, directions.clone(), times.clone())
+    kf.X[:, 5] = speed
+    out["X0"], out["P0"], out["T0"] = snap(kf.X), snap(kf.P), snap(kf.T)
+    kf.predict()
+    out["X1"], out["P1"], out["T1"] = snap(kf.X), snap(kf.P), snap(kf.T)
+    kf.predict(dt=0.05)
+    out["X2"], out["P2"], out["T2"] = snap(kf.X), snap(kf.P), snap(kf.T)
+    kf.predict(dt=dts.clone())
+    out["X3"], out["P3"], out["T3"] = snap(kf.X), snap(kf.P), snap(kf.T)
+    _, v = kf.view(dt=dts.clone(), with_direction=True)
+    out["view_dir"] = t2n(v)
+    _, v = kf.view(dt=1 / 30.0)
+    out["view_plain"] = t2n(v)
+    kf.update(z.clone(), [ids[i] for i in upd_ids])
+    out["X4"], out["P4"] = snap(kf.X), snap(kf.P)
+    kf.remove([ids[0], ids[5]])
+    out["X5"], out["T5"] = snap(kf.X), snap(kf.T)
+    out["ids5"] = np.array(kf.view()[0])
+    # the default constructor (diagonal matrices, H sees 4 of 5 measurements: kf.py:60-68)
+    kd = kfmod.Torch_KF(torch.device("cpu"))
+    kd.add(det.clone(), ids, directions.clone(), times.clone())
+    kd.predict()
+    kd.update(z.clone(), [ids[i] for i in upd_ids])
+    out["Xd"], out["Pd"] = snap(kd.X), snap(kd.P)
+    np.savez_compressed(os.path.join(OUT, "kf.npz"), **out)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
@@ -438,7 +484,7 @@ def main():
     m_dir, l_dir, u_dir, a_dir = import_variant("dir")
     dir_mods = (m_dir, l_dir, u_dir, a_dir)
     m_2d, l_2d, u_2d, a_2d = import_variant("2d")
-    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv", "tracker_post", "crop_refine"}
+    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv", "tracker_post", "crop_refine", "kf"}
     if "anchors" in which:
         gen_anchors(a_dir)
     if "losses" in which:
@@ -457,6 +503,8 @@ def main():
         gen_tracker_post()
     if "crop_refine" in which:
         gen_crop_refine()
+    if "kf" in which:
+        gen_kf()
     for fn in sorted(os.listdir(OUT)):
         print("%-20s %8.1f KiB" % (fn, os.path.getsize(os.path.join(OUT, fn)) / 1024))
     del dir_mods
