@@ -5,11 +5,12 @@
 // tap][ci], i.e.  M = Cout,  N = kh*kw*Cin (the packed-weight row, so a tile may span several taps of a
 // narrow layer),  K = N*Ho*Wo pixels.
 //
-// Both operands are pixel-major in memory (NHWC: one pixel = one contiguous channel vector) while the MFMA wants
-// each lane's k operands -- pixels -- of one channel row.  A thread therefore stages 4x4 blocks (4 pixels x 4
-// channels: four 16-byte global loads), transposes them in registers for free and writes four 16-byte LDS rows into
-// a [channel][32 pixels] tile (XOR-swizzled, conflict-free both ways); a fragment is then one ds_read_b128 = the k
-// operands of 4 MFMAs: 16 LDS reads against 64 MFMAs (64 cycles each) per wave per K-step.
+// Both operands are pixel-major in memory (NHWC: one pixel = one contiguous channel vector) and are staged into LDS
+// exactly as they lie -- [32 pixels][channels], plain 16-byte copies.  The MFMA wants one operand value per lane,
+// A[row = lane&31][k = lane>>5]: a lane reads two adjacent channels of pixel k with one ds_read_b64 and feeds them to
+// two different 32-row tiles (tile tm holds channels 2*i + tm), so no transposition is ever done; the permutation is
+// undone by the epilogue's index arithmetic.  32 ds_read_b64 against 64 MFMAs (64 cycles each) per wave per K-step,
+// every fragment address an immediate.
 //
 // K is split over gridDim.y; partial tiles are added with fp32 atomics (two 128-byte row segments per wave
 // instruction, the full-rate shape) into a buffer the caller zeroes -- the five pyramid levels of a shared head
@@ -24,6 +25,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WK 32                    // pixels per K-step
+#define TB 8                     // K-steps per pixel-table batch (TB * WK = 256 = one entry per thread)
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
     const float *dy, *x;
@@ -37,19 +40,13 @@ struct WgradArgs {
     int64_t pixels, per_split;   // K extent and K per grid.y slice (multiple of WK)
 };
 
-// LDS tile layout: [channel row][32 pixels], pixel-contiguous, no padding; the 16-byte slot (4 pixels) of a row is
-// XOR-swizzled with s(row) = (row & 7) ^ ((row >> 3) & 7).  Both access patterns then touch 8 distinct slots per 8
-// consecutive lanes: the staging writes (lane -> rows 4*ca + j, fixed slot) and the fragment reads (lane -> 32
-// consecutive rows, fixed slot).
-__device__ __forceinline__ int wg_swz(int row) { return (row & 7) ^ ((row >> 3) & 7); }
-
 template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int CA = BM / 4, CB = BN / 4;                  // 4-channel chunks per tile
     constexpr int NA = (CA * 8 + 255) / 256, NB = (CB * 8 + 255) / 256;   // 4x4 (pixel x channel) blocks per thread
     __shared__ float lds[2][WK * (BM + BN)];
-    __shared__ int4 pixtab[2][WK];                           // per K-step: (n*Hi, oh*st - pad, ow*st - pad, valid)
+    __shared__ int4 pixtab[2][TB * WK];                      // two batches of TB K-steps: (x byte offset, ih0, iw0, -)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -74,9 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int nks = (int)((kend - kbeg + WK - 1) / WK);
     const int HoWo = p.Ho * p.Wo;
 
-    // Staging.  A thread owns 4x4 blocks: 4 consecutive channels (one 16-byte global load per pixel) x 4 consecutive
-    // pixels; the block is transposed in registers (free: it is only a renaming) and leaves as four 16-byte LDS
-    // writes, one per channel row, 4 pixels each.  Block b of a tile: chunk = b % chunks, pixel group = b / chunks.
+    // Staging.  A thread owns 4x4 blocks: 4 consecutive channels (one 16-byte load per pixel) x 4 consecutive pixels,
+    // stored as they come.  Block b of a tile: chunk = b % chunks, pixel group = b / chunks.
     const int ca = tid % CA, pga0 = tid / CA;                // A: block i -> pixel group pga0 + (256 / CA) * i
     const bool a_active = (CA * 8 >= 256) || tid < CA * 8;
     const bool a_col_ok = (m0 + 4 * ca) < p.ldy;
@@ -87,80 +83,86 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int fr = tap / p.kw, fs = tap - fr * p.kw;
     const bool b_col_ok = jcol < p.Kflat;
 
-    // One lane per pixel of a K-step decomposes it into (n, oh, ow) for everybody: two integer divisions per
-    // K-step instead of two per staged row.
-    auto fill_table = [&](int ks) {
-        if (tid < WK) {
-            const int64_t pix = kbeg + (int64_t)ks * WK + tid;
-            int4 e = make_int4(0, 0, 0, 0);
-            if (pix < kend) {
-                const int n = (int)(pix / HoWo);
-                const int rem = (int)(pix - (int64_t)n * HoWo);
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                e = make_int4(n * p.Hi, oh * p.stride - p.pad, ow * p.stride - p.pad, 1);
-            }
-            pixtab[ks & 1][tid] = e;
+    // Both operands are read with BUFFER loads, and everything that must read as zero -- image padding, pixels past
+    // the end of the K slice, columns past the matrix -- is simply given an out-of-range offset: the hardware range
+    // check returns 0.0 for it (checked per dword against num_records, soffset included; tools/probes/buffer_probe.hip).
+    // So the load phase has no clamps and no validity masks, the store phase no selects, and for dY not even address
+    // arithmetic: four per-thread offsets fixed for the whole kernel + one scalar K-step advance.
+    //   dY: descriptor = the K slice [kbeg, kend) only, so "pixel >= kend" is out of range by itself;
+    //   X : descriptor starts at the first image the slice touches; the host guarantees the slice's span of images
+    //       stays below 2 GiB, so byte offsets are plain int32 and -1 is always out of range.
+    const int n_first = (int)(kbeg / HoWo);
+    const int rel0 = (int)(kbeg - (int64_t)n_first * HoWo);  // slice-relative pixel index of kbeg within image n_first
+    const int64_t img = (int64_t)p.Hi * p.Wi * p.Cin;        // floats per input image
+    int64_t xbytes = ((int64_t)p.N - n_first) * img * 4;
+    if (xbytes > 0x7FFFFFFF) xbytes = 0x7FFFFFFF;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.dy + kbeg * p.ldy), 0, (unsigned)((kend - kbeg) * p.ldy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.x + (int64_t)n_first * img), 0, (unsigned)xbytes, 0x00020000);
+    unsigned a_voff[NA][4];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px = 4 * (pga0 + (256 / CA) * i) + q;
+            a_voff[i][q] = (a_active && a_col_ok) ? (unsigned)((px * p.ldy + m0 + 4 * ca) * 4) : 0x80000000u;
         }
+    const int fr_t = b_col_ok ? fr : (1 << 24);              // a column past the matrix fails every row test below
+    const int tap_off = ((fr * p.Wi + fs) * p.Cin + ci0) * 4;
+
+    // Pixel table: one entry per pixel of the K range, (byte offset of input pixel (ih0, iw0) channel 0, ih0, iw0) with
+    // ih0 = oh*stride - pad: the two integer divisions of the (n, oh, ow) decomposition are done once per pixel for all
+    // 256 threads and all taps.  Filled TB K-steps at a time by the whole workgroup (one entry per thread).
+    auto fill_batch = [&](int j) {
+        const int rel = rel0 + j * (TB * WK) + tid;           // pixel index relative to image n_first
+        int4 e = make_int4(0, -(1 << 28), 0, 0);              // past the slice: fails the row test (also with fr_t = 2^24 added)
+        if (kbeg + (int64_t)j * (TB * WK) + tid < kend) {
+            const unsigned n = (unsigned)rel / (unsigned)HoWo;
+            const unsigned rem = (unsigned)rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)p.Wo, ow = rem - oh * (unsigned)p.Wo;
+            const int ih0 = (int)oh * p.stride - p.pad, iw0 = (int)ow * p.stride - p.pad;
+            e = make_int4((((int)n * p.Hi + ih0) * p.Wi + iw0) * p.Cin * 4, ih0, iw0, 0);
+        }
+        pixtab[j & 1][tid] = e;
     };
     const bool do_cs = p.colsum != nullptr && (tile % p.tiles_n) == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[NA][4], vb[NB][4];
-    unsigned okmask = 0;                                     // validity of the staged blocks: bit i*4+q for A, 16 + i*4+q for B
-    // Loads are unconditional, from clamped (always mapped) addresses; what must read as zero (image padding, rows
-    // past the end of the K range, columns past the tile) is zeroed in store_step, after the MFMAs.  A select or a
-    // branch right behind a load would make the compiler wait for it here, one round trip per load.
-    const int64_t a_col = a_col_ok ? (int64_t)(m0 + 4 * ca) : 0;
-    const int ci_safe = b_col_ok ? ci0 : 0;
-    const int fr_safe = b_col_ok ? fr : 0, fs_safe = b_col_ok ? fs : 0;
+    auto bufload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+    };
     auto load_step = [&](int ks) {
-        const int64_t kb = kbeg + (int64_t)ks * WK;
-        okmask = 0;
+        const unsigned so = (unsigned)ks * (unsigned)(WK * 4) * (unsigned)p.ldy;   // scalar: the K-step advance
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int pg = pga0 + (256 / CA) * i;
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t pix = kb + 4 * pg + q;
-                const bool ok = a_active && a_col_ok && pix < kend;
-                okmask |= ok ? (1u << (i * 4 + q)) : 0u;
-                const int64_t pc = pix < p.pixels ? pix : p.pixels - 1;
-                va[i][q] = *reinterpret_cast<const float4 *>(p.dy + pc * p.ldy + a_col);
-            }
-        }
+            for (int q = 0; q < 4; ++q) va[i][q] = bufload(rs_a, a_voff[i][q], so);
+        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int pg = pgb0 + (256 / CB) * i;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int4 e = pixtab[ks & 1][4 * pg + q];
-                const int ih = e.y + fr_safe, iw = e.z + fs_safe;
-                const bool ok = b_col_ok && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-                okmask |= ok ? (1u << (16 + i * 4 + q)) : 0u;
-                const int ihc = ih < 0 ? 0 : (ih >= p.Hi ? p.Hi - 1 : ih);
-                const int iwc = iw < 0 ? 0 : (iw >= p.Wi ? p.Wi - 1 : iw);
-                vb[i][q] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(e.x + ihc) * p.Wi + iwc) * p.Cin + ci_safe);
+                const int4 e = tab[4 * pg + q];
+                const bool ok = (unsigned)(e.y + fr_t) < (unsigned)p.Hi && (unsigned)(e.z + fs) < (unsigned)p.Wi;
+                vb[i][q] = bufload(rs_b, ok ? (unsigned)(e.x + tap_off) : 0xFFFFFFFFu, 0u);
             }
         }
     };
     auto store_step = [&](int buf) {
-        float *A = lds[buf], *B = lds[buf] + WK * BM;
+        float *A = lds[buf], *B = lds[buf] + WK * BM;      // [pixel][channel], exactly as the data lies in memory; zeros came from the loads
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!a_active) break;
             const int pg = pga0 + (256 / CA) * i;
             float4 *v = va[i];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (!(okmask & (1u << (i * 4 + q)))) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int r = 4 * ca;                                        // rows r..r+3 share (r >> 3) only pairwise: swizzle per row
-            *reinterpret_cast<float4 *>(A + (r + 0) * WK + 4 * (pg ^ wg_swz(r + 0))) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            *reinterpret_cast<float4 *>(A + (r + 1) * WK + 4 * (pg ^ wg_swz(r + 1))) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            *reinterpret_cast<float4 *>(A + (r + 2) * WK + 4 * (pg ^ wg_swz(r + 2))) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-            *reinterpret_cast<float4 *>(A + (r + 3) * WK + 4 * (pg ^ wg_swz(r + 3))) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
-            // column sums ride on the staged dY; accumulated here, after the MFMAs, so the loads stay in flight
-            if (do_cs) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w; }
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<float4 *>(A + (4 * pg + q) * BM + 4 * ca) = v[q];
+                // column sums ride on the staged dY; accumulated here, after the MFMAs, so the loads stay in flight
+                if (do_cs) { cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w; }
             }
         }
 #pragma unroll
@@ -168,17 +170,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             const int pg = pgb0 + (256 / CB) * i;
             float4 *v = vb[i];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (!(okmask & (1u << (16 + i * 4 + q)))) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.in_relu) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f); }
+            for (int q = 0; q < 4; ++q) {
+                if (p.in_relu) { v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f); }
+                *reinterpret_cast<float4 *>(B + (4 * pg + q) * BN + 4 * cb) = v[q];
             }
-            const int r = 4 * cb;
-            *reinterpret_cast<float4 *>(B + (r + 0) * WK + 4 * (pg ^ wg_swz(r + 0))) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            *reinterpret_cast<float4 *>(B + (r + 1) * WK + 4 * (pg ^ wg_swz(r + 1))) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            *reinterpret_cast<float4 *>(B + (r + 2) * WK + 4 * (pg ^ wg_swz(r + 2))) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-            *reinterpret_cast<float4 *>(B + (r + 3) * WK + 4 * (pg ^ wg_swz(r + 3))) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
         }
     };
 
@@ -190,58 +185,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    fill_table(0);
-    fill_table(1);
+    fill_batch(0);
     __syncthreads();
     if (nks > 0) {
         load_step(0);
         store_step(0);
     }
     __syncthreads();
-    // fragment rows of this lane: A tiles tm = 0,1 and B tiles tn = 0,1; v_mfma_f32_32x32x2_f32 wants A[m = lane&31][k = lane>>5]:
-    // one ds_read_b128 gives 4 consecutive pixels of the row = the k operands of 4 MFMAs (lanes 0-31 take pixel group 2t,
-    // lanes 32-63 group 2t+1; A and B use the same assignment, so the products pair up the same pixels)
+    // Fragments.  v_mfma_f32_32x32x2_f32 wants A[row i = lane&31][k = lane>>5] in one register per lane.  A lane reads TWO
+    // adjacent channels of pixel k with one ds_read_b64 and uses them as row i of two different 32-row MFMA tiles: tile tm
+    // then holds channels 2*i + tm (a fixed permutation of the wave's 64 channels, undone in the epilogue's index
+    // arithmetic).  No transposition anywhere: staging is the plain 16-byte copy, the 32 lanes of a read cover 256
+    // contiguous bytes (conflict-free), and every fragment address is base + immediate.
     const int hi = lane >> 5;
-    int rowA[2], rowB[2], swA[2], swB[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        rowA[t] = wm * 64 + t * 32 + (lane & 31);
-        rowB[t] = wn * 64 + t * 32 + (lane & 31);
-        swA[t] = wg_swz(rowA[t]);
-        swB[t] = wg_swz(rowB[t]);
-    }
+    const int fa0 = hi * BM + wm * 64 + 2 * (lane & 31);
+    const int fb0 = hi * BN + wn * 64 + 2 * (lane & 31);
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nks) load_step(ks + 1);                 // reads pixtab[(ks+1)&1], published by an earlier barrier
-        const float *A = lds[buf];
-        const float *B = lds[buf] + WK * BM;
-        float4 fa[2][2], fb[2][2];                            // [slot][tile]: reads run one group of 16 MFMAs ahead
-        auto read_frag = [&](int t, float4 (&a)[2], float4 (&b)[2]) {
-            const int kg = 2 * t + hi;
+        if (ks + 1 < nks) load_step(ks + 1);                 // reads table batch (ks+1)/TB, published by an earlier barrier
+        const float *A = lds[buf] + fa0;
+        const float *B = lds[buf] + WK * BM + fb0;
+        float2 fa[3], fb[3];                                  // reads run two k-pairs ahead of the MFMAs that consume them
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                a[q] = *reinterpret_cast<const float4 *>(A + rowA[q] * WK + 4 * (kg ^ swA[q]));
-                b[q] = *reinterpret_cast<const float4 *>(B + rowB[q] * WK + 4 * (kg ^ swB[q]));
-            }
-        };
-        read_frag(0, fa[0], fb[0]);
-#pragma unroll
-        for (int t = 0; t < WK / 8; ++t) {
-            const int cur = t & 1;
-            if (t + 1 < WK / 8) read_frag(t + 1, fa[cur ^ 1], fb[cur ^ 1]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a0 = j == 0 ? fa[cur][0].x : j == 1 ? fa[cur][0].y : j == 2 ? fa[cur][0].z : fa[cur][0].w;
-                const float a1 = j == 0 ? fa[cur][1].x : j == 1 ? fa[cur][1].y : j == 2 ? fa[cur][1].z : fa[cur][1].w;
-                const float b0 = j == 0 ? fb[cur][0].x : j == 1 ? fb[cur][0].y : j == 2 ? fb[cur][0].z : fb[cur][0].w;
-                const float b1 = j == 0 ? fb[cur][1].x : j == 1 ? fb[cur][1].y : j == 2 ? fb[cur][1].z : fb[cur][1].w;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
+        for (int pre = 0; pre < 2; ++pre) {
+            fa[pre] = *reinterpret_cast<const float2 *>(A + 2 * pre * BM);
+            fb[pre] = *reinterpret_cast<const float2 *>(B + 2 * pre * BN);
         }
-        if (ks + 2 < nks) fill_table(ks + 2);                 // slot [ks&1] was last read by load_step(ks), before the previous barrier
+#pragma unroll
+        for (int kp = 0; kp < WK / 2; ++kp) {
+            const int cur = kp % 3, nxt = (kp + 2) % 3;
+            if (kp + 2 < WK / 2) {
+                fa[nxt] = *reinterpret_cast<const float2 *>(A + 2 * (kp + 2) * BM);
+                fb[nxt] = *reinterpret_cast<const float2 *>(B + 2 * (kp + 2) * BN);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[1][1], 0, 0, 0);
+            // keep that order: (2 LDS reads for k-pair kp+2) then (4 MFMAs of k-pair kp)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        // next table batch: needed from iteration ks = TB*(j+1) - 1 on; its slot held batch j-1, last read at TB*j - 2
+        if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
         if (ks + 1 < nks) store_step(buf ^ 1);
         __syncthreads();
     }
@@ -266,10 +252,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+            const int col = n0 + wn * 64 + 2 * (lane & 31) + tn;          // tile tn holds columns 2*j + tn (see the fragments)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int row = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) + tm;   // tile tm: channels 2*i + tm
                 if (row < p.Cout && col < p.Kflat) atomicAdd(p.dw + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
             }
         }
@@ -300,7 +286,17 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
     if (splits > 65535) splits = 65535;
     a.xcd_map = tiles >= 16 && splits > 8 && splits + 7 <= max_splits;
     if (a.xcd_map) splits = (splits + 7) / 8 * 8;            // whole slices per XCD: equal shares for the 8
-    a.per_split = ((a.pixels + splits - 1) / splits + WK - 1) / WK * WK;
+    // Buffer-load addressing (see the kernel): the dY bytes of one K slice and the span of input images a slice can
+    // touch must each stay below 2 GiB; more slices make both smaller.
+    const int64_t HoWo = (int64_t)Ho * Wo, img_bytes = (int64_t)Hi * Wi * Cin * 4;
+    for (;;) {
+        a.per_split = ((a.pixels + splits - 1) / splits + WK - 1) / WK * WK;
+        const int64_t span_imgs = (a.per_split + HoWo - 2) / HoWo + 1;
+        if ((a.per_split + WK) * ldy * 4 <= 0x7FFFFFFF && span_imgs * img_bytes <= 0x7FFFFFFF) break;
+        if (a.per_split <= WK || splits >= 65535) return RN_EINVAL;   // a single image of > 2 GiB
+        splits = splits * 2 > 65535 ? 65535 : splits * 2;
+        a.xcd_map = 0;
+    }
     splits = (a.pixels + a.per_split - 1) / a.per_split;
     a.tiles = tiles;
     a.splits = (int)splits;
