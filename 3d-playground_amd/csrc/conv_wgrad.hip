@@ -5,28 +5,64 @@
 // tap][ci], i.e.  M = Cout,  N = kh*kw*Cin (the packed-weight row, so a tile may span several taps of a
 // narrow layer),  K = N*Ho*Wo pixels.
 //
-// Both operands are pixel-major in memory (NHWC: one pixel = one contiguous channel vector) and are staged into LDS
-// exactly as they lie -- [32 pixels][channels], plain 16-byte copies.  The MFMA wants one operand value per lane,
-// A[row = lane&31][k = lane>>5]: a lane reads two adjacent channels of pixel k with one ds_read_b64 and feeds them to
-// two different 32-row tiles (tile tm holds channels 2*i + tm), so no transposition is ever done; the permutation is
-// undone by the epilogue's index arithmetic.  32 ds_read_b64 against 64 MFMAs (64 cycles each) per wave per K-step,
-// every fragment address an immediate.
+// Both operands are pixel-major in memory (NHWC: one pixel = one contiguous channel vector), which for THIS product
+// is reduction-major -- the layout the MFMA operands want anyway.  So the tiles go global -> LDS exactly as they lie,
+// [32 pixels][channels], and they go there directly: buffer loads with the LDS bit set (16 bytes per lane, a wave
+// instruction fills 1 KiB of contiguous LDS = 256/BM pixels of a tile), no staging registers, no ds_write, no store
+// phase.  Everything that must read as zero -- image padding, pixels past the end of the K slice, columns past the
+// matrix -- is given an out-of-range offset and the buffer range check writes 0.0 for it (per dword, soffset included;
+// tools/probes/buffer_probe.hip, lds_dma_probe.hip), so there are no clamps, masks or selects either.  Per wave and
+// K-step that leaves: 8 DMA instructions, for the X half one pixel-table read + 6 VALU each, for the dY half nothing
+// (one offset register fixed for the whole kernel, the pixel advance rides in the scalar soffset).
+// Why it matters: timing the kernel with pieces knocked out showed that whatever a wave does outside its MFMA stream is
+// paid in full -- it is NOT hidden behind the partner wave's MFMAs -- so the staging work had to go, not move.
 //
-// K is split over gridDim.y; partial tiles are added with fp32 atomics (two 128-byte row segments per wave
-// instruction, the full-rate shape) into a buffer the caller zeroes -- the five pyramid levels of a shared head
-// accumulate into the same buffer.  All tiles of one K-slice run on the same XCD so they stream the same dY /
-// X slabs through one L2.
+// Fragments: v_mfma_f32_32x32x2_f32 wants A[row i = lane&31][k = lane>>5] in one register per lane.  A lane reads TWO
+// adjacent channels of pixel k with one ds_read_b64 and uses them as row i of two different 32-row MFMA tiles (tile tm
+// holds channels 2*i + tm: a fixed permutation of the wave's 64 channels, undone by the epilogue's index arithmetic).
+// The 32 lanes of a read cover 256 contiguous bytes (conflict-free), every fragment address is base + immediate,
+// 32 ds_read_b64 against 64 MFMAs (64 cycles each) per wave per K-step.
 //
-// The column sums of dY (bias / batch-norm beta gradients, and the mean term of the gamma gradient) ride along:
-// the workgroups of N-tile 0 add up the dY chunks they stage anyway and finish with one atomic per channel.
+// K is split over the grid; partial tiles are added with fp32 atomics into a buffer the caller zeroes -- the five
+// pyramid levels of a shared head accumulate into the same buffer.  All tiles of one K-slice run on the same XCD so
+// they stream the same dY / X slabs through one L2.
+//
+// The column sums of dY (bias / batch-norm beta gradients, and the mean term of the gamma gradient) ride along: the
+// waves of N-tile 0 that own distinct channels add up their A fragments (two v_add per four MFMAs, inside the MFMA
+// shadow) and finish with one atomic per channel.
 //
 // Roofline: MFMA (fp32 157.3 TF).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (stride 0): base, num_records in bytes, the gfx9-family dword 3 for untyped 32-bit data.
+__device__ __forceinline__ v4i32 make_rsrc(const void *base, unsigned bytes) {
+    const uint64_t b = (uint64_t)base;
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// One direct-to-LDS buffer load: lane l's 16 bytes at (descriptor base + voff + soff) land at LDS byte address
+// lds_dst + 16*l; out-of-range lanes write zeros.  Issued as asm so that the compiler's waitcnt bookkeeping does not see
+// it -- seen, it is taken to alias every later ds_read and fenced with vmcnt(0) BEFORE the MFMA phase it is meant to
+// overlap.  The kernel counts it itself: one "s_waitcnt vmcnt(0)" in front of the barrier that publishes the buffer.
+// M0 (the LDS base of the instruction) is compiler-reserved: saved, set and restored inside the one statement.
+__device__ __forceinline__ void dma16(v4i32 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
 #define WK 32                    // pixels per K-step
 #define TB 8                     // K-steps per pixel-table batch (TB * WK = 256 = one entry per thread)
-typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
     const float *dy, *x;
@@ -37,15 +73,17 @@ struct WgradArgs {
     int tiles_n;                 // number of N tiles
     int tiles, splits;           // tiles_m * tiles_n, K slices
     int xcd_map;                 // 1: whole K slices per XCD (see the kernel)
-    int64_t pixels, per_split;   // K extent and K per grid.y slice (multiple of WK)
+    int64_t pixels, per_split;   // K extent and K per slice (multiple of WK)
 };
 
-template <int WM, int WN>
+template <int WM, int WN, bool RELU>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int CA = BM / 4, CB = BN / 4;                  // 4-channel chunks per tile
-    constexpr int NA = (CA * 8 + 255) / 256, NB = (CB * 8 + 255) / 256;   // 4x4 (pixel x channel) blocks per thread
-    __shared__ float lds[2][WK * (BM + BN)];
+    constexpr int CA = BM / 4, CB = BN / 4;                  // 16-byte chunks per tile row
+    constexpr int PA = 64 / CA, PB = 64 / CB;                // pixels one wave instruction (64 lanes x 16 B) covers
+    constexpr int IA = WK / PA / 4, IB = WK / PB / 4;        // DMA instructions per wave per K-step (4 waves share a tile)
+    static_assert(PA >= 1 && PB >= 1 && IA >= 1 && IB >= 1, "tile shape");
+    __shared__ float lds[2][WK * (BM + BN)];                 // per buffer: A [32 px][BM], then B [32 px][BN]
     __shared__ int4 pixtab[2][TB * WK];                      // two batches of TB K-steps: (x byte offset, ih0, iw0, -)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,54 +107,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int64_t kbeg = (int64_t)slice * p.per_split;
     const int64_t kend = (kbeg + p.per_split < p.pixels) ? kbeg + p.per_split : p.pixels;
     const int nks = (int)((kend - kbeg + WK - 1) / WK);
+    if (nks <= 0) return;
     const int HoWo = p.Ho * p.Wo;
 
-    // Staging.  A thread owns 4x4 blocks: 4 consecutive channels (one 16-byte load per pixel) x 4 consecutive pixels,
-    // stored as they come.  Block b of a tile: chunk = b % chunks, pixel group = b / chunks.
-    const int ca = tid % CA, pga0 = tid / CA;                // A: block i -> pixel group pga0 + (256 / CA) * i
-    const bool a_active = (CA * 8 >= 256) || tid < CA * 8;
-    const bool a_col_ok = (m0 + 4 * ca) < p.ldy;
-    const int cb = tid % CB, pgb0 = tid / CB;                // B: chunk cb -> fixed (tap, ci0)
-    const int jcol = n0 + 4 * cb;
-    const int tap = jcol / p.Cin;
-    const int ci0 = jcol - tap * p.Cin;
-    const int fr = tap / p.kw, fs = tap - fr * p.kw;
-    const bool b_col_ok = jcol < p.Kflat;
-
-    // Both operands are read with BUFFER loads, and everything that must read as zero -- image padding, pixels past
-    // the end of the K slice, columns past the matrix -- is simply given an out-of-range offset: the hardware range
-    // check returns 0.0 for it (checked per dword against num_records, soffset included; tools/probes/buffer_probe.hip).
-    // So the load phase has no clamps and no validity masks, the store phase no selects, and for dY not even address
-    // arithmetic: four per-thread offsets fixed for the whole kernel + one scalar K-step advance.
-    //   dY: descriptor = the K slice [kbeg, kend) only, so "pixel >= kend" is out of range by itself;
-    //   X : descriptor starts at the first image the slice touches; the host guarantees the slice's span of images
-    //       stays below 2 GiB, so byte offsets are plain int32 and -1 is always out of range.
+    // Buffer descriptors (scalar registers).
+    //   dY: the K slice [kbeg, kend) only, so "pixel >= kend" is out of range by itself;
+    //   X : from the first image the slice touches; the host guarantees that the span of images of one slice stays
+    //       below 2 GiB, so byte offsets are plain int32 and -1 is always out of range.
     const int n_first = (int)(kbeg / HoWo);
-    const int rel0 = (int)(kbeg - (int64_t)n_first * HoWo);  // slice-relative pixel index of kbeg within image n_first
+    const int rel0 = (int)(kbeg - (int64_t)n_first * HoWo);  // index of pixel kbeg within image n_first
     const int64_t img = (int64_t)p.Hi * p.Wi * p.Cin;        // floats per input image
     int64_t xbytes = ((int64_t)p.N - n_first) * img * 4;
     if (xbytes > 0x7FFFFFFF) xbytes = 0x7FFFFFFF;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.dy + kbeg * p.ldy), 0, (unsigned)((kend - kbeg) * p.ldy * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.x + (int64_t)n_first * img), 0, (unsigned)xbytes, 0x00020000);
-    unsigned a_voff[NA][4];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int px = 4 * (pga0 + (256 / CA) * i) + q;
-            a_voff[i][q] = (a_active && a_col_ok) ? (unsigned)((px * p.ldy + m0 + 4 * ca) * 4) : 0x80000000u;
-        }
-    const int fr_t = b_col_ok ? fr : (1 << 24);              // a column past the matrix fails every row test below
+    const v4i32 rs_a = make_rsrc(p.dy + kbeg * p.ldy, (unsigned)((kend - kbeg) * p.ldy * 4));
+    const v4i32 rs_b = make_rsrc(p.x + (int64_t)n_first * img, (unsigned)xbytes);
+
+    // Lane -> (pixel within the instruction's group, 16-byte chunk).  Instruction j of wave w fills pixels
+    // (w * I + j) * P + lane / C of the tile: 1 KiB of LDS starting at that pixel's row.
+    const int ca = lane % CA, pa = lane / CA;
+    const int cb = lane % CB, pb = lane / CB;
+    const bool a_col_ok = (m0 + 4 * ca) < p.ldy;
+    const unsigned a_voff = a_col_ok ? (unsigned)(((wave * IA * PA + pa) * p.ldy + m0 + 4 * ca) * 4) : 0x80000000u;
+    const unsigned a_step = (unsigned)(PA * 4) * (unsigned)p.ldy;          // bytes between consecutive instructions (scalar)
+    const int jcol = n0 + 4 * cb;                            // B: the chunk fixes (tap, first input channel)
+    const int tap = jcol / p.Cin;
+    const int ci0 = jcol - tap * p.Cin;
+    const int fr = tap / p.kw, fs = tap - fr * p.kw;
+    const int fr_t = jcol < p.Kflat ? fr : (1 << 24);        // a column past the matrix fails every row test below
     const int tap_off = ((fr * p.Wi + fs) * p.Cin + ci0) * 4;
+    const int b_px0 = wave * IB * PB + pb;                   // this lane's pixel for instruction 0
 
     // Pixel table: one entry per pixel of the K range, (byte offset of input pixel (ih0, iw0) channel 0, ih0, iw0) with
     // ih0 = oh*stride - pad: the two integer divisions of the (n, oh, ow) decomposition are done once per pixel for all
-    // 256 threads and all taps.  Filled TB K-steps at a time by the whole workgroup (one entry per thread).
+    // lanes and all taps.  Filled TB K-steps at a time by the whole workgroup (one entry per thread).
     auto fill_batch = [&](int j) {
-        const int rel = rel0 + j * (TB * WK) + tid;           // pixel index relative to image n_first
-        int4 e = make_int4(0, -(1 << 28), 0, 0);              // past the slice: fails the row test (also with fr_t = 2^24 added)
+        const int rel = rel0 + j * (TB * WK) + tid;
+        int4 e = make_int4(0, -(1 << 28), 0, 0);              // past the slice: fails the row test (also with fr_t added)
         if (kbeg + (int64_t)j * (TB * WK) + tid < kend) {
             const unsigned n = (unsigned)rel / (unsigned)HoWo;
             const unsigned rem = (unsigned)rel - n * (unsigned)HoWo;
@@ -126,54 +152,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         }
         pixtab[j & 1][tid] = e;
     };
-    const bool do_cs = p.colsum != nullptr && (tile % p.tiles_n) == 0;
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 va[NA][4], vb[NB][4];
-    auto bufload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-        const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-        return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
-    };
-    auto load_step = [&](int ks) {
+    // Issue the DMA of K-step ks into buffer `buf`.  The caller's barrier has made sure nobody still reads it.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds0 = lds_addr(&lds[0][0]);
+    auto dma_step = [&](int ks, int buf) {
+        const unsigned A = lds0 + (unsigned)((buf * WK * (BM + BN) + wave_u * (IA * PA) * BM) * 4);   // this wave's first row
+        const unsigned B = lds0 + (unsigned)((buf * WK * (BM + BN) + WK * BM + wave_u * (IB * PB) * BN) * 4);
         const unsigned so = (unsigned)ks * (unsigned)(WK * 4) * (unsigned)p.ldy;   // scalar: the K-step advance
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
+        for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (PA * BM * 4), a_voff, so + j * a_step);
+        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK + b_px0];
+        int4 e[IB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) va[i][q] = bufload(rs_a, a_voff[i][q], so);
-        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK];
+        for (int j = 0; j < IB; ++j) e[j] = tab[j * PB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int pg = pgb0 + (256 / CB) * i;
+        for (int j = 0; j < IB; ++j)                          // all entries first, in one LDS round trip: without this the
+            asm volatile("" : "+v"(e[j].x), "+v"(e[j].y), "+v"(e[j].z));   // compiler sinks each offset read under its test
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int4 e = tab[4 * pg + q];
-                const bool ok = (unsigned)(e.y + fr_t) < (unsigned)p.Hi && (unsigned)(e.z + fs) < (unsigned)p.Wi;
-                vb[i][q] = bufload(rs_b, ok ? (unsigned)(e.x + tap_off) : 0xFFFFFFFFu, 0u);
-            }
-        }
-    };
-    auto store_step = [&](int buf) {
-        float *A = lds[buf], *B = lds[buf] + WK * BM;      // [pixel][channel], exactly as the data lies in memory; zeros came from the loads
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (!a_active) break;
-            const int pg = pga0 + (256 / CA) * i;
-            float4 *v = va[i];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<float4 *>(A + (4 * pg + q) * BM + 4 * ca) = v[q];
-                // column sums ride on the staged dY; accumulated here, after the MFMAs, so the loads stay in flight
-                if (do_cs) { cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int pg = pgb0 + (256 / CB) * i;
-            float4 *v = vb[i];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (p.in_relu) { v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f); }
-                *reinterpret_cast<float4 *>(B + (4 * pg + q) * BN + 4 * cb) = v[q];
-            }
+        for (int j = 0; j < IB; ++j) {
+            const bool ok = ((unsigned)(e[j].y + fr_t) < (unsigned)p.Hi) & ((unsigned)(e[j].z + fs) < (unsigned)p.Wi);
+            dma16(rs_b, B + j * (PB * BN * 4), ok ? (unsigned)(e[j].x + tap_off) : 0xFFFFFFFFu, 0u);
         }
     };
 
@@ -184,25 +182,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float2 cs = make_float2(0.f, 0.f);                       // column sums of this lane's two channels (its k parity)
 
     fill_batch(0);
     __syncthreads();
-    if (nks > 0) {
-        load_step(0);
-        store_step(0);
-    }
+    dma_step(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // Fragments.  v_mfma_f32_32x32x2_f32 wants A[row i = lane&31][k = lane>>5] in one register per lane.  A lane reads TWO
-    // adjacent channels of pixel k with one ds_read_b64 and uses them as row i of two different 32-row MFMA tiles: tile tm
-    // then holds channels 2*i + tm (a fixed permutation of the wave's 64 channels, undone in the epilogue's index
-    // arithmetic).  No transposition anywhere: staging is the plain 16-byte copy, the 32 lanes of a read cover 256
-    // contiguous bytes (conflict-free), and every fragment address is base + immediate.
+
     const int hi = lane >> 5;
     const int fa0 = hi * BM + wm * 64 + 2 * (lane & 31);
     const int fb0 = hi * BN + wn * 64 + 2 * (lane & 31);
     for (int ks = 0; ks < nks; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < nks) load_step(ks + 1);                 // reads table batch (ks+1)/TB, published by an earlier barrier
+        if (ks + 1 < nks) dma_step(ks + 1, buf ^ 1);          // table batch (ks+1)/TB was published by an earlier barrier
         const float *A = lds[buf] + fa0;
         const float *B = lds[buf] + WK * BM + fb0;
         float2 fa[3], fb[3];                                  // reads run two k-pairs ahead of the MFMAs that consume them
@@ -218,34 +211,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
                 fa[nxt] = *reinterpret_cast<const float2 *>(A + 2 * (kp + 2) * BM);
                 fb[nxt] = *reinterpret_cast<const float2 *>(B + 2 * (kp + 2) * BN);
             }
+            if (RELU) { fb[cur].x = fmaxf(fb[cur].x, 0.f); fb[cur].y = fmaxf(fb[cur].y, 0.f); }
+            cs.x += fa[cur].x;
+            cs.y += fa[cur].y;
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[1][1], 0, 0, 0);
-            // keep that order: (2 LDS reads for k-pair kp+2) then (4 MFMAs of k-pair kp)
+            // keep that order: the 2 LDS reads for k-pair kp+2, the few VALU, then the 4 MFMAs of k-pair kp
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, RELU ? 4 : 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         // next table batch: needed from iteration ks = TB*(j+1) - 1 on; its slot held batch j-1, last read at TB*j - 2
         if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
-        if (ks + 1 < nks) store_step(buf ^ 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed ...
+        __syncthreads();                                      // ... and so has everybody's; buffer `buf` is free again
     }
-    if (nks == 0) return;
-    if (do_cs) {                                              // the last barrier of the loop freed the staging LDS
-        float4 *red = reinterpret_cast<float4 *>(lds[0]);
-        constexpr int GA = (CA * 8 >= 256) ? 256 / CA : 8;    // pixel groups that carried A blocks (x NA passes, already summed)
-        if (a_active) red[pga0 * CA + ca] = cs;
-        __syncthreads();
-        if (tid < CA) {
-            float4 t = red[tid];
-#pragma unroll
-            for (int j = 1; j < GA; ++j) { const float4 u = red[j * CA + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-            const int c = m0 + 4 * tid;
-            if (c + 0 < p.Cout) atomicAdd(p.colsum + c + 0, t.x);
-            if (c + 1 < p.Cout) atomicAdd(p.colsum + c + 1, t.y);
-            if (c + 2 < p.Cout) atomicAdd(p.colsum + c + 2, t.z);
-            if (c + 3 < p.Cout) atomicAdd(p.colsum + c + 3, t.w);
+    if (p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0) {
+        cs.x += __shfl_xor(cs.x, 32);                         // the two k parities of the same channel pair
+        cs.y += __shfl_xor(cs.y, 32);
+        const int c = m0 + wm * 64 + 2 * (lane & 31);
+        if (lane < 32) {
+            if (c + 0 < p.Cout) atomicAdd(p.colsum + c + 0, cs.x);
+            if (c + 1 < p.Cout) atomicAdd(p.colsum + c + 1, cs.y);
         }
     }
 #pragma unroll
@@ -301,10 +290,13 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
     a.tiles = tiles;
     a.splits = (int)splits;
     const dim3 grid((unsigned)(tiles * (a.xcd_map ? (splits + 7) / 8 * 8 : splits)));
-    if (narrow_m)
-        hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (narrow_m) {
+        if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<1, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
