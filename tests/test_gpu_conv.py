@@ -87,6 +87,35 @@ def test_fprop_dgrad_wgrad(cv, dev, case):
     close(dweight, wr.grad)
 
 
+WGRAD_LONG_CASES = [  # cin, cout, k, stride, pad, N, H, W : tens of K slices, slices crossing image boundaries,
+    (64, 64, 3, 1, 1, 3, 67, 91),        # several pixel-table batches per slice; 64 x 256 tile
+    (64, 256, 1, 1, 0, 3, 61, 83),       # 256 x 64 tile
+    (128, 128, 3, 2, 1, 3, 131, 93),     # 128 x 128 tile, stride 2, odd sizes
+    (256, 72, 3, 1, 1, 2, 45, 80),       # ld of dY (72) is not the tile width; columns past Cout
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_LONG_CASES)
+def test_wgrad_long_k(cv, dev, case):
+    """Weight gradient and dY column sums over a long, split K range (the shapes the training step runs), against
+    torch's fp64 conv2d backward."""
+    cin, cout, k, stride, pad, N, H, W = case
+    x = rnd((N, cin, H, W), 11)
+    w = rnd((cout, cin, k, k), 12, (2.0 / (k * k * cin)) ** 0.5)
+    wr = w.double().requires_grad_(True)
+    y_ref = F.conv2d(x.double(), wr, None, stride, pad)
+    gy = rnd(tuple(y_ref.shape), 13)
+    (y_ref * gy.double()).sum().backward()
+    xg, gyg = nhwc(x).to(dev), nhwc(gy).to(dev)
+    wp = cv.pack_weights(w.to(dev), 0)
+    dw = torch.zeros_like(wp)
+    cs = torch.zeros(cout, device=dev)
+    cv.wgrad(gyg, xg, dw, cout, k, stride, pad, colsum=cs)
+    dweight, _, _ = cv.unpack_wgrad(dw, wp, tuple(w.shape))
+    close(dweight, wr.grad, tol=2e-5)
+    close(cs, gy.double().sum(dim=(0, 2, 3)), tol=2e-5)
+
+
 def test_stem_conv_bn_relu(cv, dev):
     """7x7 s2 p3 on a 3-channel NCHW image: NHWC4 staging, kw padded to 8, folded frozen BN + ReLU epilogue."""
     N, H, W = 2, 37, 45
