@@ -83,3 +83,36 @@ __device__ __forceinline__ void block_sum4(float v[4], float *red) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Buffer addressing and direct-to-LDS loads (conv_wgrad.hip, conv_igemm_tile.h).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (stride 0): base, num_records in bytes, the gfx9-family dword 3 for untyped 32-bit data.
+// A lane whose byte offset (voffset + soffset) is not below num_records reads 0.0 -- per dword, no memory access
+// (tools/probes/buffer_probe.hip); the kernels use that as their zero-fill.
+__device__ __forceinline__ v4i32 make_rsrc(const void *base, unsigned bytes) {
+    const uint64_t b = (uint64_t)base;
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// One direct-to-LDS buffer load: lane l's 16 bytes at (descriptor base + voff + soff) land at LDS byte address
+// lds_dst + 16*l; out-of-range lanes write zeros (tools/probes/lds_dma_probe.hip).  Issued as asm so that the compiler's
+// waitcnt bookkeeping does not see it -- seen, it is taken to alias every later ds_read and fenced with vmcnt(0) BEFORE
+// the MFMA phase it is meant to overlap.  The kernels count it themselves: rn_wait_dma() in front of the barrier that
+// publishes the buffer.  M0 (the LDS base of the instruction) is compiler-reserved: saved, set and restored inside
+// the one statement.
+__device__ __forceinline__ void dma16(v4i32 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void rn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}

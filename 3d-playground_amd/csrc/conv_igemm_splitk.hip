@@ -6,7 +6,7 @@
 // 112x112 crop detector): grid.y slices the K loop, each slice writes its raw partial tile to its own slab of a workspace
 // (plain stores: no atomics, no zero-fill, the same bits every run) and conv_splitk_finish_kernel adds the slabs in slice
 // order and applies the epilogue.
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, bool RELU = false>
 __global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_splitk_kernel(
     const rn_conv_desc d, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ ws, int steps_per_slice,
     int nks_total) {
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm
     // literal nullptrs make the (dead) epilogue a store through a constant null after inlining, and hipcc 7.2's
     // optimizer segfaults on that.
     float *slab = ws + (int64_t)blockIdx.y * M * d.Cout;
-    conv_igemm_tile<WM, WN, false, BK>(d, x, w, slab, w, w, x, x, x, (int)blockIdx.x, ks_lo, ks_hi, slab);
+    conv_igemm_tile<WM, WN, false, BK, RELU>(d, x, w, slab, w, w, x, x, x, (int)blockIdx.x, ks_lo, ks_hi, slab);
 }
 
 template <bool GENERAL>
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
 // Slices worth using for this problem (1 = do not split) -- few output tiles and a long K loop.
 static int splitk_slices(const rn_conv_desc *d) {
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-    const bool narrow = d->Cout <= 64;
+    const bool narrow = d->Cout <= 64 && !d->in_relu;      // the input-ReLU form exists for the 128 x 128 tile, K-step 32 only
     const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);
     const int K = d->kh * d->kw * d->Cin;
-    const int bk = (narrow || K <= 256) ? 16 : 32;
+    const int bk = d->in_relu ? 32 : ((narrow || K <= 256) ? 16 : 32);
     const int nks = ((K + 31) / 32 * 32) / bk;
     if (tiles >= 160 || nks < 16) return 1;
     int64_t s = (512 + tiles - 1) / tiles;                   // ~2 workgroups per CU in total
@@ -84,16 +84,17 @@ extern "C" int rn_conv_igemm_splitk(const rn_conv_desc *d, const float *x, const
     if (slices <= 1 || !workspace) return RN_EINVAL;         // ask rn_conv_splitk_workspace_bytes first
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     hipStream_t s = (hipStream_t)stream;
-    const bool narrow = d->Cout <= 64;
+    const bool narrow = d->Cout <= 64 && !d->in_relu;
     const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);
     const int K = d->kh * d->kw * d->Cin;
-    const int bk = (narrow || K <= 256) ? 16 : 32;
+    const int bk = d->in_relu ? 32 : ((narrow || K <= 256) ? 16 : 32);
     const int nks = ((K + 31) / 32 * 32) / bk;
     const int per = (nks + slices - 1) / slices;
     const int used = (nks + per - 1) / per;                  // slices that actually get K-steps
     const dim3 grid((unsigned)tiles, (unsigned)used), block(256);
     float *ws = reinterpret_cast<float *>(workspace);
-    if (narrow) hipLaunchKernelGGL((conv_igemm_splitk_kernel<4, 1, 16>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
+    if (d->in_relu) hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 32, true>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
+    else if (narrow) hipLaunchKernelGGL((conv_igemm_splitk_kernel<4, 1, 16>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
     else if (bk == 16) hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 16>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
     else hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 32>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
     RN_LAUNCH_CHECK();

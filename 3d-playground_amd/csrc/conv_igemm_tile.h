@@ -70,7 +70,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
         } \
     } while (0)
 
-template <int WM, int WN, bool GENERAL, int BK>
+// LDS image of a staged operand: [rows][BK floats], rows unpadded (a direct-to-LDS load fills 1 KiB linearly: 64/CPK whole
+// rows per wave instruction).  To keep the fragment reads conflict-free the 16-byte chunks of a row are permuted:
+// logical chunk c of row r sits at position c ^ swz(r).  The permutation is applied on the SOURCE address of the load
+// (the lane that fills position p of row r fetches chunk p ^ swz(r)) and again on the read.
+//   BK = 32 (128-byte rows): swz = (r & 7) ^ ((r >> 3) & 7);   BK = 16 (64-byte rows): swz = (r >> 2) & 3.
+// Checked against the servicing groups of ds_read_b128 (4 x 16 lanes: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the
+// same + 32): within a group the 16 lanes hit 16 distinct 16-byte bank groups.
+template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+    return BK == 32 ? ((row & 7) ^ ((row >> 3) & 7)) : ((row >> 2) & 3);
+}
+
+template <int WM, int WN, bool GENERAL, int BK, bool RELU = false>
 __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const float *__restrict__ x,
                                                 const float *__restrict__ w, float *__restrict__ y,
                                                 const float *__restrict__ scale, const float *__restrict__ shift,
@@ -78,15 +90,20 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                                                 const float *__restrict__ add2, const int tile, const int ks_lo = 0,
                                                 const int ks_hi = -1, float *__restrict__ partial = nullptr) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int LDK = BK + 4;                            // padded LDS row, floats (conflict-free b128 reads)
     constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
-    constexpr int RPS = 256 / CPK;                         // rows staged per pass
-    constexpr int AR = BM / RPS, BR = BN / RPS;            // rows of A / B each thread stages per K-step
-    static_assert(WM * WN == 4, "4 waves");
-    __shared__ float lds[2][(BM + BN) * LDK];
+    constexpr int RPI = 64 / CPK;                          // rows one wave instruction fills
+    constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;    // instructions per wave per K-step and operand
+    constexpr int STEP = (BM + BN) * BK;                   // floats per buffer: A rows, then B rows
+    constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
+    constexpr int EP = (BM * LDT > 2 * STEP) ? 2 : 1;      // epilogue passes when the output tile outgrows the staging LDS
+    constexpr int RP = BM / EP;                            // tile rows per pass
+    constexpr int LDSF = 2 * STEP > RP * LDT ? 2 * STEP : RP * LDT;
+    static_assert(WM * WN == 4 && RP % 64 == 0 && IA >= 1 && IB >= 1, "tile shape");
+    __shared__ float lds[LDSF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int ntn = (d.Cout + BN - 1) / BN;
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int HoWo = d.Ho * d.Wo;
@@ -96,45 +113,54 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     const int nks = (ks_hi < 0 ? Kpad / BK : ks_hi) - ks_lo;   // K-steps of this workgroup: all of them, or one split-K slice
     const int dmask = (1 << d.div_shift) - 1;
 
-    // ---- per-thread staging geometry: chunk column q (4 floats of K), rows srow + 32*i
-    const int q = tid % CPK, srow = tid / CPK;
-    const float *a_base[AR];
-    int a_h[AR], a_w[AR];
+    // ---- buffer descriptors (scalar).  Out-of-range offsets read as zero: that is the zero padding of the convolution,
+    // the rows past M and the weight rows past Cout -- no clamps, no masks, no selects on the data.
+    //   x: from the first image this tile touches (a tile spans few images; the launcher checks that their byte span
+    //      stays below 2 GiB, so offsets are plain int32 and 0x80000000 is always out of range);   w: the whole tensor.
+    const int n_first = (int)(m0 / HoWo);
+    const int64_t x_floats = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
+    const v4i32 rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride,
+                                 (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
+    const v4i32 rs_b = make_rsrc(w, (unsigned)((int64_t)d.Cout * Kpad * 4));
+
+    // ---- per-lane staging geometry: instruction j of this wave fills rows (wave*I + j)*RPI .. +RPI-1 of the operand;
+    // the lane fills position pos of row rsub of them, i.e. fetches logical chunk pos ^ swz(row)
+    const int pos = lane % CPK, rsub = lane / CPK;
+    int a_h[IA], a_w[IA], a_img[IA], a_c[IA];              // row's input origin, its image's byte offset, chunk's first channel
+    unsigned a_voff[IA];                                   // fast path: byte offset for the current tap (0x80000000 = zero row)
+    const int rel0 = m0 - n_first * HoWo;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int64_t m = (int64_t)m0 + srow + RPS * i;
-        if (m < M) {
-            const int n = (int)(m / HoWo);
-            const int rem = (int)(m - (int64_t)n * HoWo);
-            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
-            a_base[i] = x + (int64_t)n * d.x_batch_stride;
-            a_h[i] = oh * d.a + d.p;
-            a_w[i] = ow * d.a + d.p_w;
+    for (int j = 0; j < IA; ++j) {
+        const int row = (wave * IA + j) * RPI + rsub;
+        a_c[j] = 4 * (pos ^ lds_swz<BK>(row));
+        if ((int64_t)m0 + row < M) {
+            const unsigned rel = (unsigned)(rel0 + row);
+            const unsigned n = rel / (unsigned)HoWo;
+            const unsigned rem = rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)d.Wo, ow = rem - oh * (unsigned)d.Wo;
+            a_img[j] = (int)((int64_t)n * d.x_batch_stride * 4);
+            a_h[j] = (int)oh * d.a + d.p;
+            a_w[j] = (int)ow * d.a + d.p_w;
         } else {
-            a_base[i] = x;
-            a_h[i] = -(1 << 28);                           // fails every bounds test
-            a_w[i] = 0;
+            a_img[j] = 0;
+            a_h[j] = -(1 << 28);                           // fails every bounds test
+            a_w[j] = 0;
         }
+        a_voff[j] = 0x80000000u;
     }
-    const float *b_base[BR];
-    bool b_ok[BR];
+    unsigned b_voff[IB];                                   // fixed for the whole kernel; the K-step advance is scalar
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + srow + RPS * i;
-        b_ok[i] = n < d.Cout;
-        b_base[i] = w + (int64_t)(b_ok[i] ? n : 0) * Kpad + 4 * q;
+    for (int j = 0; j < IB; ++j) {
+        const int row = (wave * IB + j) * RPI + rsub;
+        const int n = n0 + row;
+        b_voff[j] = n < d.Cout ? (unsigned)((n * Kpad + 4 * (pos ^ lds_swz<BK>(row))) * 4) : 0x80000000u;
     }
 
-    // two register sets: the loads of K-step ks+2 are issued while step ks is multiplied and step ks+1 waits in the
-    // other set -- two K-steps (~4 us) of prefetch distance, enough for an HBM miss on inputs that fit neither L2 nor
-    // the Infinity Cache (the 135x240 and larger levels)
-    struct Stage { float4 ra[AR], rb[BR]; unsigned a_ok; };
-    Stage sA, sB;
     // Fast path (Cin a multiple of the K-step, i.e. every layer but the 4-channel stem and channel-padded head
-    // gradients): a K-step lies inside one filter tap, so the per-row input coordinate, bounds test and pixel offset
-    // are recomputed only when the tap changes (every Cin/BK steps); in between a step is one add per row.
+    // gradients): a K-step lies inside one filter tap, so the per-row input coordinate, bounds test and byte offset
+    // are recomputed only when the tap changes (every Cin/BK steps); in between a step costs the vector ALU nothing --
+    // the channel advance rides in the scalar offset of the load.
     const bool fast = (d.Cin % BK) == 0;
-    int a_pix[AR];                                         // fast path: in-image offset of the row's pixel for the tap, <0 = zero
     int f_r = 0, f_s = 0, f_c = 0;                         // tap (r,s) and channel offset of the NEXT step to load
     bool f_new = true;                                     // the first step computes its tap even when it starts mid-tap
     if (fast && ks_lo > 0) {
@@ -143,74 +169,44 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         f_r = tap0 / d.kw;
         f_s = tap0 - f_r * d.kw;
     }
-    auto load_step = [&](int ks_raw, Stage &S) {
-        // always executed (a step index past the end is clamped and its data never read): loads inside conditional
-        // blocks make the compiler's s_waitcnt accounting fall back to vmcnt(0)
-        const int ks = ks_lo + (ks_raw < nks ? ks_raw : nks - 1);
-        float4 (&ra)[AR] = S.ra;
-        float4 (&rb)[BR] = S.rb;
-        unsigned &a_ok = S.a_ok;
-        // weights first: their addresses need no arithmetic, and every load of the step is then in flight together
+    const unsigned lds0 = lds_addr(lds);
+    // Issue the loads of K-step ks (relative to ks_lo) into buffer buf.  The caller's barrier has freed that buffer.
+    auto dma_step = [&](int ks_rel, int buf) {
+        const int ks = ks_lo + ks_rel;
+        const unsigned A = lds0 + (unsigned)((buf * STEP + (wave_u * IA) * RPI * BK) * 4);
+        const unsigned B = lds0 + (unsigned)((buf * STEP + BM * BK + (wave_u * IB) * RPI * BK) * 4);
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const float4 *>(b_base[i] + ks * BK);   // row clamped above
+        for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (RPI * BK * 4), b_voff[j], (unsigned)(ks * BK * 4));
         if (fast) {
             if (f_c == 0 || f_new) {                       // new tap (wave-uniform)
                 f_new = false;
                 const bool tap_ok = f_r < d.kh;
                 const int hoff = f_r * d.b, woff = f_s * d.b;
 #pragma unroll
-                for (int i = 0; i < AR; ++i) {
-                    const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
+                for (int j = 0; j < IA; ++j) {
+                    const int nh = a_h[j] + hoff, nw = a_w[j] + woff;
                     const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
-                    const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
-                    a_pix[i] = ok ? (ih * d.Wi + iw) * d.Cin : -1;
+                    const bool ok = tap_ok & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
+                    a_voff[j] = ok ? (unsigned)(a_img[j] + ((ih * d.Wi + iw) * d.Cin + a_c[j]) * 4) : 0x80000000u;
                 }
             }
-            const int c = f_c + 4 * q;
-            a_ok = 0;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {                  // unconditional, from a clamped offset; zeroed in store_step
-                a_ok |= a_pix[i] >= 0 ? (1u << i) : 0u;
-                ra[i] = *reinterpret_cast<const float4 *>(a_base[i] + ((a_pix[i] >= 0 ? a_pix[i] : 0) + c));
-            }
+            for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (RPI * BK * 4), a_voff[j], (unsigned)(f_c * 4));
             f_c += BK;
             if (f_c >= d.Cin) { f_c = 0; if (++f_s == d.kw) { f_s = 0; ++f_r; } }
         } else {
-            const int k = ks * BK + 4 * q;
-            const int tap = k / d.Cin;
-            const int c0 = k - tap * d.Cin;
-            const int r = tap / d.kw, s = tap - r * d.kw;
-            const bool tap_ok = r < d.kh;
-            const int hoff = r * d.b, woff = s * d.b;
-            a_ok = 0;
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const int nh = a_h[i] + hoff, nw = a_w[i] + woff;
+            for (int j = 0; j < IA; ++j) {
+                const int k = ks * BK + a_c[j];
+                const int tap = k / d.Cin;
+                const int c0 = k - tap * d.Cin;
+                const int r = tap / d.kw, s_ = tap - r * d.kw;
+                const int nh = a_h[j] + r * d.b, nw = a_w[j] + s_ * d.b;
                 const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
-                const bool ok = tap_ok && ((nh | nw) >= 0) && (((nh | nw) & dmask) == 0) && ih < d.Hi && iw < d.Wi;
-                // offsets inside one image fit 32 bits (x_batch_stride < 2^31 floats is checked by the launcher)
-                a_ok |= ok ? (1u << i) : 0u;
-                ra[i] = *reinterpret_cast<const float4 *>(a_base[i] + (ok ? (ih * d.Wi + iw) * d.Cin + c0 : 0));
+                const bool ok = (r < d.kh) & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
+                dma16(rs_a, A + j * (RPI * BK * 4), ok ? (unsigned)(a_img[j] + ((ih * d.Wi + iw) * d.Cin + c0) * 4) : 0x80000000u, 0u);
             }
         }
-    };
-    // Nothing in load_step may depend on a loaded value: a select, a clamp or a branch right behind a global load makes
-    // the compiler wait for it on the spot -- one memory round trip per load instead of one per K-step.  Padding /
-    // out-of-range rows are zeroed and the input ReLU applied here, on the way into LDS, after the MFMAs.
-    auto store_step = [&](int buf, Stage &S) {
-        float *A = lds[buf], *B = lds[buf] + BM * LDK;
-        float4 (&ra)[AR] = S.ra;
-        float4 (&rb)[BR] = S.rb;
-        const unsigned a_ok = S.a_ok;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            float4 v = (a_ok & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4 *>(A + (srow + RPS * i) * LDK + 4 * q) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<float4 *>(B + (srow + RPS * i) * LDK + 4 * q) = b_ok[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     f32x16 acc[2][2];
@@ -221,21 +217,29 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_step(0, sA);
-    store_step(0, sA);
-    __syncthreads();
-    load_step(1, sA);
-
-    const int frag = (lane & 31) * LDK + (lane >> 5) * 4;   // [row = lane&31][k = 4*(lane>>5)]
-    auto multiply = [&](int buf) {
-        const float *A = lds[buf] + (wm * 64) * LDK + frag;
-        const float *B = lds[buf] + BM * LDK + (wn * 64) * LDK + frag;
+    // ---- fragment addresses (floats, within a buffer): row = lane & 31 of each 32-row MFMA tile, logical chunk
+    // 2*st + (lane >> 5) of K-sub-step st, at its swizzled position
+    int fa[2][BK / 8], fb[2][BK / 8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int st = 0; st < BK / 8; ++st) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(A + st * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LDK + st * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(B + st * 8);
-            const float4 b1 = *reinterpret_cast<const float4 *>(B + 32 * LDK + st * 8);
+            const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+            fa[t][st] = ra * BK + 4 * ((2 * st + (lane >> 5)) ^ lds_swz<BK>(ra));
+            fb[t][st] = BM * BK + rb * BK + 4 * ((2 * st + (lane >> 5)) ^ lds_swz<BK>(rb));
+        }
+    auto multiply = [&](int buf) {
+        const float *S = lds + buf * STEP;
+#pragma unroll
+        for (int st = 0; st < BK / 8; ++st) {
+            float4 a0 = *reinterpret_cast<const float4 *>(S + fa[0][st]);
+            float4 a1 = *reinterpret_cast<const float4 *>(S + fa[1][st]);
+            const float4 b0 = *reinterpret_cast<const float4 *>(S + fb[0][st]);
+            const float4 b1 = *reinterpret_cast<const float4 *>(S + fb[1][st]);
+            if (RELU) {                                     // input ReLU, on the fragments (inside the MFMA shadow)
+                a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
+                a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
+            }
             const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
             const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
 #pragma unroll
@@ -247,37 +251,31 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
         }
     };
-    if constexpr (BK >= 32) {
-        for (int ks = 0; ks < nks; ks += 2) {
-            load_step(ks + 2, sB);
-            multiply(0);
-            store_step(1, sA);                              // step ks+1 (past the end: clamped data into the idle buffer)
-            __syncthreads();
-            if (ks + 1 >= nks) break;
-            load_step(ks + 3, sA);
-            multiply(1);
-            store_step(0, sB);
-            __syncthreads();
-        }
-    } else {
-        // K-step 16 (small K, three workgroups per CU): one register set -- a second one would not fit 168 VGPRs
-        for (int ks = 0; ks < nks; ++ks) {
-            multiply(ks & 1);
-            store_step((ks & 1) ^ 1, sA);
-            __syncthreads();
-            load_step(ks + 2, sA);
-        }
+
+    // ---- K loop: the loads of step ks+1 go straight into the idle LDS buffer while step ks is multiplied; one barrier
+    // per K-step.  (Unrolled by two so that buffer addresses are immediates.)
+    if (nks > 0) {
+        dma_step(0, 0);
+        rn_wait_dma();
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nks; ks += 2) {
+        if (ks + 1 < nks) dma_step(ks + 1, 1);
+        multiply(0);
+        rn_wait_dma();                                      // this wave's loads have landed ...
+        __syncthreads();                                    // ... and everybody's; buffer 0 is free
+        if (ks + 1 >= nks) break;
+        if (ks + 2 < nks) dma_step(ks + 2, 0);
+        multiply(1);
+        rn_wait_dma();
+        __syncthreads();
     }
 
     // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add (+ add2); act; [mask after]
     // The accumulator tile goes through LDS (the staging buffers are free after the last barrier) so that global
     // memory sees 16-byte accesses, 32 consecutive lanes on one 512-byte row segment: out, add and mask all move as
     // float4.  Accumulator element e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile.
-    constexpr int LDT = BN + 4;
-    constexpr int EP = (BM * LDT > 2 * (BM + BN) * LDK) ? 2 : 1;   // passes when the tile outgrows the staging LDS
-    constexpr int RP = BM / EP;                                    // tile rows per pass
-    static_assert(RP * LDT <= 2 * (BM + BN) * LDK && RP % 64 == 0, "output tile pass must fit the staging LDS");
-    float *T = &lds[0][0];
+    float *T = lds;
     constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 16-byte chunks per tile row, rows per pass of stores
     const int c4 = tid % CPR;
     const int col = n0 + 4 * c4;
@@ -327,6 +325,12 @@ static inline int check_desc(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 4 || (d->Cin & 3)) return RN_EINVAL;                     // 16-byte chunks must not straddle taps
     if ((int64_t)d->Hi * d->Wi * d->Cin > 0x7fffffffLL) return RN_EINVAL; // in-image offsets are 32-bit
+    {   // buffer addressing: the images one 256-row tile can touch, and the packed weights, within 2 GiB each
+        const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 255 / HoWo + 2;
+        if (d->x_batch_stride < 0 || (span - 1) * d->x_batch_stride * 4 + (int64_t)d->Hi * d->Wi * d->Cin * 4 > 0x7fffffffLL) return RN_EINVAL;
+        const int64_t Kpad = ((int64_t)d->kh * d->kw * d->Cin + 31) / 32 * 32;
+        if (d->Cout * Kpad * 4 > 0x7fffffffLL || (int64_t)d->N * HoWo > 0x7fffffffLL) return RN_EINVAL;
+    }
     if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
     if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
     if (d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;

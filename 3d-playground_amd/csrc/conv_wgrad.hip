@@ -35,32 +35,6 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-
-// Raw buffer descriptor (stride 0): base, num_records in bytes, the gfx9-family dword 3 for untyped 32-bit data.
-__device__ __forceinline__ v4i32 make_rsrc(const void *base, unsigned bytes) {
-    const uint64_t b = (uint64_t)base;
-    v4i32 r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xFFFFu));
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-
-// One direct-to-LDS buffer load: lane l's 16 bytes at (descriptor base + voff + soff) land at LDS byte address
-// lds_dst + 16*l; out-of-range lanes write zeros.  Issued as asm so that the compiler's waitcnt bookkeeping does not see
-// it -- seen, it is taken to alias every later ds_read and fenced with vmcnt(0) BEFORE the MFMA phase it is meant to
-// overlap.  The kernel counts it itself: one "s_waitcnt vmcnt(0)" in front of the barrier that publishes the buffer.
-// M0 (the LDS base of the instruction) is compiler-reserved: saved, set and restored inside the one statement.
-__device__ __forceinline__ void dma16(v4i32 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
-}
 #define WK_MAX 32                // pixels per K-step: 32 or 16 (the kernel's WK parameter)
 
 struct WgradArgs {
@@ -188,7 +162,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     fill_batch(0);
     __syncthreads();
     dma_step(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rn_wait_dma();
     __syncthreads();
 
     const int hi = lane >> 5;
@@ -226,7 +200,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
         }
         // next table batch: needed from iteration ks = TB*(j+1) - 1 on; its slot held batch j-1, last read at TB*j - 2
         if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed ...
+        rn_wait_dma();      // this wave's DMA has landed ...
         __syncthreads();                                      // ... and so has everybody's; buffer `buf` is free again
     }
     if (p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0) {
