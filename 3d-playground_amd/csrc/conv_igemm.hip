@@ -11,7 +11,7 @@
 // GEMM view:  M = N*Ho*Wo output pixels,  N = Cout,  K = kh*kw*Cin.
 // Layout:     activations NHWC fp32 (channels contiguous: 16-byte loads along K, 128-byte stores along Cout);
 //             weights packed [Cout][kh][kw][Cin] (K contiguous per output channel) by pack kernels.
-// Tile:       workgroup 64*WM x 64*WN outputs, K-step 32 or 16; 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32
+// Tile:       workgroup 64*WM x 64*WN outputs, K-step 16; 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32
 //             accumulators (64 VGPRs).  Both operands are staged as K-contiguous rows in LDS, and they get there by
 //             direct-to-LDS buffer loads (16 bytes per lane, 1 KiB of whole rows per wave instruction): no staging
 //             registers, no ds_write, no store phase.  Rows are unpadded (the load fills LDS linearly), so the 16-byte
@@ -29,8 +29,8 @@
 // Epilogue:   the 128x128 (256x64) accumulator tile is staged through the now idle LDS and leaves as float4 rows:
 //             out, residual / gradient addend and ReLU mask are all 16-byte coalesced accesses.
 //
-// Roofline: MFMA (fp32 157.3 TF).  Per K-step of 32 a wave issues 64 MFMAs (4096 cycles) against 16 ds_read_b128 and
-// 8 direct-to-LDS loads.  Small-K layers (1x1, Cin 64..128) are HBM-bound instead:
+// Roofline: MFMA (fp32 157.3 TF).  Per K-step of 16 a wave issues 32 MFMAs (2048 cycles) against 8 ds_read_b128 and
+// 4 direct-to-LDS loads.  Small-K layers (1x1, Cin 64..128) are HBM-bound instead:
 // e.g. 1x1 64->256 at 270x480 moves 1.33 GB per 34 GFLOP.
 #include "conv_igemm_tile.h"
 
@@ -83,10 +83,8 @@ extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_pack
     }
     const dim3 grid((unsigned)prev), block(256);
     hipStream_t s = (hipStream_t)stream;
-    const bool bk16 = d0.kh * d0.kw * d0.Cin <= 256;
     if (narrow) hipLaunchKernelGGL((conv_igemm_grouped_kernel<4, 1, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
-    else if (bk16) hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
-    else hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 32>), grid, block, 0, s, *g, w_packed, scale, shift);
+    else hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -110,17 +108,15 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     const dim3 grid((unsigned)tiles), block(256);
 #define RN_LAUNCH_IGEMM(WM, WN, G, K) \
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G, K>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
-    // K-step 16 keeps 3 workgroups per CU: measured better only when the K loop is a handful of steps long
-    static const int bk16_env = getenv("RN_IGEMM_BK16") ? atoi(getenv("RN_IGEMM_BK16")) : -1;
-    const int bk16 = bk16_env >= 0 ? bk16_env : (d->kh * d->kw * d->Cin <= 256);
+    // K-step 16 (34-41 KB of LDS, three workgroups per CU for the 128 x 128 tile) everywhere: with the operands arriving
+    // by direct-to-LDS loads it ties or beats K-step 32 at two workgroups per CU on every layer shape (measured), and
+    // four per CU does not fit the registers (it spills into the K loop).
     if (d->in_relu) {
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, true, 32, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
+        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, true, 16, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
     } else if (narrow) {
         if (dense) RN_LAUNCH_IGEMM(4, 1, false, 16); else RN_LAUNCH_IGEMM(4, 1, true, 16);
-    } else if (bk16) {
-        if (dense) RN_LAUNCH_IGEMM(2, 2, false, 16); else RN_LAUNCH_IGEMM(2, 2, true, 16);
     } else {
-        if (dense) RN_LAUNCH_IGEMM(2, 2, false, 32); else RN_LAUNCH_IGEMM(2, 2, true, 32);
+        if (dense) RN_LAUNCH_IGEMM(2, 2, false, 16); else RN_LAUNCH_IGEMM(2, 2, true, 16);
     }
 #undef RN_LAUNCH_IGEMM
     RN_LAUNCH_CHECK();

@@ -54,14 +54,14 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
 // Slices worth using for this problem (1 = do not split) -- few output tiles and a long K loop.
 static int splitk_slices(const rn_conv_desc *d) {
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-    const bool narrow = d->Cout <= 64 && !d->in_relu;      // the input-ReLU form exists for the 128 x 128 tile, K-step 32 only
+    const bool narrow = d->Cout <= 64 && !d->in_relu;      // the input-ReLU form exists for the 128 x 128 tile only
     const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);
     const int K = d->kh * d->kw * d->Cin;
-    const int bk = d->in_relu ? 32 : ((narrow || K <= 256) ? 16 : 32);
+    const int bk = 16;
     const int nks = ((K + 31) / 32 * 32) / bk;
-    if (tiles >= 160 || nks < 16) return 1;
+    if (tiles >= 160 || nks < 32) return 1;                  // K < 512: not worth a second pass over the output
     int64_t s = (512 + tiles - 1) / tiles;                   // ~2 workgroups per CU in total
-    if (s > nks / 8) s = nks / 8;                            // at least 8 K-steps per slice
+    if (s > nks / 16) s = nks / 16;                          // at least 16 K-steps (256 of K) per slice
     if (s > 32) s = 32;
     return s < 2 ? 1 : (int)s;
 }
@@ -87,16 +87,15 @@ extern "C" int rn_conv_igemm_splitk(const rn_conv_desc *d, const float *x, const
     const bool narrow = d->Cout <= 64 && !d->in_relu;
     const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);
     const int K = d->kh * d->kw * d->Cin;
-    const int bk = d->in_relu ? 32 : ((narrow || K <= 256) ? 16 : 32);
+    const int bk = 16;
     const int nks = ((K + 31) / 32 * 32) / bk;
     const int per = (nks + slices - 1) / slices;
     const int used = (nks + per - 1) / per;                  // slices that actually get K-steps
     const dim3 grid((unsigned)tiles, (unsigned)used), block(256);
     float *ws = reinterpret_cast<float *>(workspace);
-    if (d->in_relu) hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 32, true>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
+    if (d->in_relu) hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 16, true>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
     else if (narrow) hipLaunchKernelGGL((conv_igemm_splitk_kernel<4, 1, 16>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
-    else if (bk == 16) hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 16>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
-    else hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 32>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
+    else hipLaunchKernelGGL((conv_igemm_splitk_kernel<2, 2, 16>), grid, block, 0, s, *d, x, w_packed, ws, per, nks);
     RN_LAUNCH_CHECK();
     const bool dense = d->os == 1 && d->oo_h == 0 && d->oo_w == 0 && d->Hy == d->Ho && d->Wy == d->Wo &&
                        d->y_batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->add_mode != 2 && d->add2_mode == 0 &&
