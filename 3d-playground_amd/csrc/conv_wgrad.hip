@@ -32,6 +32,8 @@
 // shadow) and finish with one atomic per channel.
 //
 // Roofline: MFMA (fp32 157.3 TF).
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -127,27 +129,37 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
         }
         pixtab[j & 1][tid] = e;
     };
-    // Issue the DMA of K-step ks into buffer `buf`.  The caller's barrier has made sure nobody still reads it.
+    // The X half's offsets are software-pipelined one K-step ahead of their loads: the table entries of step ks+2 are
+    // read right after the loads of step ks+1 went out, and turned into offsets half-way through the MFMA stream of step
+    // ks (inside its shadow).  So the load phase at the top of an iteration is eight instructions with ready operands --
+    // no LDS round trip, no VALU.  (Measured on the 256-channel 3x3 layers: the read -> test -> load chain at the top
+    // cost 4-5 %, the table fill 2.5 %, unconditional column-sum adds 3 %.)
+    unsigned b_voff[IB];                                     // offsets of the next step to issue
+    int4 e[IB];                                              // table entries of the step after that
+    auto table_read = [&](int ks) {
+        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK + b_px0];
+#pragma unroll
+        for (int j = 0; j < IB; ++j) e[j] = tab[j * PB];
+    };
+    auto make_offsets = [&]() {
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+            const bool ok = ((unsigned)(e[j].y + fr_t) < (unsigned)p.Hi) & ((unsigned)(e[j].z + fs) < (unsigned)p.Wi);
+            b_voff[j] = ok ? (unsigned)(e[j].x + tap_off) : 0xFFFFFFFFu;
+        }
+    };
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds0 = lds_addr(&lds[0][0]);
+    // Issue the loads of K-step ks into buffer `buf` (b_voff holds that step's offsets).  The caller's barrier has made
+    // sure nobody still reads the buffer.
     auto dma_step = [&](int ks, int buf) {
         const unsigned A = lds0 + (unsigned)((buf * WK * (BM + BN) + wave_u * (IA * PA) * BM) * 4);   // this wave's first row
         const unsigned B = lds0 + (unsigned)((buf * WK * (BM + BN) + WK * BM + wave_u * (IB * PB) * BN) * 4);
         const unsigned so = (unsigned)ks * (unsigned)(WK * 4) * (unsigned)p.ldy;   // scalar: the K-step advance
 #pragma unroll
         for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (PA * BM * 4), a_voff, so + j * a_step);
-        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK + b_px0];
-        int4 e[IB];
 #pragma unroll
-        for (int j = 0; j < IB; ++j) e[j] = tab[j * PB];
-#pragma unroll
-        for (int j = 0; j < IB; ++j)                          // all entries first, in one LDS round trip: without this the
-            asm volatile("" : "+v"(e[j].x), "+v"(e[j].y), "+v"(e[j].z));   // compiler sinks each offset read under its test
-#pragma unroll
-        for (int j = 0; j < IB; ++j) {
-            const bool ok = ((unsigned)(e[j].y + fr_t) < (unsigned)p.Hi) & ((unsigned)(e[j].z + fs) < (unsigned)p.Wi);
-            dma16(rs_b, B + j * (PB * BN * 4), ok ? (unsigned)(e[j].x + tap_off) : 0xFFFFFFFFu, 0u);
-        }
+        for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (PB * BN * 4), b_voff[j], 0u);
     };
 
     f32x16 acc[2][2];
@@ -156,54 +168,65 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e_ = 0; e_ < 16; ++e_) acc[i][j][e_] = 0.f;
     float2 cs = make_float2(0.f, 0.f);                       // column sums of this lane's two channels (its k parity)
 
     fill_batch(0);
     __syncthreads();
+    table_read(0);
+    make_offsets();
     dma_step(0, 0);
+    table_read(nks > 1 ? 1 : 0);
+    make_offsets();                                          // offsets of step 1
     rn_wait_dma();
     __syncthreads();
 
     const int hi = lane >> 5;
     const int fa0 = hi * BM + wm * 64 + 2 * (lane & 31);
     const int fb0 = hi * BN + wn * 64 + 2 * (lane & 31);
-    for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) dma_step(ks + 1, buf ^ 1);          // table batch (ks+1)/TB was published by an earlier barrier
-        const float *A = lds[buf] + fa0;
-        const float *B = lds[buf] + WK * BM + fb0;
-        float2 fa[3], fb[3];                                  // reads run two k-pairs ahead of the MFMAs that consume them
+    // Only the waves that own distinct channels of N-tile 0 add up column sums: two copies of the loop, chosen once.
+    const bool do_cs = p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0;
+    auto k_loop = [&](auto cs_tag) {
+        constexpr bool CS = decltype(cs_tag)::value;
+        for (int ks = 0; ks < nks; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < nks) dma_step(ks + 1, buf ^ 1);
+            table_read(ks + 2 < nks ? ks + 2 : nks - 1);      // its batch was published by an earlier barrier (see below)
+            const float *A = lds[buf] + fa0;
+            const float *B = lds[buf] + WK * BM + fb0;
+            float2 fa[3], fb[3];                              // reads run two k-pairs ahead of the MFMAs that consume them
 #pragma unroll
-        for (int pre = 0; pre < 2; ++pre) {
-            fa[pre] = *reinterpret_cast<const float2 *>(A + 2 * pre * BM);
-            fb[pre] = *reinterpret_cast<const float2 *>(B + 2 * pre * BN);
-        }
-#pragma unroll
-        for (int kp = 0; kp < WK / 2; ++kp) {
-            const int cur = kp % 3, nxt = (kp + 2) % 3;
-            if (kp + 2 < WK / 2) {
-                fa[nxt] = *reinterpret_cast<const float2 *>(A + 2 * (kp + 2) * BM);
-                fb[nxt] = *reinterpret_cast<const float2 *>(B + 2 * (kp + 2) * BN);
+            for (int pre = 0; pre < 2; ++pre) {
+                fa[pre] = *reinterpret_cast<const float2 *>(A + 2 * pre * BM);
+                fb[pre] = *reinterpret_cast<const float2 *>(B + 2 * pre * BN);
             }
-            if (RELU) { fb[cur].x = fmaxf(fb[cur].x, 0.f); fb[cur].y = fmaxf(fb[cur].y, 0.f); }
-            cs.x += fa[cur].x;
-            cs.y += fa[cur].y;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[1][1], 0, 0, 0);
-            // keep that order: the 2 LDS reads for k-pair kp+2, the few VALU, then the 4 MFMAs of k-pair kp
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, RELU ? 4 : 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+            for (int kp = 0; kp < WK / 2; ++kp) {
+                const int cur = kp % 3, nxt = (kp + 2) % 3;
+                if (kp + 2 < WK / 2) {
+                    fa[nxt] = *reinterpret_cast<const float2 *>(A + 2 * (kp + 2) * BM);
+                    fb[nxt] = *reinterpret_cast<const float2 *>(B + 2 * (kp + 2) * BN);
+                }
+                if (RELU) { fb[cur].x = fmaxf(fb[cur].x, 0.f); fb[cur].y = fmaxf(fb[cur].y, 0.f); }
+                if (CS) { cs.x += fa[cur].x; cs.y += fa[cur].y; }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[1][1], 0, 0, 0);
+                if (kp == WK / 4 - 1) {
+                    make_offsets();                           // step ks+2, from the entries read above
+                    // next table batch: first read (two steps ahead) at iteration TB*(j+1) - 2; its slot held batch j-1,
+                    // last read at iteration TB*j - 3
+                    if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
+                }
+            }
+            rn_wait_dma();                                    // this wave's loads have landed ...
+            __syncthreads();                                  // ... and so have everybody's; buffer `buf` is free again
         }
-        // next table batch: needed from iteration ks = TB*(j+1) - 1 on; its slot held batch j-1, last read at TB*j - 2
-        if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
-        rn_wait_dma();      // this wave's DMA has landed ...
-        __syncthreads();                                      // ... and so has everybody's; buffer `buf` is free again
-    }
-    if (p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0) {
+    };
+    if (do_cs) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    if (do_cs) {
         cs.x += __shfl_xor(cs.x, 32);                         // the two k parities of the same channel pair
         cs.y += __shfl_xor(cs.y, 32);
         const int c = m0 + wm * 64 + 2 * (lane & 31);
