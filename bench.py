@@ -102,8 +102,9 @@ def pmc_traffic(kind):
     """Average HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command
     (tools/collect_traffic.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).
     PMC counters cannot be read from inside the process, so the number is the last collected one, or None."""
-    prefix = {"conv_igemm_2x2": "conv_igemm_kernel<2, 2", "conv_igemm_4x1": "conv_igemm_kernel<4, 1",
-              "conv_wgrad": "conv_wgrad_kernel"}.get(kind)
+    prefix = {"conv_igemm_2x2": ("conv_igemm_kernel<2, 2", "conv_igemm_grouped_kernel<2, 2"),
+              "conv_igemm_4x1": ("conv_igemm_kernel<4, 1", "conv_igemm_grouped_kernel<4, 1"),
+              "conv_wgrad": ("conv_wgrad_kernel",)}.get(kind)
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if prefix is None or not os.path.exists(path):
         return None

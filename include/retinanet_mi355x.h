@@ -221,6 +221,10 @@ int rn_frame_ingest(const uint8_t *frames, int B, int H, int W, int swap_rb, flo
  * (oh>>1, ow>>1) -- the FPN nearest-upsample + add, cropped to the output (D/model.py:88-108).
  * batch strides are in floats; y_batch_stride lets a head write straight into its slice of the concatenated
  * [B, A, n] tensor (the reference's permute+view+cat, D/model.py:155-157, 302-304).
+ *
+ * Size limits (RN_EINVAL otherwise): the operands are read through 32-bit buffer offsets, so one input image
+ * (Hi*Wi*Cin floats) plus the images a 256-pixel run of outputs can span ((255 / (Ho*Wo) + 1) * x_batch_stride) must
+ * stay below 2 GiB, likewise the packed weights, and N*Ho*Wo below 2^31.  x, w_packed need 4-byte alignment only.
  */
 typedef struct rn_conv_desc {
     int N, Hi, Wi, Cin;            /* input  [N,Hi,Wi,Cin]; Cin % 4 == 0 */
@@ -261,7 +265,7 @@ int rn_conv_igemm_splitk(const rn_conv_desc *d, const float *x, const float *w_p
  * geometry (N, Hi, Wi, Ho, Wo, output map, batch strides) run as ONE grid -- the five pyramid levels of a head tower
  * (D/model.py:302-304 loops over them): the small levels no longer occupy a fraction of the GPU for a full
  * workgroup round each.  tile_end[i] = exclusive prefix sum of the problems' tile counts (tile = 128x128 outputs,
- * 256x64 when Cout <= 64); add2 is not available in grouped launches. */
+ * 256x64 when Cout <= 64); add2 and in_relu are not available in grouped launches (RN_EINVAL). */
 #define RN_MAX_GROUP 5
 typedef struct rn_conv_group {
     int n;
@@ -280,7 +284,9 @@ int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_packed, const f
  * weights; heads accumulate their five pyramid levels into one buffer).  dy: [N,Ho,Wo,Cout] with channel
  * stride ldy >= Cout (a padded copy is allowed), x: [N,Hi,Wi,Cin]; in_relu applies max(x,0) on load.
  * colsum (may be NULL): colsum[co] += sum over pixels of dy[.,co] -- the bias / batch-norm-beta gradient, fused
- * because this kernel streams dy anyway. */
+ * because this kernel streams dy anyway.
+ * Size limit: the K range is cut into slices whose dy bytes and span of input images each stay below 2 GiB (the
+ * slices are made finer if need be); RN_EINVAL only if a single input image exceeds that. */
 int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
                   int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
 

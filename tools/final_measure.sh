@@ -1,0 +1,21 @@
+#!/bin/bash
+# The measurement set behind DESIGN.md section 6 / profiles/README.md, in one call on the GPU box:
+#   bash tools/final_measure.sh        -> gpurun_out/final/*   (copy what is to be judged into profiles/)
+# Steps are chained: a failing step stops the script (no GPU step is started after a failed one).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/final
+rm -rf "$O" && mkdir -p "$O"
+timeout -k 10 900 python3 -m pytest tests -q -m gpu > "$O/gpu_tests.log" 2>&1
+echo "tests done" && tail -1 "$O/gpu_tests.log"
+timeout -k 10 600 python3 bench.py --steps 5 --warmup 2 > "$O/bench.log" 2>&1
+echo "bench done"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$O/bench_under_rocprof.log" 2>&1
+cp "$(ls $O/stats/*/*kernel_stats.csv | head -1)" "$O/kernel_stats.csv"
+echo "stats done"
+bash tools/collect_traffic.sh
+python3 tools/summarize_traffic.py gpurun_out/traffic > "$O/pmc_traffic.json"
+echo "traffic done"
+timeout -k 10 300 python3 tools/bench_conv.py > "$O/conv_microbench.txt" 2>&1
+bash tools/pmc_conv.sh > "$O/pmc_conv.txt" 2>&1
+echo "all done"
