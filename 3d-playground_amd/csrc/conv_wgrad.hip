@@ -17,11 +17,13 @@
 // Why it matters: timing the kernel with pieces knocked out showed that whatever a wave does outside its MFMA stream is
 // paid in full -- it is NOT hidden behind the partner wave's MFMAs -- so the staging work had to go, not move.
 //
-// Fragments: v_mfma_f32_32x32x2_f32 wants A[row i = lane&31][k = lane>>5] in one register per lane.  A lane reads TWO
-// adjacent channels of pixel k with one ds_read_b64 and uses them as row i of two different 32-row MFMA tiles (tile tm
-// holds channels 2*i + tm: a fixed permutation of the wave's 64 channels, undone by the epilogue's index arithmetic).
-// The 32 lanes of a read cover 256 contiguous bytes (conflict-free), every fragment address is base + immediate,
-// 32 ds_read_b64 against 64 MFMAs (64 cycles each) per wave per K-step.
+// Fragments: v_mfma_f32_32x32x2_f32 wants A[row i = lane&31][k = lane>>5] in one register per lane.  For dY a lane reads
+// TWO adjacent channels of pixel k with one ds_read_b64 and uses them as row i of two different 32-row MFMA tiles (tile
+// tm holds channels 2*i + tm: a fixed permutation of the wave's 64 channels, undone by the epilogue's index arithmetic).
+// For X it reads channels j and j + 32 with one ds_read2_b32, so that tile tn holds 32 CONTIGUOUS columns and an atomic
+// instruction of the epilogue covers two full 128-byte row segments (the full-rate shape; stride-2 columns touched
+// twice the cache lines and cost the short-K 1x1 layers up to 18 %).  Both reads are conflict-free, every fragment
+// address is base + immediate; per wave and 16-pixel K-step 16 LDS reads against 32 MFMAs (64 cycles each).
 //
 // K is split over the grid; partial tiles are added with fp32 atomics into a buffer the caller zeroes -- the five
 // pyramid levels of a shared head accumulate into the same buffer.  All tiles of one K-slice run on the same XCD so
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
 
     const int hi = lane >> 5;
     const int fa0 = hi * BM + wm * 64 + 2 * (lane & 31);
-    const int fb0 = hi * BN + wn * 64 + 2 * (lane & 31);
+    const int fb0 = hi * BN + wn * 64 + (lane & 31);          // B: channels j and j + 32 (see the epilogue)
     // Only the waves that own distinct channels of N-tile 0 add up column sums: two copies of the loop, chosen once.
     const bool do_cs = p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0;
     auto k_loop = [&](auto cs_tag) {
@@ -198,14 +200,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
 #pragma unroll
             for (int pre = 0; pre < 2; ++pre) {
                 fa[pre] = *reinterpret_cast<const float2 *>(A + 2 * pre * BM);
-                fb[pre] = *reinterpret_cast<const float2 *>(B + 2 * pre * BN);
+                fb[pre] = make_float2(B[2 * pre * BN], B[2 * pre * BN + 32]);
             }
 #pragma unroll
             for (int kp = 0; kp < WK / 2; ++kp) {
                 const int cur = kp % 3, nxt = (kp + 2) % 3;
                 if (kp + 2 < WK / 2) {
                     fa[nxt] = *reinterpret_cast<const float2 *>(A + 2 * (kp + 2) * BM);
-                    fb[nxt] = *reinterpret_cast<const float2 *>(B + 2 * (kp + 2) * BN);
+                    fb[nxt] = make_float2(B[2 * (kp + 2) * BN], B[2 * (kp + 2) * BN + 32]);   // one ds_read2_b32
                 }
                 if (RELU) { fb[cur].x = fmaxf(fb[cur].x, 0.f); fb[cur].y = fmaxf(fb[cur].y, 0.f); }
                 if (CS) { cs.x += fa[cur].x; cs.y += fa[cur].y; }
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wn * 64 + 2 * (lane & 31) + tn;          // tile tn holds columns 2*j + tn (see the fragments)
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);         // contiguous: an atomic instruction covers two full 128-byte row segments
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) + tm;   // tile tm: channels 2*i + tm
