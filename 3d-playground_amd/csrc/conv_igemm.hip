@@ -11,7 +11,7 @@
 // GEMM view:  M = N*Ho*Wo output pixels,  N = Cout,  K = kh*kw*Cin.
 // Layout:     activations NHWC fp32 (channels contiguous: 16-byte loads along K, 128-byte stores along Cout);
 //             weights packed [Cout][kh][kw][Cin] (K contiguous per output channel) by pack kernels.
-// Tile:       workgroup 64*WM x 64*WN outputs, K-step 16; 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32
+// Tile:       workgroup 64*WM x 64*WN outputs, K-step 16, four workgroups per CU; 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32
 //             accumulators (64 VGPRs).  Both operands are staged as K-contiguous rows in LDS, and they get there by
 //             direct-to-LDS buffer loads (16 bytes per lane, 1 KiB of whole rows per wave instruction): no staging
 //             registers, no ds_write, no store phase.  Rows are unpadded (the load fills LDS linearly), so the 16-byte
@@ -35,7 +35,7 @@
 #include "conv_igemm_tile.h"
 
 template <int WM, int WN, bool GENERAL, int BK, bool RELU = false>
-__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
+__global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                             const float *__restrict__ w, float *__restrict__ y,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                                             const float *__restrict__ add, const float *__restrict__ mask,
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm
 // Grouped launch: the workgroup looks up which problem its tile belongs to (wave-uniform compare chain, static
 // indices into the by-value table) and runs the same tile code with that problem's descriptor and pointers.
 template <int WM, int WN, int BK>
-__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_grouped_kernel(const rn_conv_group g,
+__global__ __launch_bounds__(256, 4) void conv_igemm_grouped_kernel(const rn_conv_group g,
                                                             const float *__restrict__ w, const float *__restrict__ scale,
                                                             const float *__restrict__ shift) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -108,9 +108,8 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     const dim3 grid((unsigned)tiles), block(256);
 #define RN_LAUNCH_IGEMM(WM, WN, G, K) \
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G, K>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
-    // K-step 16 (34-41 KB of LDS, three workgroups per CU for the 128 x 128 tile) everywhere: with the operands arriving
-    // by direct-to-LDS loads it ties or beats K-step 32 at two workgroups per CU on every layer shape (measured), and
-    // four per CU does not fit the registers (it spills into the K loop).
+    // K-step 16 (34-41 KB of LDS, four workgroups per CU) everywhere: with the operands arriving by direct-to-LDS loads it
+    // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
     if (d->in_relu) {
         hipLaunchKernelGGL((conv_igemm_kernel<2, 2, true, 16, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
     } else if (narrow) {

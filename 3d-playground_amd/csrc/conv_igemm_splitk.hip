@@ -7,7 +7,7 @@
 // (plain stores: no atomics, no zero-fill, the same bits every run) and conv_splitk_finish_kernel adds the slabs in slice
 // order and applies the epilogue.
 template <int WM, int WN, int BK, bool RELU = false>
-__global__ __launch_bounds__(256, (BK == 16 && WM == 2) ? 3 : 2) void conv_igemm_splitk_kernel(
+__global__ __launch_bounds__(256, 4) void conv_igemm_splitk_kernel(
     const rn_conv_desc d, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ ws, int steps_per_slice,
     int nks_total) {
     const int ks_lo = blockIdx.y * steps_per_slice;

@@ -95,9 +95,10 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;    // instructions per wave per K-step and operand
     constexpr int STEP = (BM + BN) * BK;                   // floats per buffer: A rows, then B rows
     constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
-    constexpr int EP = (BM * LDT > 2 * STEP) ? 2 : 1;      // epilogue passes when the output tile outgrows the staging LDS
+    constexpr int NBUF = 2;                                // LDS ring (see the K loop for why not three)
+    constexpr int EP = (BM * LDT > NBUF * STEP) ? 2 : 1;   // epilogue passes when the output tile outgrows the staging LDS
     constexpr int RP = BM / EP;                            // tile rows per pass
-    constexpr int LDSF = 2 * STEP > RP * LDT ? 2 * STEP : RP * LDT;
+    constexpr int LDSF = NBUF * STEP > RP * LDT ? NBUF * STEP : RP * LDT;
     static_assert(WM * WN == 4 && RP % 64 == 0 && IA >= 1 && IB >= 1, "tile shape");
     __shared__ float lds[LDSF];
 
@@ -252,23 +253,32 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         }
     };
 
-    // ---- K loop: the loads of step ks+1 go straight into the idle LDS buffer while step ks is multiplied; one barrier
-    // per K-step.  (Unrolled by two so that buffer addresses are immediates.)
-    if (nks > 0) {
-        dma_step(0, 0);
-        rn_wait_dma();
-    }
+    // ---- K loop over a ring of NBUF LDS buffers: the loads of step ks + NBUF-1 are issued before the MFMAs of step ks,
+    // one barrier per K-step.  With three buffers the wait in front of the barrier is COUNTED (everything but the newest
+    // step's IA + IB loads must have landed) and loads stay in flight across it.
+    // The loop is rolled: the buffer offset is a scalar added to the eight fragment addresses inside the MFMA shadow.
+    // Unrolled (immediates for the buffer addresses) the kernel took 168 registers, rolled it takes 108-118, and that
+    // decides the configuration: two buffers = 34 KB of LDS and <= 128 registers = FOUR workgroups per CU.  Measured per
+    // training step (igemm kernels): unrolled, 2 buffers, 3 per CU 118.6 ms; rolled, 3 buffers, 3 per CU 119.9; rolled,
+    // 2 buffers, 4 per CU 112.0 -- residency beats prefetch distance, most of all on the small-K layers.
+    constexpr int NLD = IA + IB;                           // loads one wave issues per K-step
+    auto wait_but_newest = [&](bool newest_in_flight) {
+        if (NBUF > 2 && newest_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else rn_wait_dma();
+    };
+    if (nks > 0) dma_step(0, 0);
+    if (NBUF > 2 && nks > 1) dma_step(1, 1);
+    wait_but_newest(nks > 1);
     __syncthreads();
-    for (int ks = 0; ks < nks; ks += 2) {
-        if (ks + 1 < nks) dma_step(ks + 1, 1);
-        multiply(0);
-        rn_wait_dma();                                      // this wave's loads have landed ...
-        __syncthreads();                                    // ... and everybody's; buffer 0 is free
-        if (ks + 1 >= nks) break;
-        if (ks + 2 < nks) dma_step(ks + 2, 0);
-        multiply(1);
-        rn_wait_dma();
-        __syncthreads();
+    int rb = 0, wb = NBUF - 1;                              // buffer read by this step / filled for step ks + NBUF-1
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + (NBUF - 1) < nks;
+        if (more) dma_step(ks + (NBUF - 1), wb);
+        multiply(rb);
+        wait_but_newest(more);                              // the next step has landed (this wave's part) ...
+        __syncthreads();                                    // ... and everybody's; buffer rb is free
+        rb = rb == NBUF - 1 ? 0 : rb + 1;
+        wb = wb == NBUF - 1 ? 0 : wb + 1;
     }
 
     // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add (+ add2); act; [mask after]
