@@ -214,6 +214,21 @@ class Engine:
         for L in self.layers.values():
             L.prepare(P, self.cache)
 
+    def _zero_grad_accumulators(self, device):
+        """Weight-gradient and column-sum accumulators of every layer as views of ONE buffer, zeroed by one fill per step
+        (they are atomically accumulated into: ~140 separate zero-fills per step otherwise)."""
+        sizes = [(L, L.wf.numel(), (L.spec.cout + 3) // 4 * 4) for L in self.layers.values()]
+        total = sum(a + b for _, a, b in sizes)
+        arena = getattr(self, "_arena", None)
+        if arena is None or arena.numel() != total or arena.device != device:
+            arena = self._arena = torch.empty(total, dtype=torch.float32, device=device)
+        arena.zero_()
+        o = 0
+        for L, a, b in sizes:
+            L.dw = arena[o:o + a].view_as(L.wf)
+            L.cs = arena[o + a:o + a + L.spec.cout]
+            o += a + b
+
     # ------------------------------------------------------------------------------------------- forward
     def forward(self, P, img, save, x4=None):
         """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None).  x4: the input already
@@ -292,6 +307,7 @@ class Engine:
         """dreg [B,A,n_reg], dcls [B,A,C] (gradient w.r.t. the post-sigmoid classification) -> {param: grad}."""
         Ls = self.layers
         grads = {}
+        self._zero_grad_accumulators(dreg.device)
 
         def done(layer):
             g = layer.finish()
