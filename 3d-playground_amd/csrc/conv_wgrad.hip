@@ -293,7 +293,7 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
     a.tiles = tiles;
     a.splits = (int)splits;
     const dim3 grid((unsigned)(tiles * (a.xcd_map ? (splits + 7) / 8 * 8 : splits)));
-    // 16-pixel K-steps: 40-48 KiB of LDS, three workgroups per CU (measured: +2..4 % over 32-pixel steps at two per CU
+    // 16-pixel K-steps: 40-48 KiB of LDS, four / three workgroups per CU (measured: +2..4 % over 32-pixel steps at two per CU
     // on the mid-size layers, equal on the largest; the 64 x 256 tile does not fit twice at 32).
 #define RN_WGRAD_LAUNCH(WM_, WN_)                                                                                        \
     do {                                                                                                                 \
