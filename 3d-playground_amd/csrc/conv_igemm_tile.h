@@ -15,12 +15,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // Epilogue of one 16-byte chunk (4 output channels of one output pixel m): v = scale*t + shift; [mask before add];
-// v += add (+ add2); act; [mask after]; store through the output map.  One body, expanded in place by the tile epilogue
-// and by the split-K finish kernel; it reads d, m, col, ncol, vec, t, sc, sh, y, add, mask, add2, HoWo from the scope it
-// is expanded in.  (A macro so that both expansions are guaranteed in-line; a shared function would do as well.)
-#define RN_EPI_CHUNK_BODY(GENERAL)                                                                              \
-    do {                                                                                                         \
-        float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]}; \
+// v += add (+ add2); act; [mask after]; store through the output map.  Three stages, expanded in place by the tile
+// epilogue and by the split-K finish kernel (macros so that both expansions are guaranteed in-line); they read d, m,
+// col, ncol, vec, t, sc, sh, y, add, mask, add2, HoWo from the scope they are expanded in.
+//   RN_EPI_ADDR   -> int64_t off (output / mask / same-geometry addend), aoff, a2off (-1 = none)
+//   RN_EPI_LOAD   -> float mk[4], ad[4] from mask / add / add2
+//   RN_EPI_FINISH -> arithmetic and the store
+#define RN_EPI_ADDR(GENERAL)                                                                                     \
         int64_t off, aoff = -1, a2off = -1; \
         if (!GENERAL) { \
             off = m * d.Cout + col; \
@@ -37,7 +38,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
                 aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col; \
             if (d.add2_mode == 3 && ((ph | pw) & 1) == 0) \
                 a2off = (int64_t)n * d.add2_batch_stride + ((int64_t)(ph >> 1) * d.Wa2 + (pw >> 1)) * d.Cout + col; \
-        } \
+        }
+
+#define RN_EPI_LOAD()                                                                                            \
         float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f}; \
         if (vec) { \
             if (d.mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; } \
@@ -50,7 +53,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
                 if (j < ncol && aoff >= 0) ad[j] = add[aoff + j]; \
                 if (j < ncol && a2off >= 0) ad[j] += add2[a2off + j]; \
             } \
-        } \
+        }
+
+#define RN_EPI_FINISH()                                                                                          \
+        float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]}; \
     _Pragma("unroll") \
         for (int j = 0; j < 4; ++j) { \
             float u = v[j]; \
@@ -67,7 +73,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     _Pragma("unroll") \
             for (int j = 0; j < 4; ++j) \
                 if (j < ncol) y[off + j] = v[j]; \
-        } \
+        }
+
+#define RN_EPI_CHUNK_BODY(GENERAL) \
+    do {                           \
+        RN_EPI_ADDR(GENERAL)       \
+        RN_EPI_LOAD()              \
+        RN_EPI_FINISH()            \
     } while (0)
 
 // LDS image of a staged operand: [rows][BK floats], rows unpadded (a direct-to-LDS load fills 1 KiB linearly: 64/CPK whole
@@ -313,17 +325,60 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                             acc[tm][tn][e];
         }
         __syncthreads();
-        for (int r = tid / CPR; r < RP; r += RPP) {
-            const int64_t m = (int64_t)m0 + pass * RP + r;
-            if (m >= M || !col_ok) break;
-            const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
-            if (partial != nullptr) {                        // split-K: raw partial tile, the finish kernel does the rest
-                float *pp = partial + m * d.Cout + col;
-                if (vec) *reinterpret_cast<float4 *>(pp) = t;
-                else { const float tt[4] = {t.x, t.y, t.z, t.w}; for (int j = 0; j < ncol; ++j) pp[j] = tt[j]; }
-                continue;
+        if (vec && partial == nullptr) {
+            // The residual / mask operands of a GROUP of rows are requested first, unconditionally (rows past M re-read row
+            // M-1), then the group is finished: one memory round trip per group instead of one per row.  With the loads
+            // inside the row loop a workgroup paid ~16 serialised HBM round trips here -- on the small-K layers (four K-steps
+            // per tile) more than its whole K loop.
+            constexpr int NIT = RP / RPP, G = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);
+            if (col_ok) {
+#pragma unroll 1
+                for (int g = 0; g < NIT; g += G) {
+                    int64_t off_[G];
+                    float4 mk_[G], ad_[G];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int64_t mr = (int64_t)m0 + pass * RP + tid / CPR + (g + i) * RPP;
+                        const int64_t m = mr < M ? mr : M - 1;
+                        RN_EPI_ADDR(GENERAL)
+                        off_[i] = off;
+                        mk_[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                        ad_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (d.mask_mode != 0) mk_[i] = *reinterpret_cast<const float4 *>(mask + off);
+                        if (d.add_mode != 0) ad_[i] = *reinterpret_cast<const float4 *>(add + aoff);
+                        (void)a2off;
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const int r = tid / CPR + (g + i) * RPP;
+                        const int64_t m = (int64_t)m0 + pass * RP + r;
+                        if (m < M) {
+                            const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                            const int64_t off = off_[i];
+                            float mk[4] = {mk_[i].x, mk_[i].y, mk_[i].z, mk_[i].w}, ad[4] = {ad_[i].x, ad_[i].y, ad_[i].z, ad_[i].w};
+                            if (d.add2_mode == 3) {             // rare (1x1 stride-2 shortcut gradient): its address again, then the load
+                                int64_t a2;
+                                { RN_EPI_ADDR(GENERAL) a2 = a2off; (void)aoff; (void)off; }
+                                if (a2 >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
+                            }
+                            RN_EPI_FINISH()
+                        }
+                    }
+                }
             }
-            RN_EPI_CHUNK_BODY(GENERAL);
+        } else {
+            for (int r = tid / CPR; r < RP; r += RPP) {
+                const int64_t m = (int64_t)m0 + pass * RP + r;
+                if (m >= M || !col_ok) break;
+                const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                if (partial != nullptr) {                        // split-K: raw partial tile, the finish kernel does the rest
+                    float *pp = partial + m * d.Cout + col;
+                    if (vec) *reinterpret_cast<float4 *>(pp) = t;
+                    else { const float tt[4] = {t.x, t.y, t.z, t.w}; for (int j = 0; j < ncol; ++j) pp[j] = tt[j]; }
+                    continue;
+                }
+                RN_EPI_CHUNK_BODY(GENERAL);
+            }
         }
     }
 }
