@@ -95,6 +95,13 @@ def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
         res[name] = {"kernel": "focal_kernel<dir,%s>" % name[-3:], "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "ms": round(ms, 4),
                      "algorithmic_bytes": nbytes}
+    # the pair as the training step runs it: one forward + one backward launch per step
+    ms = res["focal_loss_fwd"]["ms"] + res["focal_loss_bwd"]["ms"]
+    gbs = (fbytes + bbytes) / (ms * 1e-3) / 1e9
+    res["focal_loss_fwd_bwd"] = {"kernel": "focal_kernel<dir,fwd> + focal_kernel<dir,bwd>", "bound": "hbm",
+                                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "ms": round(ms, 4),
+                                 "algorithmic_bytes": fbytes + bbytes}
     return res
 
 
