@@ -134,7 +134,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     const int64_t x_floats = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
     const v4i32 rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride,
                                  (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
-    const v4i32 rs_b = make_rsrc(w, (unsigned)((int64_t)d.Cout * Kpad * 4));
+    const v4i32 rs_b = make_rsrc(w + (int64_t)n_first * d.w_batch_stride, (unsigned)((int64_t)d.Cout * Kpad * 4));   // per-image weights: a batch of GEMMs
 
     // ---- per-lane staging geometry: instruction j of this wave fills rows (wave*I + j)*RPI .. +RPI-1 of the operand;
     // the lane fills position pos of row rsub of them, i.e. fetches logical chunk pos ^ swz(row)
@@ -402,6 +402,7 @@ static inline int check_desc(const rn_conv_desc *d) {
     if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0 || (d->add2_mode != 0 && d->add2_mode != 3)) return RN_EINVAL;
     if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
     if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
+    if (d->w_batch_stride < 0 || (d->w_batch_stride != 0 && ((int64_t)d->Ho * d->Wo) % 256 != 0)) return RN_EINVAL;
     return RN_OK;
 }
 

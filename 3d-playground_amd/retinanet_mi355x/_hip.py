@@ -63,7 +63,8 @@ class ConvDesc(ctypes.Structure):
                 ("mask_mode", c_i32), ("in_relu", c_i32),
                 ("os", c_i32), ("oo_h", c_i32), ("oo_w", c_i32), ("Hy", c_i32), ("Wy", c_i32),
                 ("add2_mode", c_i32), ("Ha2", c_i32), ("Wa2", c_i32), ("add2_batch_stride", c_i64),
-                ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64)]
+                ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64),
+                ("w_batch_stride", c_i64)]
 
 
 RN_MAX_GROUP = 5
@@ -94,6 +95,9 @@ SIGNATURES.update({
     "rn_relu_mask": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp]),
     "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_wino_input": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
+    "rn_wino_output": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "rn_wino_weights": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rn_opt_workspace_bytes": (c_i64, [c_i32]),
     "rn_opt_clip_adam": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
 })

@@ -45,7 +45,7 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None)
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
                mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0,
-               out_map=None, add2=None):
+               out_map=None, add2=None, w_batch_stride=0, kind=None):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift) with p an int or (p_rows, p_cols).
     out_map = (os, oo_h, oo_w, Hy, Wy) stores output pixel (oh,ow) at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
@@ -61,9 +61,10 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
     a2 = (0, 0, 0, 0) if add2 is None else (3, add2.shape[1], add2.shape[2], add2.shape[1] * add2.shape[2] * Cout)
     d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p_h, p_w, ds, act, add_mode, add_hw[0], add_hw[1],
                  (mask_mode if mask is not None else 0), int(in_relu), os_, oo_h, oo_w, Hy, Wy,
-                 a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride)
-    kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
-    ws_bytes = lib.rn_conv_splitk_workspace_bytes(ctypes.byref(d))           # > 0: few output tiles, long K -> split-K
+                 a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride, w_batch_stride)
+    if kind is None:
+        kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
+    ws_bytes = 0 if w_batch_stride else lib.rn_conv_splitk_workspace_bytes(ctypes.byref(d))   # > 0: few output tiles, long K -> split-K
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_splitk(
@@ -90,6 +91,73 @@ def _make_desc(x, geom, act, add_mode, add_hw, mask_mode, in_relu, out_map, y_ba
     return ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p_h, p_w, ds, act, add_mode, add_hw[0], add_hw[1],
                     mask_mode, int(in_relu), os_, oo_h, oo_w, Hy, Wy, a2[0], a2[1], a2[2], a2[3],
                     Hi * Wi * Cin, ybs, add_batch_stride)
+
+
+# ---------------------------------------------------------------------------------------------- Winograd F(4x4,3x3)
+def wino_weights(weight, mode=0, scale=None):
+    """OIHW 3x3 parameter -> U [36, rows, Kpad] (mode 0: forward; mode 1: data gradient, batch-norm scale folded in)."""
+    lib = _hip.load()
+    w = _hip.f32c(weight.detach())
+    _hip.need_gpu(w, scale)
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    rows, k = (cout, cin) if mode == 0 else (cin, cout)
+    U = torch.empty((36, rows, (k + 31) // 32 * 32), dtype=torch.float32, device=w.device)
+    _hip.check(lib.rn_wino_weights(w.data_ptr(), U.data_ptr(), cout, cin, mode, _hip.ptr(scale), _hip.stream()),
+               "rn_wino_weights")
+    return U
+
+
+_WINO_WS = {}
+
+
+def _wino_workspace(device, floats_v, floats_m):
+    """V and M of the Winograd path: two scratch tensors per device, grown on demand and reused by every layer."""
+    ws = _WINO_WS.get(device)
+    if ws is None or ws[0].numel() < floats_v or ws[1].numel() < floats_m:
+        ws = (torch.empty(max(floats_v, ws[0].numel() if ws else 0), dtype=torch.float32, device=device),
+              torch.empty(max(floats_m, ws[1].numel() if ws else 0), dtype=torch.float32, device=device))
+        _WINO_WS[device] = ws
+    return ws
+
+
+def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
+                    flops=0.0):
+    """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
+    [36, Cout, Kpad]: input transform per problem into one V, ONE batched GEMM launch, output transform + epilogue
+    per problem (dense outputs).  Returns the outputs."""
+    lib = _hip.load()
+    dev = xs[0].device
+    C = xs[0].shape[3]
+    cout = U.shape[1]
+    tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
+    T = sum(tiles)
+    Tpad = (T + 255) // 256 * 256
+    V, M = _wino_workspace(dev, 36 * Tpad * C, 36 * Tpad * cout)
+    off = 0
+    for x, t in zip(xs, tiles):
+        N, H, W, _ = x.shape
+        _hip.check(prof.timed("wino_input", 4.0 * (x.numel() + 36 * t * C), lambda: lib.rn_wino_input(x.data_ptr(), V.data_ptr(), N, H, W, C, off, Tpad,
+                                                                          _hip.stream())), "rn_wino_input")
+        off += t
+    # rows past T hold whatever the scratch tensor held: they produce rows of M nobody reads
+    Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
+    Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)
+    conv_igemm(Vv, U.view(36 * cout, U.shape[2]), Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0),
+               flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2], kind="conv_wino_gemm")
+    if outs is None:
+        outs = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in xs]
+    off = 0
+    for i, (x, t) in enumerate(zip(xs, tiles)):
+        N, H, W, _ = x.shape
+        add = None if adds is None else adds[i]
+        mask = None if masks is None else masks[i]
+        nb = 4.0 * (36 * t * cout + outs[i].numel() * (1 + (add is not None) + (mask is not None)))
+        _hip.check(prof.timed("wino_output", nb, lambda: lib.rn_wino_output(
+            M.data_ptr(), outs[i].data_ptr(), N, H, W, cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(add),
+            _hip.ptr(mask), mask_mode if mask is not None else 0, act, _hip.stream())), "rn_wino_output")
+        off += t
+    return outs
 
 
 def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):

@@ -17,6 +17,8 @@ Backward identities used (frozen batch-norm folded as y = s*c + t, s = gamma*rst
   dgamma  = (sum_k W[c,k] * wgrad(g,x)[c,k] - mean[c]*colsum(g)[c]) * rstd[c]
             (because sum_p g*c = sum_k W*dWraw: the pre-BN conv output never has to be stored)
 """
+import os
+
 import torch
 
 from . import _hip, arch, conv as cv, ops
@@ -30,11 +32,15 @@ class Layer:
         self.kw_pad = spec.k if kw_pad is None else kw_pad
         self.cin_pad = spec.cin if cin_pad is None else cin_pad
         self.cout_pad = (spec.cout + 31) // 32 * 32 if spec.cout % 4 else spec.cout
+        # Winograd F(4x4,3x3) is available for 3x3 / stride 1 / padding 1 layers with whole 16-byte channel chunks; the
+        # engine turns it on for the head towers in training (conv_wino.hip: 2.1-2.3x on those layers, ~1e-5 accuracy)
+        self.wino_ok = spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
         self.reset()
 
     def reset(self):
         self.wf = self.wd = self.scale = self.shift = self.rstd = self.mean = None
         self.dw = self.cs = None
+        self.uf = self.ud = None
 
     # ---- per-step preparation
     def prepare(self, P, cache):
@@ -52,6 +58,17 @@ class Layer:
             self.shift = P[s.name + ".bias"].detach() if s.bias else None
         self.wd = None
         self.dw = self.cs = None
+        self.uf = self.ud = None
+
+    def wino_weights(self, mode):
+        """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
+        if mode == 0:
+            if self.uf is None:
+                self.uf = cv.wino_weights(self.weight, 0)
+            return self.uf
+        if self.ud is None:
+            self.ud = cv.wino_weights(self.weight, 1, scale=self.scale)
+        return self.ud
 
     def dgrad_weights(self):
         """Packed dgrad weights (BN scale folded in); for a stride-2 k>1 layer: one tap subset per parity class."""
@@ -76,10 +93,13 @@ class Layer:
                       y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo))
         return out
 
-    def fwd_group(self, xs, act=cv.ACT_NONE, outs=None, y_batch_stride=None):
+    def fwd_group(self, xs, act=cv.ACT_NONE, outs=None, y_batch_stride=None, wino=False):
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
-        (with y_batch_stride) or None for fresh dense outputs."""
+        (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only)."""
         s = self.spec
+        if wino and self.wino_ok and outs is None and act in (cv.ACT_NONE, cv.ACT_RELU):
+            fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
+            return cv.wino_conv_group(xs, self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, flops=fl)
         probs, ys, fl = [], [], 0.0
         for i, x in enumerate(xs):
             N, Hi, Wi, _ = x.shape
@@ -92,10 +112,13 @@ class Layer:
         cv.conv_igemm_grouped(probs, self.wf, scale=self.scale, shift=self.shift, act=act, flops=fl)
         return ys
 
-    def bwd_data_group(self, gs, in_hws, adds=None, masks=None):
+    def bwd_data_group(self, gs, in_hws, adds=None, masks=None, wino=False):
         """Stride-1 data gradient of several problems in one launch; adds / masks: per-problem tensors or None."""
         s = self.spec
         assert s.stride == 1
+        if wino and self.wino_ok and all(g.shape[3] == s.cout for g in gs):
+            fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
+            return cv.wino_conv_group(gs, self.wino_weights(1), adds=adds, masks=masks, mask_mode=2, flops=fl)
         probs, outs, fl = [], [], 0.0
         for i, g in enumerate(gs):
             N = g.shape[0]
@@ -153,7 +176,7 @@ class Layer:
             out[s.bn + ".bias"] = dbeta
         elif s.bias:
             out[s.name + ".bias"] = dbeta
-        self.dw = self.cs = self.wd = None
+        self.dw = self.cs = self.wd = self.uf = self.ud = None
         return out
 
 
@@ -184,6 +207,8 @@ class Engine:
         self.cache = _Cache()
         self.anchor_cache = {}
         self.grad_hook = None                      # callable({name: grad}) as soon as a layer's gradients are final
+        # Winograd for the head towers when activations are saved (= training); RN_WINOGRAD=0 keeps the direct kernels
+        self.use_wino = os.environ.get("RN_WINOGRAD", "1") != "0"
         # layers
         self.layers = {}
         self.blocks = []                            # [(prefix, [roles...])] in forward order
@@ -291,7 +316,7 @@ class Engine:
             ts = pyramid
             acts = []                                                     # acts[i][level]
             for i in range(1, 5):                                         # one launch per tower conv, all 5 levels
-                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU)
+                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino)
                 acts.append(ts)
             views, off = [], 0
             for cnt in counts:
@@ -339,11 +364,11 @@ class Engine:
             for i in (3, 2, 1):
                 for li in range(5):
                     tower[i].bwd_params(gs[li], acts[li][i - 1])
-                gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)])
+                gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino)
             for li in range(5):
                 tower[0].bwd_params(gs[li], pyramid[li])
             first = dpyr[0] is None
-            dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr)
+            dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino)
             S["towers"][prefix] = None
             done(Lout)
             for L in reversed(tower):

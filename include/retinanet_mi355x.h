@@ -246,6 +246,9 @@ typedef struct rn_conv_desc {
     int Ha2, Wa2;
     int64_t add2_batch_stride;
     int64_t x_batch_stride, y_batch_stride, add_batch_stride;
+    int64_t w_batch_stride;        /* 0: one weight tensor.  != 0 (floats): image n uses w_packed + n * w_batch_stride -- a batch of
+                                      independent GEMMs in one launch (the 36 positions of the Winograd path); Ho*Wo must then
+                                      be a multiple of 256 so that no tile spans two images */
 } rn_conv_desc;
 
 int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
@@ -289,6 +292,23 @@ int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_packed, const f
  * slices are made finer if need be); RN_EINVAL only if a single input image exceeds that. */
 int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
                   int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
+
+/* Winograd F(4x4,3x3) stages for 3x3 / stride 1 / padding 1 convolutions (the head towers, D/model.py:120-205), fp32:
+ *   rn_wino_input   x [N,H,W,C] -> V [36][Tpad][C]: B^T d B of every 6x6 patch; the problem's tiles (N * ceil(H/4) *
+ *                   ceil(W/4), image-major) are written from row tile_offset on, so several problems (pyramid levels)
+ *                   share one V;
+ *   (GEMM)          rn_conv_igemm as a 1x1 convolution over 36 images of Tpad pixels with w_batch_stride = rows * Kpad:
+ *                   M [36][Tpad][Cout] = V_p x U_p^T;
+ *   rn_wino_output  M -> y [N,H,W,Cout] (dense): A^T m A, then v = scale*v + shift; mask_mode 1: v = mask > 0 ? v : 0;
+ *                   v += add; act 1: ReLU; mask_mode 2: v = mask > 0 ? v : 0  (mask / add: geometry of y, may be NULL);
+ *   rn_wino_weights U [36][rows][Kpad] from the OIHW parameter: mode 0 forward (rows = Cout, K = Cin), mode 1 data
+ *                   gradient (rows = Cin, K = Cout, filter rotated by 180 degrees, times scale[co]); Kpad = K rounded up to 32.
+ * Accuracy: ~1e-5 of the output's max magnitude (the direct kernel: ~3e-7). */
+int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);
+int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int64_t tile_offset, int64_t Tpad,
+                   const float *scale, const float *shift, const float *add, const float *mask, int mask_mode, int act,
+                   void *stream);
+int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int mode, const float *scale, void *stream);
 
 /* Weight packing.  src is the reference's OIHW parameter [Cout][Cin][kh][kw] (state_dict layout).
  *   mode 0 (forward):  dst[co][r][s][ci]          = src[co][ci][r][s]

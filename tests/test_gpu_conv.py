@@ -116,6 +116,31 @@ def test_wgrad_long_k(cv, dev, case):
     close(cs, gy.double().sum(dim=(0, 2, 3)), tol=2e-5)
 
 
+def test_winograd_group_fprop_and_dgrad(cv, dev):
+    """Winograd F(4x4,3x3) path of the head towers on a small pyramid (odd sizes: partial tiles on both edges): forward
+    with bias + ReLU, data gradient with ReLU mask + accumulated gradient, against torch's fp64 conv2d.
+    Tolerance 1e-4 of the max magnitude (north_star); F(4x4,3x3) in fp32 measures ~1e-5."""
+    cin = cout = 64
+    w = rnd((cout, cin, 3, 3), 21, (2.0 / (9 * cin)) ** 0.5)
+    b = rnd((cout,), 22, 0.1)
+    shapes = [(2, 19, 23), (2, 10, 12), (2, 5, 6), (2, 3, 3), (2, 2, 2)]
+    xs = [rnd((n, cin, h, ww), 30 + i) for i, (n, h, ww) in enumerate(shapes)]
+    U = cv.wino_weights(w.to(dev), 0)
+    ys = cv.wino_conv_group([nhwc(x).to(dev) for x in xs], U, shift=b.to(dev), act=cv.ACT_RELU)
+    for x, y in zip(xs, ys):
+        ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+        close(nchw(y), ref, tol=1e-4)
+    # data gradient: dx = mask * conv_transpose(dy, w) + add
+    Ud = cv.wino_weights(w.to(dev), 1)
+    gys = [rnd((n, cout, h, ww), 40 + i) for i, (n, h, ww) in enumerate(shapes)]
+    adds = [rnd((n, cin, h, ww), 50 + i) for i, (n, h, ww) in enumerate(shapes)]
+    dxs = cv.wino_conv_group([nhwc(g).to(dev) for g in gys], Ud, adds=[nhwc(a).to(dev) for a in adds],
+                             masks=[nhwc(x).to(dev) for x in xs], mask_mode=2)
+    for x, g, a, dx in zip(xs, gys, adds, dxs):
+        ref = (F.conv_transpose2d(g.double(), w.double(), None, 1, 1) + a.double()) * (x.double() > 0)
+        close(nchw(dx), ref, tol=1e-4)
+
+
 def test_stem_conv_bn_relu(cv, dev):
     """7x7 s2 p3 on a 3-channel NCHW image: NHWC4 staging, kw padded to 8, folded frozen BN + ReLU epilogue."""
     N, H, W = 2, 37, 45
