@@ -50,6 +50,9 @@ struct WgradArgs {
     int tiles_n;                 // number of N tiles
     int tiles, splits;           // tiles_m * tiles_n, K slices
     int xcd_map;                 // 1: whole K slices per XCD (see the kernel)
+    int tiles_per_batch;         // tiles of ONE problem; tiles = tiles_per_batch * batch count
+    int colsum_batch;            // the batch entry whose dy column sums are wanted
+    int64_t dy_bstride, x_bstride, dw_bstride;   // floats between the operands of consecutive batch entries
     int64_t pixels, per_split;   // K extent and K per slice (multiple of WK)
 };
 
@@ -82,6 +85,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
         tile = blockIdx.x % p.tiles;
     }
     if (slice >= p.splits) return;                           // padding of the last group of 8 slices
+    // Batched form (the 36 positions of the Winograd weight gradient): independent problems of identical shape, operands
+    // and result p.*_bstride apart; a tile index enumerates (batch entry, tile).
+    const int batch = tile / p.tiles_per_batch;
+    tile -= batch * p.tiles_per_batch;
+    const float *dy_b = p.dy + (int64_t)batch * p.dy_bstride;
+    const float *x_b = p.x + (int64_t)batch * p.x_bstride;
+    float *dw_b = p.dw + (int64_t)batch * p.dw_bstride;
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int64_t kbeg = (int64_t)slice * p.per_split;
     const int64_t kend = (kbeg + p.per_split < p.pixels) ? kbeg + p.per_split : p.pixels;
@@ -98,8 +108,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     const int64_t img = (int64_t)p.Hi * p.Wi * p.Cin;        // floats per input image
     int64_t xbytes = ((int64_t)p.N - n_first) * img * 4;
     if (xbytes > 0x7FFFFFFF) xbytes = 0x7FFFFFFF;
-    const v4i32 rs_a = make_rsrc(p.dy + kbeg * p.ldy, (unsigned)((kend - kbeg) * p.ldy * 4));
-    const v4i32 rs_b = make_rsrc(p.x + (int64_t)n_first * img, (unsigned)xbytes);
+    const v4i32 rs_a = make_rsrc(dy_b + kbeg * p.ldy, (unsigned)((kend - kbeg) * p.ldy * 4));
+    const v4i32 rs_b = make_rsrc(x_b + (int64_t)n_first * img, (unsigned)xbytes);
 
     // Lane -> (pixel within the instruction's group, 16-byte chunk).  Instruction j of wave w fills pixels
     // (w * I + j) * P + lane / C of the tile: 1 KiB of LDS starting at that pixel's row.
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     const int fa0 = hi * BM + wm * 64 + 2 * (lane & 31);
     const int fb0 = hi * BN + wn * 64 + (lane & 31);          // B: channels j and j + 32 (see the epilogue)
     // Only the waves that own distinct channels of N-tile 0 add up column sums: two copies of the loop, chosen once.
-    const bool do_cs = p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0;
+    const bool do_cs = p.colsum != nullptr && batch == p.colsum_batch && (tile % p.tiles_n) == 0 && wn == 0;
     auto k_loop = [&](auto cs_tag) {
         constexpr bool CS = decltype(cs_tag)::value;
         for (int ks = 0; ks < nks; ++ks) {
@@ -245,17 +255,21 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) + tm;   // tile tm: channels 2*i + tm
-                if (row < p.Cout && col < p.Kflat) atomicAdd(p.dw + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                if (row < p.Cout && col < p.Kflat) atomicAdd(dw_b + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
             }
         }
 }
 
-extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
-                             int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
-                             void *stream) {
+extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
+                                     int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
+                                     int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                     int in_relu, void *stream) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
         return RN_EINVAL;
+    if (nbatch < 1 || nbatch > 4096 || dy_bstride < 0 || x_bstride < 0 || dw_bstride < 0 || colsum_batch < 0 || colsum_batch >= nbatch)
+        return RN_EINVAL;
     WgradArgs a;
+    a.dy_bstride = dy_bstride; a.x_bstride = x_bstride; a.dw_bstride = dw_bstride; a.colsum_batch = colsum_batch;
     a.dy = dy; a.x = x; a.dw = dw; a.colsum = colsum; a.ldy = ldy;
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.in_relu = in_relu;
@@ -267,7 +281,8 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
     const int BM = shape == 0 ? 64 : (shape == 1 ? 256 : 128), BN = shape == 0 ? 256 : (shape == 1 ? 64 : 128);
     const int tiles_m = (Cout + BM - 1) / BM;
     a.tiles_n = (a.Kflat + BN - 1) / BN;
-    const int tiles = tiles_m * a.tiles_n;
+    a.tiles_per_batch = tiles_m * a.tiles_n;
+    const int tiles = a.tiles_per_batch * nbatch;
     // enough K slices for ~2048 workgroups -- two rounds of what the chip holds (4 per CU at 40 KB of LDS); measured per
     // training step: 512 -> 66.0 ms, 1024 -> 57.3, 1536 -> 55.2, 2048 -> 54.2, 4096 -> 54.9, 8192 -> 55.1 -- each at
     // least 512 pixels long
@@ -306,4 +321,11 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
 #undef RN_WGRAD_LAUNCH
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
+                             int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
+                             void *stream) {
+    return rn_conv_wgrad_batched(dy, ldy, x, dw, colsum, 1, 0, 0, 0, 0, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
+                                 in_relu, stream);
 }

@@ -186,6 +186,85 @@ __global__ void wino_weight_kernel(const float *__restrict__ w, float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dL/dg = G^T [ sum over tiles of (A dy A^T) .* (B^T d B) ] G.  Z = A dy A^T (4x4 output-gradient tile -> 6x6) is this
+// kernel; V = B^T d B is wino_in_kernel; dU[p] = Z_p^T V_p is the weight-gradient GEMM kernel run as 36 batched 1x1
+// problems (rn_conv_wgrad_batched); wino_dw_kernel folds G^T dU G into the layer's packed gradient.  Z at position
+// (1,1) is the plain sum of the tile's dy, so the bias gradient is the column sum of that one batch entry.
+// o = A v for one 4-vector (A = transpose of the A^T of at6)
+__device__ __forceinline__ void a6(const float4 v[4], float4 o[6]) {
+    const float4 s02 = v[0] + v[2], s13 = v[1] + v[3];
+    o[0] = v[0];
+    o[1] = s02 + s13;
+    o[2] = s02 - s13;
+    const float4 e = v[0] + 4.f * v[2], f = 2.f * v[1] + 8.f * v[3];
+    o[3] = e + f;
+    o[4] = e - f;
+    o[5] = v[3];
+}
+
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float *__restrict__ dy, float *__restrict__ Z, int N, int H, int W,
+                                                      int C, int TH, int TW, int64_t t0, int64_t Tpad) {
+    const int cq = C >> 2;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tile = id / cq;
+    if (tile >= (int64_t)N * TH * TW) return;
+    const int c4 = (int)(id - tile * cq) * 4;
+    const int n = (int)(tile / (TH * TW));
+    const int r = (int)(tile - (int64_t)n * TH * TW);
+    const int th = r / TW, tw = r - th * TW;
+    const float *yb = dy + (int64_t)n * H * W * C + c4;
+    float4 t[6][4];                                           // t[a][j] = (A dy)[a][j]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 v[4], o[6];
+        const int w = 4 * tw + j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h = 4 * th + i;
+            v[i] = (h < H && w < W) ? *reinterpret_cast<const float4 *>(yb + ((int64_t)h * W + w) * C) : f4(0.f);
+        }
+        a6(v, o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) t[a][j] = o[a];
+    }
+    float *zb = Z + (t0 + tile) * C + c4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float4 o[6];
+        a6(t[a], o);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) *reinterpret_cast<float4 *>(zb + (int64_t)(a * 6 + b) * Tpad * C) = o[b];
+    }
+}
+
+// dw[co][(r*3 + s)*Cin + ci] += (G^T dU G)[r][s],  dU [36][Cout][Ku] (Ku = Cin rounded up to 32)
+__global__ void wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, int Cout, int Cin, int Ku, int Kpad) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)Cout * Cin) return;
+    const int co = (int)(id / Cin), ci = (int)(id - (int64_t)co * Cin);
+    const float *u = dU + (int64_t)co * Ku + ci;
+    const int64_t ps = (int64_t)Cout * Ku;
+    float t[3][6];                                            // t[r][j] = sum_i G[i][r] dU[i][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = u[(i * 6 + j) * ps];
+        t[0][j] = v[0] * (1.f / 4.f) - (v[1] + v[2]) * (1.f / 6.f) + (v[3] + v[4]) * (1.f / 24.f);
+        t[1][j] = (v[2] - v[1]) * (1.f / 6.f) + (v[3] - v[4]) * (1.f / 12.f);
+        t[2][j] = (v[3] + v[4] - v[1] - v[2]) * (1.f / 6.f) + v[5];
+    }
+    float *o = dw + (int64_t)co * Kpad + ci;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float *v = t[r];
+        o[(r * 3 + 0) * Cin] += v[0] * (1.f / 4.f) - (v[1] + v[2]) * (1.f / 6.f) + (v[3] + v[4]) * (1.f / 24.f);
+        o[(r * 3 + 1) * Cin] += (v[2] - v[1]) * (1.f / 6.f) + (v[3] - v[4]) * (1.f / 12.f);
+        o[(r * 3 + 2) * Cin] += (v[3] + v[4] - v[1] - v[2]) * (1.f / 6.f) + v[5];
+    }
+}
+
 extern "C" int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad,
                              void *stream) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || tile_offset < 0) return RN_EINVAL;
@@ -218,6 +297,26 @@ extern "C" int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int 
     const int Kpad = ((mode == 0 ? Cin : Cout) + 31) / 32 * 32;
     hipLaunchKernelGGL(wino_weight_kernel, dim3(rn_blocks((int64_t)rows * Kpad, 256)), dim3(256), 0, (hipStream_t)stream, w, U,
                        Cout, Cin, mode, scale, rows, Kpad);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+extern "C" int rn_wino_dy(const float *dy, float *Z, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || tile_offset < 0) return RN_EINVAL;
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+    const int64_t tiles = (int64_t)N * TH * TW;
+    if (tile_offset + tiles > Tpad) return RN_EINVAL;
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(rn_blocks(tiles * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, dy, Z, N, H, W,
+                       C, TH, TW, tile_offset, Tpad);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+extern "C" int rn_wino_dw(const float *dU, float *dw, int Cout, int Cin, void *stream) {
+    if (Cout <= 0 || Cin <= 0) return RN_EINVAL;
+    const int Ku = (Cin + 31) / 32 * 32, Kpad = (9 * Cin + 31) / 32 * 32;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3(rn_blocks((int64_t)Cout * Cin, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw, Cout,
+                       Cin, Ku, Kpad);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -160,6 +160,35 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     return outs
 
 
+def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0):
+    """Weight gradient of a 3x3 / stride 1 / padding 1 convolution over several problems (gs[i] = dY [N,H,W,Cout],
+    xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum."""
+    lib = _hip.load()
+    dev = xs[0].device
+    C, cout = xs[0].shape[3], gs[0].shape[3]
+    tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
+    T = sum(tiles)
+    Tpad = (T + 255) // 256 * 256
+    V, Z = _wino_workspace(dev, 36 * Tpad * C, 36 * Tpad * cout)
+    off = 0
+    for x, g, t in zip(xs, gs, tiles):
+        N, H, W, _ = x.shape
+        assert g.shape[:3] == x.shape[:3] and g.is_contiguous() and x.is_contiguous()
+        _hip.check(prof.timed("wino_input", 4.0 * (x.numel() + 36 * t * C), lambda: lib.rn_wino_input(
+            x.data_ptr(), V.data_ptr(), N, H, W, C, off, Tpad, _hip.stream())), "rn_wino_input")
+        _hip.check(prof.timed("wino_input", 4.0 * (g.numel() + 36 * t * cout), lambda: lib.rn_wino_dy(
+            g.data_ptr(), Z.data_ptr(), N, H, W, cout, off, Tpad, _hip.stream())), "rn_wino_dy")
+        off += t
+    ku = (C + 31) // 32 * 32
+    dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
+    rc = prof.timed("conv_wino_wgrad", 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(
+        Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
+        1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0, _hip.stream()))
+    _hip.check(rc, "rn_conv_wgrad_batched")
+    _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
+    return dw
+
+
 def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):
     """One launch for up to 5 problems sharing weights / epilogue scalars (the pyramid levels of a head tower).
     problems: list of dicts with x, y, geom and optional add, mask, mask_mode, y_batch_stride."""

@@ -146,6 +146,19 @@ class Layer:
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
                  flops=self.flops(g.shape[0], g.shape[1], g.shape[2]), colsum=self.cs)
 
+    def bwd_params_group(self, gs, xs, wino=False):
+        """bwd_params over several problems (pyramid levels); wino: one Winograd weight-gradient pass over all of them."""
+        s = self.spec
+        if wino and self.wino_ok and all(g.shape[3] == s.cout and g.is_contiguous() for g in gs):
+            if self.dw is None:
+                self.dw = torch.zeros_like(self.wf)
+                self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
+            fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
+            cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl)
+            return
+        for g, x in zip(gs, xs):
+            self.bwd_params(g, x)
+
     def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2, add2=None):
         s = self.spec
         kw = dict(add=add, add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
@@ -362,11 +375,9 @@ class Engine:
                 Lout.bwd_params(gs[li], acts[li][3])
             gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
             for i in (3, 2, 1):
-                for li in range(5):
-                    tower[i].bwd_params(gs[li], acts[li][i - 1])
+                tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino)
                 gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino)
-            for li in range(5):
-                tower[0].bwd_params(gs[li], pyramid[li])
+            tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino)
             first = dpyr[0] is None
             dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino)
             S["towers"][prefix] = None

@@ -292,6 +292,11 @@ int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_packed, const f
  * slices are made finer if need be); RN_EINVAL only if a single input image exceeds that. */
 int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *colsum, int N, int Hi, int Wi,
                   int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
+/* nbatch independent problems of identical shape in one launch: operands and result of entry b at dy + b*dy_bstride,
+ * x + b*x_bstride, dw + b*dw_bstride (floats); colsum (if given) is taken from entry colsum_batch only. */
+int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
+                          int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
+                          int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
 
 /* Winograd F(4x4,3x3) stages for 3x3 / stride 1 / padding 1 convolutions (the head towers, D/model.py:120-205), fp32:
  *   rn_wino_input   x [N,H,W,C] -> V [36][Tpad][C]: B^T d B of every 6x6 patch; the problem's tiles (N * ceil(H/4) *
@@ -309,6 +314,14 @@ int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int6
                    const float *scale, const float *shift, const float *add, const float *mask, int mask_mode, int act,
                    void *stream);
 int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int mode, const float *scale, void *stream);
+/* Weight gradient of the same convolutions:  dL/dg = G^T [ sum over tiles (A dy A^T) .* (B^T d B) ] G.
+ *   rn_wino_dy   dy [N,H,W,C] -> Z [36][Tpad][C] (A dy A^T of every 4x4 tile; same tile order as rn_wino_input);
+ *   (GEMM)       rn_conv_wgrad_batched over the 36 positions: dU[p] += Z_p^T V_p, a 1x1 problem with Tpad-strided
+ *                operands and T "pixels"; colsum of batch entry 7 (position (1,1)) is the bias gradient;
+ *   rn_wino_dw   dw[co][(r*3+s)*Cin + ci] += (G^T dU G)[r][s]  (the packed layout rn_conv_wgrad accumulates into,
+ *                dU [36][Cout][Cin rounded up to 32]). */
+int rn_wino_dy(const float *dy, float *Z, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);
+int rn_wino_dw(const float *dU, float *dw, int Cout, int Cin, void *stream);
 
 /* Weight packing.  src is the reference's OIHW parameter [Cout][Cin][kh][kw] (state_dict layout).
  *   mode 0 (forward):  dst[co][r][s][ci]          = src[co][ci][r][s]

@@ -141,6 +141,27 @@ def test_winograd_group_fprop_and_dgrad(cv, dev):
         close(nchw(dx), ref, tol=1e-4)
 
 
+def test_winograd_group_wgrad(cv, dev):
+    """Winograd weight gradient + bias gradient over a small pyramid (partial tiles), against torch's fp64 conv2d backward."""
+    cin, cout = 64, 128
+    w = rnd((cout, cin, 3, 3), 61, (2.0 / (9 * cin)) ** 0.5)
+    shapes = [(2, 19, 23), (2, 10, 12), (2, 5, 6), (2, 3, 3), (2, 2, 2)]
+    xs = [rnd((n, cin, h, ww), 70 + i) for i, (n, h, ww) in enumerate(shapes)]
+    gys = [rnd((n, cout, h, ww), 80 + i) for i, (n, h, ww) in enumerate(shapes)]
+    wr = w.double().requires_grad_(True)
+    tot = 0
+    for x, g in zip(xs, gys):
+        tot = tot + (F.conv2d(x.double(), wr, None, 1, 1) * g.double()).sum()
+    tot.backward()
+    wp = cv.pack_weights(w.to(dev), 0)
+    dw = torch.zeros_like(wp)
+    cs = torch.zeros(cout, device=dev)
+    cv.wino_wgrad_group([nhwc(g).to(dev) for g in gys], [nhwc(x).to(dev) for x in xs], dw, cs)
+    dweight, _, _ = cv.unpack_wgrad(dw, wp, tuple(w.shape))
+    close(dweight, wr.grad, tol=1e-4)
+    close(cs, sum(g.double().sum(dim=(0, 2, 3)) for g in gys), tol=2e-5)
+
+
 def test_stem_conv_bn_relu(cv, dev):
     """7x7 s2 p3 on a 3-channel NCHW image: NHWC4 staging, kw padded to 8, folded frozen BN + ReLU epilogue."""
     N, H, W = 2, 37, 45

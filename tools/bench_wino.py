@@ -63,3 +63,26 @@ prof.ACTIVE = prof.KernelTimer()
 wino_fwd()
 for k, v in prof.ACTIVE.summary().items():
     print("   %-16s %d launches  %.3f ms" % (k, v["launches"], v["ms_total"]))
+
+# weight gradient: direct (one launch per level) against Winograd (transforms + one batched launch)
+gs = [torch.randn_like(x) for x in xs]
+dw = torch.zeros_like(wp)
+cs = torch.zeros(C, device=dev)
+
+
+def direct_wgrad():
+    for g, x in zip(gs, xs):
+        cv.wgrad(g, x, dw, C, 3, 1, 1, colsum=cs)
+
+
+def wino_wgrad():
+    cv.wino_wgrad_group(gs, xs, dw, cs)
+
+
+td, tw = timeit(direct_wgrad), timeit(wino_wgrad)
+print("%-28s direct %.3f ms (%.1f TF)   winograd %.3f ms (%.1f TF algorithmic)   x%.2f" %
+      ("weight gradient", td * 1e3, flops / td / 1e12, tw * 1e3, flops / tw / 1e12, td / tw))
+prof.ACTIVE = prof.KernelTimer()
+wino_wgrad()
+for k, v in prof.ACTIVE.summary().items():
+    print("   %-16s %d launches  %.3f ms" % (k, v["launches"], v["ms_total"]))
