@@ -35,6 +35,9 @@ class Layer:
         # Winograd F(4x4,3x3) is available for 3x3 / stride 1 / padding 1 layers with whole 16-byte channel chunks; the
         # engine turns it on for the head towers in training (conv_wino.hip: 2.1-2.3x on those layers, ~1e-5 accuracy)
         self.wino_ok = spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
+        # worth it from 128 channels on (below, the 36 GEMMs have too short a K loop); set per step by the engine
+        self.wino_layer = self.wino_ok and spec.cin >= 128 and spec.cout >= 128
+        self.wino_active = False
         self.reset()
 
     def reset(self):
@@ -86,6 +89,9 @@ class Layer:
         s = self.spec
         N, Hi, Wi, _ = x.shape
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
+        if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
+                and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
+            return cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act)[0]
         if out is None:
             out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
         cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
@@ -97,7 +103,7 @@ class Layer:
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only)."""
         s = self.spec
-        if wino and self.wino_ok and outs is None and act in (cv.ACT_NONE, cv.ACT_RELU):
+        if (wino or self.wino_active) and self.wino_ok and outs is None and act in (cv.ACT_NONE, cv.ACT_RELU):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
             return cv.wino_conv_group(xs, self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, flops=fl)
         probs, ys, fl = [], [], 0.0
@@ -116,7 +122,7 @@ class Layer:
         """Stride-1 data gradient of several problems in one launch; adds / masks: per-problem tensors or None."""
         s = self.spec
         assert s.stride == 1
-        if wino and self.wino_ok and all(g.shape[3] == s.cout for g in gs):
+        if (wino or self.wino_active) and self.wino_ok and all(g.shape[3] == s.cout for g in gs):
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
             return cv.wino_conv_group(gs, self.wino_weights(1), adds=adds, masks=masks, mask_mode=2, flops=fl)
         probs, outs, fl = [], [], 0.0
@@ -143,13 +149,16 @@ class Layer:
         if self.dw is None:
             self.dw = torch.zeros_like(self.wf)
             self.cs = torch.zeros(s.cout, dtype=torch.float32, device=g.device)
+        if self.wino_active and not in_relu and g.shape[3] == s.cout and g.is_contiguous() and x.is_contiguous():
+            cv.wino_wgrad_group([g], [x], self.dw, self.cs)
+            return
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
                  flops=self.flops(g.shape[0], g.shape[1], g.shape[2]), colsum=self.cs)
 
     def bwd_params_group(self, gs, xs, wino=False):
         """bwd_params over several problems (pyramid levels); wino: one Winograd weight-gradient pass over all of them."""
         s = self.spec
-        if wino and self.wino_ok and all(g.shape[3] == s.cout and g.is_contiguous() for g in gs):
+        if (wino or self.wino_active) and self.wino_ok and all(g.shape[3] == s.cout and g.is_contiguous() for g in gs):
             if self.dw is None:
                 self.dw = torch.zeros_like(self.wf)
                 self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
@@ -161,6 +170,9 @@ class Layer:
 
     def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2, add2=None):
         s = self.spec
+        if self.wino_active and add2 is None and g.shape[3] == s.cout and g.is_contiguous():
+            return cv.wino_conv_group([g], self.wino_weights(1), adds=None if add is None else [add],
+                                      masks=None if mask is None else [mask], mask_mode=mask_mode)[0]
         kw = dict(add=add, add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
                   flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
         if s.stride == 2 and s.k > 1:
@@ -273,6 +285,8 @@ class Engine:
         in the stem's layout ([B,H,W,4] fp32, e.g. from ops.frame_ingest(nhwc4=True)); img is then ignored."""
         Ls = self.layers
         self._prepare(P)
+        for L in Ls.values():                              # Winograd where it pays, and only when training (save)
+            L.wino_active = bool(save and self.use_wino and L.wino_layer)
         if x4 is None:
             _hip.need_gpu(img)
             x4 = cv.nchw_to_nhwc4(img)
