@@ -122,7 +122,7 @@ def _wino_workspace(device, floats_v, floats_m):
 
 
 def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
-                    flops=0.0):
+                    flops=0.0, keep_v=False):
     """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
     [36, Cout, Kpad]: input transform per problem into one V, ONE batched GEMM launch, output transform + epilogue
     per problem (dense outputs).  Returns the outputs."""
@@ -133,7 +133,9 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
     Tpad = (T + 255) // 256 * 256
-    V, M = _wino_workspace(dev, 36 * Tpad * C, 36 * Tpad * cout)
+    V, M = _wino_workspace(dev, 0 if keep_v else 36 * Tpad * C, 36 * Tpad * cout)
+    if keep_v:                                       # the caller keeps B^T d B of the inputs for the weight gradient
+        V = torch.empty(36 * Tpad * C, dtype=torch.float32, device=dev)
     off = 0
     for x, t in zip(xs, tiles):
         N, H, W, _ = x.shape
@@ -144,7 +146,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
     Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)
     conv_igemm(Vv, U.view(36 * cout, U.shape[2]), Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0),
-               flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2], kind="conv_wino_gemm")
+               flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2])    # executed FLOPs: same kernel, same family
     if outs is None:
         outs = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in xs]
     off = 0
@@ -157,10 +159,10 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
             M.data_ptr(), outs[i].data_ptr(), N, H, W, cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(add),
             _hip.ptr(mask), mask_mode if mask is not None else 0, act, _hip.stream())), "rn_wino_output")
         off += t
-    return outs
+    return (outs, V) if keep_v else outs
 
 
-def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0):
+def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
     """Weight gradient of a 3x3 / stride 1 / padding 1 convolution over several problems (gs[i] = dY [N,H,W,Cout],
     xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum."""
     lib = _hip.load()
@@ -169,19 +171,23 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0):
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
     Tpad = (T + 255) // 256 * 256
-    V, Z = _wino_workspace(dev, 36 * Tpad * C, 36 * Tpad * cout)
+    have_v = V is not None and V.numel() == 36 * Tpad * C      # V: B^T d B of xs kept by the forward (same grouping)
+    Vw, Z = _wino_workspace(dev, 0 if have_v else 36 * Tpad * C, 36 * Tpad * cout)
+    if not have_v:
+        V = Vw
     off = 0
     for x, g, t in zip(xs, gs, tiles):
         N, H, W, _ = x.shape
         assert g.shape[:3] == x.shape[:3] and g.is_contiguous() and x.is_contiguous()
-        _hip.check(prof.timed("wino_input", 4.0 * (x.numel() + 36 * t * C), lambda: lib.rn_wino_input(
-            x.data_ptr(), V.data_ptr(), N, H, W, C, off, Tpad, _hip.stream())), "rn_wino_input")
+        if not have_v:
+            _hip.check(prof.timed("wino_input", 4.0 * (x.numel() + 36 * t * C), lambda: lib.rn_wino_input(
+                x.data_ptr(), V.data_ptr(), N, H, W, C, off, Tpad, _hip.stream())), "rn_wino_input")
         _hip.check(prof.timed("wino_input", 4.0 * (g.numel() + 36 * t * cout), lambda: lib.rn_wino_dy(
             g.data_ptr(), Z.data_ptr(), N, H, W, cout, off, Tpad, _hip.stream())), "rn_wino_dy")
         off += t
     ku = (C + 31) // 32 * 32
     dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
-    rc = prof.timed("conv_wino_wgrad", 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(
+    rc = prof.timed("conv_wgrad", 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(    # executed FLOPs
         Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
         1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0, _hip.stream()))
     _hip.check(rc, "rn_conv_wgrad_batched")

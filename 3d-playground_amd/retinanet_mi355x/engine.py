@@ -44,6 +44,7 @@ class Layer:
         self.wf = self.wd = self.scale = self.shift = self.rstd = self.mean = None
         self.dw = self.cs = None
         self.uf = self.ud = None
+        self.saved_v = None                        # Winograd input transform of the forward, kept for the weight gradient
 
     # ---- per-step preparation
     def prepare(self, P, cache):
@@ -91,7 +92,9 @@ class Layer:
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
         if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
                 and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
-            return cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act)[0]
+            ys, self.saved_v = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act,
+                                                  keep_v=True)
+            return ys[0]
         if out is None:
             out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
         cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
@@ -105,7 +108,9 @@ class Layer:
         s = self.spec
         if (wino or self.wino_active) and self.wino_ok and outs is None and act in (cv.ACT_NONE, cv.ACT_RELU):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
-            return cv.wino_conv_group(xs, self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, flops=fl)
+            ys, self.saved_v = cv.wino_conv_group(xs, self.wino_weights(0), scale=self.scale, shift=self.shift, act=act,
+                                                  flops=fl, keep_v=True)
+            return ys
         probs, ys, fl = [], [], 0.0
         for i, x in enumerate(xs):
             N, Hi, Wi, _ = x.shape
@@ -150,7 +155,8 @@ class Layer:
             self.dw = torch.zeros_like(self.wf)
             self.cs = torch.zeros(s.cout, dtype=torch.float32, device=g.device)
         if self.wino_active and not in_relu and g.shape[3] == s.cout and g.is_contiguous() and x.is_contiguous():
-            cv.wino_wgrad_group([g], [x], self.dw, self.cs)
+            cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v)
+            self.saved_v = None
             return
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
                  flops=self.flops(g.shape[0], g.shape[1], g.shape[2]), colsum=self.cs)
@@ -163,7 +169,8 @@ class Layer:
                 self.dw = torch.zeros_like(self.wf)
                 self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
-            cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl)
+            cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v)
+            self.saved_v = None
             return
         for g, x in zip(gs, xs):
             self.bwd_params(g, x)
@@ -201,7 +208,7 @@ class Layer:
             out[s.bn + ".bias"] = dbeta
         elif s.bias:
             out[s.name + ".bias"] = dbeta
-        self.dw = self.cs = self.wd = self.uf = self.ud = None
+        self.dw = self.cs = self.wd = self.uf = self.ud = self.saved_v = None
         return out
 
 
