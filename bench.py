@@ -251,7 +251,7 @@ def main():
                 wms = sum(a["ms_total"] for a in forward_passes().values())
                 kernels["forward_convs_training"] = {
                     "ms_per_pass": round(wms / 3, 2), "algorithmic_tflops": round(fwork / (wms * 1e-3) / 1e12, 2),
-                    "note": "head towers by Winograd F(4x4,3x3): a quarter of the multiplications on those layers"}
+                    "note": "3x3 stride-1 layers with >= 128 channels by Winograd F(4x4,3x3): a quarter of the multiplications there"}
             line["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
