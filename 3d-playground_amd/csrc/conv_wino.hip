@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float *__restrict__
                                                        int Cout, int TH, int TW, int64_t t0, int64_t Tpad,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ add, const float *__restrict__ mask,
-                                                       int mask_mode, int act) {
+                                                       int mask_mode, int act, int64_t y_bs) {
     const int cq = Cout >> 2;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t tile = id / cq;
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float *__restrict__
         for (int j = 0; j < 4; ++j) {
             const int ow = 4 * tw + j;
             if (ow >= W) break;
-            const int64_t off = (((int64_t)n * H + oh) * W + ow) * Cout + c4;
+            const int64_t off = (((int64_t)n * H + oh) * W + ow) * Cout + c4;      // mask / add: dense
+            const int64_t yoff = (int64_t)n * y_bs + ((int64_t)oh * W + ow) * Cout + c4;   // y: batch stride y_bs (a slice of [B, A, n])
             float v[4] = {sc.x * o[j].x + sh.x, sc.y * o[j].y + sh.y, sc.z * o[j].z + sh.z, sc.w * o[j].w + sh.w};
             float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
             if (mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; }
@@ -134,10 +135,11 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float *__restrict__
                 if (mask_mode == 1) u = mk[k] > 0.f ? u : 0.f;
                 u += ad[k];
                 if (act == 1) u = fmaxf(u, 0.f);
+                else if (act == 2) u = 1.0f / (1.0f + expf(-u));
                 if (mask_mode == 2) u = mk[k] > 0.f ? u : 0.f;
                 v[k] = u;
             }
-            *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(y + yoff) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -279,14 +281,16 @@ extern "C" int rn_wino_input(const float *x, float *V, int N, int H, int W, int 
 
 extern "C" int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int64_t tile_offset, int64_t Tpad,
                               const float *scale, const float *shift, const float *add, const float *mask, int mask_mode,
-                              int act, void *stream) {
+                              int act, int64_t y_batch_stride, void *stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout & 3) || tile_offset < 0) return RN_EINVAL;
-    if (mask_mode < 0 || mask_mode > 2 || (mask_mode != 0) != (mask != nullptr) || act < 0 || act > 1) return RN_EINVAL;
+    if (mask_mode < 0 || mask_mode > 2 || (mask_mode != 0) != (mask != nullptr) || act < 0 || act > 2) return RN_EINVAL;
+    if (y_batch_stride == 0) y_batch_stride = (int64_t)H * W * Cout;
+    if (y_batch_stride < (int64_t)H * W * Cout || (y_batch_stride & 3)) return RN_EINVAL;
     const int TH = (H + 3) / 4, TW = (W + 3) / 4;
     const int64_t tiles = (int64_t)N * TH * TW;
     if (tile_offset + tiles > Tpad) return RN_EINVAL;
     hipLaunchKernelGGL(wino_out_kernel, dim3(rn_blocks(tiles * (Cout >> 2), 256)), dim3(256), 0, (hipStream_t)stream, M, y, N, H,
-                       W, Cout, TH, TW, tile_offset, Tpad, scale, shift, add, mask, mask_mode, act);
+                       W, Cout, TH, TW, tile_offset, Tpad, scale, shift, add, mask, mask_mode, act, y_batch_stride);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -96,7 +96,7 @@ SIGNATURES.update({
     "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp]),
     "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "rn_wino_input": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
-    "rn_wino_output": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "rn_wino_output": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "rn_wino_weights": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rn_wino_dy": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "rn_wino_dw": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),

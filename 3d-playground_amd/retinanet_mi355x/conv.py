@@ -122,14 +122,14 @@ def _wino_workspace(device, floats_v, floats_m):
 
 
 def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
-                    flops=0.0, keep_v=False):
+                    flops=0.0, keep_v=False, cout=None, y_batch_stride=0):
     """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
     [36, Cout, Kpad]: input transform per problem into one V, ONE batched GEMM launch, output transform + epilogue
     per problem (dense outputs).  Returns the outputs."""
     lib = _hip.load()
     dev = xs[0].device
     C = xs[0].shape[3]
-    cout = U.shape[1]
+    cout = U.shape[1]                                # rows of the transformed weights = output channels
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
     Tpad = (T + 255) // 256 * 256
@@ -154,10 +154,10 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
         N, H, W, _ = x.shape
         add = None if adds is None else adds[i]
         mask = None if masks is None else masks[i]
-        nb = 4.0 * (36 * t * cout + outs[i].numel() * (1 + (add is not None) + (mask is not None)))
+        nb = 4.0 * (36 * t * cout + N * H * W * cout * (1 + (add is not None) + (mask is not None)))
         _hip.check(prof.timed("wino_output", nb, lambda: lib.rn_wino_output(
             M.data_ptr(), outs[i].data_ptr(), N, H, W, cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(add),
-            _hip.ptr(mask), mask_mode if mask is not None else 0, act, _hip.stream())), "rn_wino_output")
+            _hip.ptr(mask), mask_mode if mask is not None else 0, act, y_batch_stride, _hip.stream())), "rn_wino_output")
         off += t
     return (outs, V) if keep_v else outs
 

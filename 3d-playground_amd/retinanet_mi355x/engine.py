@@ -35,8 +35,9 @@ class Layer:
         # Winograd F(4x4,3x3) is available for 3x3 / stride 1 / padding 1 layers with whole 16-byte channel chunks; the
         # engine turns it on for the head towers in training (conv_wino.hip: 2.1-2.3x on those layers, ~1e-5 accuracy)
         self.wino_ok = spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
-        # worth it from 128 channels on (below, the 36 GEMMs have too short a K loop); set per step by the engine
-        self.wino_layer = self.wino_ok and spec.cin >= 128 and spec.cout >= 128
+        # worth it from 128 channels on one side and 64 on the other (below, the 36 GEMMs have too short a K loop or too
+        # few columns); set per step by the engine
+        self.wino_layer = self.wino_ok and min(spec.cin, spec.cout) >= 64 and max(spec.cin, spec.cout) >= 128
         self.wino_active = False
         self.reset()
 
@@ -106,10 +107,10 @@ class Layer:
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only)."""
         s = self.spec
-        if (wino or self.wino_active) and self.wino_ok and outs is None and act in (cv.ACT_NONE, cv.ACT_RELU):
+        if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
-            ys, self.saved_v = cv.wino_conv_group(xs, self.wino_weights(0), scale=self.scale, shift=self.shift, act=act,
-                                                  flops=fl, keep_v=True)
+            ys, self.saved_v = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift,
+                                                  act=act, flops=fl, keep_v=True, y_batch_stride=y_batch_stride or 0)
             return ys
         probs, ys, fl = [], [], 0.0
         for i, x in enumerate(xs):
@@ -392,8 +393,7 @@ class Engine:
                                        B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device)
                 gs.append(g.view(B, Hh, Ww, Lout.cout_pad))
                 off += cnt
-            for li in range(5):                                           # wgrad: split-K already fills the GPU per level
-                Lout.bwd_params(gs[li], acts[li][3])
+            Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
             gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
             for i in (3, 2, 1):
                 tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino)

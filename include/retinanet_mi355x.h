@@ -304,15 +304,16 @@ int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, f
  *                   share one V;
  *   (GEMM)          rn_conv_igemm as a 1x1 convolution over 36 images of Tpad pixels with w_batch_stride = rows * Kpad:
  *                   M [36][Tpad][Cout] = V_p x U_p^T;
- *   rn_wino_output  M -> y [N,H,W,Cout] (dense): A^T m A, then v = scale*v + shift; mask_mode 1: v = mask > 0 ? v : 0;
- *                   v += add; act 1: ReLU; mask_mode 2: v = mask > 0 ? v : 0  (mask / add: geometry of y, may be NULL);
+ *   rn_wino_output  M -> y [N,H,W,Cout]: A^T m A, then v = scale*v + shift; mask_mode 1: v = mask > 0 ? v : 0;
+ *                   v += add; act 1: ReLU, 2: sigmoid; mask_mode 2: v = mask > 0 ? v : 0  (mask / add: dense geometry of
+ *                   y, may be NULL); y_batch_stride (floats, 0 = dense) lets a head write into its slice of [B, A, n];
  *   rn_wino_weights U [36][rows][Kpad] from the OIHW parameter: mode 0 forward (rows = Cout, K = Cin), mode 1 data
  *                   gradient (rows = Cin, K = Cout, filter rotated by 180 degrees, times scale[co]); Kpad = K rounded up to 32.
  * Accuracy: ~1e-5 of the output's max magnitude (the direct kernel: ~3e-7). */
 int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);
 int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int64_t tile_offset, int64_t Tpad,
                    const float *scale, const float *shift, const float *add, const float *mask, int mask_mode, int act,
-                   void *stream);
+                   int64_t y_batch_stride, void *stream);
 int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int mode, const float *scale, void *stream);
 /* Weight gradient of the same convolutions:  dL/dg = G^T [ sum over tiles (A dy A^T) .* (B^T d B) ] G.
  *   rn_wino_dy   dy [N,H,W,C] -> Z [36][Tpad][C] (A dy A^T of every 4x4 tile; same tile order as rn_wino_input);
