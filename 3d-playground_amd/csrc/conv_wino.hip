@@ -46,16 +46,50 @@ __device__ __forceinline__ void at6(const float4 m[6], float4 o[4]) {
     o[3] = d12 + 8.f * d34 + m[5];
 }
 
+
+// Grouped launches: up to RN_MAX_GROUP problems (pyramid levels) whose tiles are concatenated in V / M / Z in table
+// order, so a global tile index is both the row of the transformed tensor and, through the table, a (problem, n, th, tw).
+struct WinoProblem { int N, H, W, TH, TW; };
+struct WinoTable {
+    int n;
+    int64_t tile_end[RN_MAX_GROUP];              // exclusive prefix sums of the problems' tile counts
+    WinoProblem p[RN_MAX_GROUP];
+    const float *src[RN_MAX_GROUP];              // x / dy (input transforms), unused by the output transform
+    float *dst[RN_MAX_GROUP];                    // y (output transform)
+    const float *add[RN_MAX_GROUP];
+    const float *mask[RN_MAX_GROUP];
+};
+__device__ __forceinline__ int wino_locate(const WinoTable &g, int64_t gt, int64_t &local) {
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) q += (i + 1 < g.n && gt >= g.tile_end[i]) ? 1 : 0;
+    int64_t first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (q == i) first = g.tile_end[i - 1];
+    local = gt - first;
+    return q;
+}
+
 // ---------------------------------------------------------------------------------------------- input transform
-__global__ __launch_bounds__(256) void wino_in_kernel(const float *__restrict__ x, float *__restrict__ V, int N, int H, int W,
-                                                      int C, int TH, int TW, int64_t t0, int64_t Tpad) {
+#define WINO_SELECT(q, g, pr, EXTRA)                          \
+    WinoProblem pr = g.p[0];                                   \
+    _Pragma("unroll") for (int i_ = 1; i_ < RN_MAX_GROUP; ++i_) \
+        if (q == i_) { pr = g.p[i_]; EXTRA }
+
+__global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *__restrict__ V, int C, int64_t t0, int64_t Tpad) {
     const int cq = C >> 2;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t tile = id / cq;
-    if (tile >= (int64_t)N * TH * TW) return;
-    const int c4 = (int)(id - tile * cq) * 4;
-    const int n = (int)(tile / (TH * TW));
-    const int r = (int)(tile - (int64_t)n * TH * TW);
+    const int64_t gt = id / cq;
+    if (gt >= g.tile_end[g.n - 1]) return;
+    const int c4 = (int)(id - gt * cq) * 4;
+    int64_t tile;
+    const int q = wino_locate(g, gt, tile);
+    const float *x = g.src[0];
+    WINO_SELECT(q, g, pr, x = g.src[i_];)
+    const int H = pr.H, W = pr.W, TW = pr.TW;
+    const int n = (int)(tile / (pr.TH * TW));
+    const int r = (int)(tile - (int64_t)n * pr.TH * TW);
     const int th = r / TW, tw = r - th * TW;
     const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
     const float *xb = x + (int64_t)n * H * W * C + c4;
@@ -74,7 +108,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 6; ++i) t[i][j] = o[i];
     }
-    float *vb = V + (t0 + tile) * C + c4;
+    float *vb = V + (t0 + gt) * C + c4;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {                              // rows: V[i][.] = t[i][.] B
         float4 o[6];
@@ -86,20 +120,24 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float *__restrict__ 
 
 // ---------------------------------------------------------------------------------------------- output transform
 // mask_mode / add / act as in rn_conv_desc (mask and add have the geometry of y, dense [N,H,W,Cout]).
-__global__ __launch_bounds__(256) void wino_out_kernel(const float *__restrict__ M, float *__restrict__ y, int N, int H, int W,
-                                                       int Cout, int TH, int TW, int64_t t0, int64_t Tpad,
-                                                       const float *__restrict__ scale, const float *__restrict__ shift,
-                                                       const float *__restrict__ add, const float *__restrict__ mask,
-                                                       int mask_mode, int act, int64_t y_bs) {
+__global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const float *__restrict__ M, int Cout, int64_t t0,
+                                                       int64_t Tpad, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, int mask_mode, int act, int64_t y_bs) {
     const int cq = Cout >> 2;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t tile = id / cq;
-    if (tile >= (int64_t)N * TH * TW) return;
-    const int c4 = (int)(id - tile * cq) * 4;
-    const int n = (int)(tile / (TH * TW));
-    const int r = (int)(tile - (int64_t)n * TH * TW);
+    const int64_t gt = id / cq;
+    if (gt >= g.tile_end[g.n - 1]) return;
+    const int c4 = (int)(id - gt * cq) * 4;
+    int64_t tile;
+    const int q = wino_locate(g, gt, tile);
+    float *y = g.dst[0];
+    const float *add = g.add[0], *mask = g.mask[0];
+    WINO_SELECT(q, g, pr, y = g.dst[i_]; add = g.add[i_]; mask = g.mask[i_];)
+    const int H = pr.H, W = pr.W, TW = pr.TW;
+    const int n = (int)(tile / (pr.TH * TW));
+    const int r = (int)(tile - (int64_t)n * pr.TH * TW);
     const int th = r / TW, tw = r - th * TW;
-    const float *mb = M + (t0 + tile) * Cout + c4;
+    const float *mb = M + (t0 + gt) * Cout + c4;
     float4 t[4][6];                                           // t[i][j] = (A^T m)[i][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -113,6 +151,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float *__restrict__
     float4 sc = f4(1.f), sh = f4(0.f);
     if (scale) sc = *reinterpret_cast<const float4 *>(scale + c4);
     if (shift) sh = *reinterpret_cast<const float4 *>(shift + c4);
+    const int64_t ybs = y_bs ? y_bs : (int64_t)H * W * Cout;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float4 o[4];
@@ -124,11 +163,11 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float *__restrict__
             const int ow = 4 * tw + j;
             if (ow >= W) break;
             const int64_t off = (((int64_t)n * H + oh) * W + ow) * Cout + c4;      // mask / add: dense
-            const int64_t yoff = (int64_t)n * y_bs + ((int64_t)oh * W + ow) * Cout + c4;   // y: batch stride y_bs (a slice of [B, A, n])
+            const int64_t yoff = (int64_t)n * ybs + ((int64_t)oh * W + ow) * Cout + c4;   // y: batch stride (a slice of [B, A, n])
             float v[4] = {sc.x * o[j].x + sh.x, sc.y * o[j].y + sh.y, sc.z * o[j].z + sh.z, sc.w * o[j].w + sh.w};
             float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
-            if (mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; }
-            if (add) { const float4 q = *reinterpret_cast<const float4 *>(add + off); ad[0] = q.x; ad[1] = q.y; ad[2] = q.z; ad[3] = q.w; }
+            if (mask_mode != 0) { const float4 q4 = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q4.x; mk[1] = q4.y; mk[2] = q4.z; mk[3] = q4.w; }
+            if (add) { const float4 q4 = *reinterpret_cast<const float4 *>(add + off); ad[0] = q4.x; ad[1] = q4.y; ad[2] = q4.z; ad[3] = q4.w; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float u = v[k];
@@ -205,15 +244,19 @@ __device__ __forceinline__ void a6(const float4 v[4], float4 o[6]) {
     o[5] = v[3];
 }
 
-__global__ __launch_bounds__(256) void wino_dy_kernel(const float *__restrict__ dy, float *__restrict__ Z, int N, int H, int W,
-                                                      int C, int TH, int TW, int64_t t0, int64_t Tpad) {
+__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoTable g, float *__restrict__ Z, int C, int64_t t0, int64_t Tpad) {
     const int cq = C >> 2;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t tile = id / cq;
-    if (tile >= (int64_t)N * TH * TW) return;
-    const int c4 = (int)(id - tile * cq) * 4;
-    const int n = (int)(tile / (TH * TW));
-    const int r = (int)(tile - (int64_t)n * TH * TW);
+    const int64_t gt = id / cq;
+    if (gt >= g.tile_end[g.n - 1]) return;
+    const int c4 = (int)(id - gt * cq) * 4;
+    int64_t tile;
+    const int q = wino_locate(g, gt, tile);
+    const float *dy = g.src[0];
+    WINO_SELECT(q, g, pr, dy = g.src[i_];)
+    const int H = pr.H, W = pr.W, TW = pr.TW;
+    const int n = (int)(tile / (pr.TH * TW));
+    const int r = (int)(tile - (int64_t)n * pr.TH * TW);
     const int th = r / TW, tw = r - th * TW;
     const float *yb = dy + (int64_t)n * H * W * C + c4;
     float4 t[6][4];                                           // t[a][j] = (A dy)[a][j]
@@ -230,7 +273,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float *__restrict__ 
 #pragma unroll
         for (int a = 0; a < 6; ++a) t[a][j] = o[a];
     }
-    float *zb = Z + (t0 + tile) * C + c4;
+    float *zb = Z + (t0 + gt) * C + c4;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         float4 o[6];
@@ -267,32 +310,76 @@ __global__ void wino_dw_kernel(const float *__restrict__ dU, float *__restrict__
     }
 }
 
-extern "C" int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad,
-                             void *stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || tile_offset < 0) return RN_EINVAL;
-    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-    const int64_t tiles = (int64_t)N * TH * TW;
-    if (tile_offset + tiles > Tpad) return RN_EINVAL;
-    hipLaunchKernelGGL(wino_in_kernel, dim3(rn_blocks(tiles * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W,
-                       C, TH, TW, tile_offset, Tpad);
+// Host side: validate a group and build the device table.
+static int wino_table(const rn_wino_group *g, WinoTable &t) {
+    if (!g || g->n < 1 || g->n > RN_MAX_GROUP) return RN_EINVAL;
+    t.n = g->n;
+    int64_t end = 0;
+    for (int i = 0; i < RN_MAX_GROUP; ++i) {
+        const int k = i < g->n ? i : g->n - 1;               // unused slots repeat the last problem (never selected)
+        if (g->N[k] <= 0 || g->H[k] <= 0 || g->W[k] <= 0) return RN_EINVAL;
+        t.p[i].N = g->N[k]; t.p[i].H = g->H[k]; t.p[i].W = g->W[k];
+        t.p[i].TH = (g->H[k] + 3) / 4; t.p[i].TW = (g->W[k] + 3) / 4;
+        if (i < g->n) end += (int64_t)g->N[k] * t.p[i].TH * t.p[i].TW;
+        t.tile_end[i] = end;
+        t.src[i] = g->src[k]; t.dst[i] = g->dst[k]; t.add[i] = g->add[k]; t.mask[i] = g->mask[k];
+    }
+    return RN_OK;
+}
+
+extern "C" int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form,
+                                   void *stream) {
+    WinoTable t;
+    const int rc = wino_table(g, t);
+    if (rc) return rc;
+    if (C <= 0 || (C & 3) || tile_offset < 0 || tile_offset + t.tile_end[t.n - 1] > Tpad) return RN_EINVAL;
+    for (int i = 0; i < t.n; ++i)
+        if (!t.src[i]) return RN_EINVAL;
+    const dim3 grid(rn_blocks(t.tile_end[t.n - 1] * (C >> 2), 256));
+    if (dy_form) hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad);
+    else hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
 
+extern "C" int rn_wino_output_group(const rn_wino_group *g, const float *M, int Cout, int64_t tile_offset, int64_t Tpad,
+                                    const float *scale, const float *shift, int mask_mode, int act, int64_t y_batch_stride,
+                                    void *stream) {
+    WinoTable t;
+    const int rc = wino_table(g, t);
+    if (rc) return rc;
+    if (Cout <= 0 || (Cout & 3) || tile_offset < 0 || tile_offset + t.tile_end[t.n - 1] > Tpad) return RN_EINVAL;
+    if (mask_mode < 0 || mask_mode > 2 || act < 0 || act > 2 || y_batch_stride < 0 || (y_batch_stride & 3)) return RN_EINVAL;
+    for (int i = 0; i < t.n; ++i) {
+        if (!t.dst[i] || (mask_mode != 0) != (t.mask[i] != nullptr)) return RN_EINVAL;
+        if (y_batch_stride && y_batch_stride < (int64_t)t.p[i].H * t.p[i].W * Cout) return RN_EINVAL;
+    }
+    hipLaunchKernelGGL(wino_out_kernel, dim3(rn_blocks(t.tile_end[t.n - 1] * (Cout >> 2), 256)), dim3(256), 0,
+                       (hipStream_t)stream, t, M, Cout, tile_offset, Tpad, scale, shift, mask_mode, act, y_batch_stride);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// Single-problem forms.
+static rn_wino_group wino_single(const float *src, float *dst, const float *add, const float *mask, int N, int H, int W) {
+    rn_wino_group g = {};
+    g.n = 1; g.N[0] = N; g.H[0] = H; g.W[0] = W; g.src[0] = src; g.dst[0] = dst; g.add[0] = add; g.mask[0] = mask;
+    return g;
+}
+extern "C" int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad,
+                             void *stream) {
+    const rn_wino_group g = wino_single(x, nullptr, nullptr, nullptr, N, H, W);
+    return rn_wino_input_group(&g, V, C, tile_offset, Tpad, 0, stream);
+}
+extern "C" int rn_wino_dy(const float *dy, float *Z, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream) {
+    const rn_wino_group g = wino_single(dy, nullptr, nullptr, nullptr, N, H, W);
+    return rn_wino_input_group(&g, Z, C, tile_offset, Tpad, 1, stream);
+}
 extern "C" int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int64_t tile_offset, int64_t Tpad,
                               const float *scale, const float *shift, const float *add, const float *mask, int mask_mode,
                               int act, int64_t y_batch_stride, void *stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout & 3) || tile_offset < 0) return RN_EINVAL;
-    if (mask_mode < 0 || mask_mode > 2 || (mask_mode != 0) != (mask != nullptr) || act < 0 || act > 2) return RN_EINVAL;
-    if (y_batch_stride == 0) y_batch_stride = (int64_t)H * W * Cout;
-    if (y_batch_stride < (int64_t)H * W * Cout || (y_batch_stride & 3)) return RN_EINVAL;
-    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-    const int64_t tiles = (int64_t)N * TH * TW;
-    if (tile_offset + tiles > Tpad) return RN_EINVAL;
-    hipLaunchKernelGGL(wino_out_kernel, dim3(rn_blocks(tiles * (Cout >> 2), 256)), dim3(256), 0, (hipStream_t)stream, M, y, N, H,
-                       W, Cout, TH, TW, tile_offset, Tpad, scale, shift, add, mask, mask_mode, act, y_batch_stride);
-    RN_LAUNCH_CHECK();
-    return RN_OK;
+    const rn_wino_group g = wino_single(nullptr, y, add, mask, N, H, W);
+    return rn_wino_output_group(&g, M, Cout, tile_offset, Tpad, scale, shift, mask_mode, act, y_batch_stride, stream);
 }
 
 extern "C" int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int mode, const float *scale, void *stream) {
@@ -301,17 +388,6 @@ extern "C" int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int 
     const int Kpad = ((mode == 0 ? Cin : Cout) + 31) / 32 * 32;
     hipLaunchKernelGGL(wino_weight_kernel, dim3(rn_blocks((int64_t)rows * Kpad, 256)), dim3(256), 0, (hipStream_t)stream, w, U,
                        Cout, Cin, mode, scale, rows, Kpad);
-    RN_LAUNCH_CHECK();
-    return RN_OK;
-}
-
-extern "C" int rn_wino_dy(const float *dy, float *Z, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || tile_offset < 0) return RN_EINVAL;
-    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-    const int64_t tiles = (int64_t)N * TH * TW;
-    if (tile_offset + tiles > Tpad) return RN_EINVAL;
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(rn_blocks(tiles * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, dy, Z, N, H, W,
-                       C, TH, TW, tile_offset, Tpad);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

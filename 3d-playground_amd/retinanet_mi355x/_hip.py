@@ -77,7 +77,16 @@ class ConvGroup(ctypes.Structure):
                 ("mask", c_vp * RN_MAX_GROUP)]
 
 
+class WinoGroup(ctypes.Structure):
+    """rn_wino_group of include/retinanet_mi355x.h."""
+    _fields_ = [("n", c_i32), ("N", c_i32 * RN_MAX_GROUP), ("H", c_i32 * RN_MAX_GROUP), ("W", c_i32 * RN_MAX_GROUP),
+                ("src", c_vp * RN_MAX_GROUP), ("dst", c_vp * RN_MAX_GROUP), ("add", c_vp * RN_MAX_GROUP),
+                ("mask", c_vp * RN_MAX_GROUP)]
+
+
 SIGNATURES.update({
+    "rn_wino_input_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
+    "rn_wino_output_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_splitk_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -111,6 +111,33 @@ def wino_weights(weight, mode=0, scale=None):
 _WINO_WS = {}
 
 
+def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None):
+    """rn_wino_group for problems shaped like xs ([N,H,W,.]); at most RN_MAX_GROUP of them."""
+    g = _hip.WinoGroup()
+    g.n = len(xs)
+    for i, x in enumerate(xs):
+        g.N[i], g.H[i], g.W[i] = x.shape[0], x.shape[1], x.shape[2]
+        g.src[i] = None if srcs is None else srcs[i].data_ptr()
+        g.dst[i] = None if dsts is None else dsts[i].data_ptr()
+        g.add[i] = None if adds is None or adds[i] is None else adds[i].data_ptr()
+        g.mask[i] = None if masks is None or masks[i] is None else masks[i].data_ptr()
+    return g
+
+
+def _wino_transform_in(xs, V, C, Tpad, dy_form):
+    """Input-side transform of every problem of xs into V, RN_MAX_GROUP problems per launch."""
+    lib = _hip.load()
+    off = 0
+    for k in range(0, len(xs), _hip.RN_MAX_GROUP):
+        part = xs[k:k + _hip.RN_MAX_GROUP]
+        t = sum(x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in part)
+        g = _wino_group(part, srcs=part)
+        nb = 4.0 * (sum(x.numel() for x in part) + 36 * t * C)
+        _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_group(
+            ctypes.byref(g), V.data_ptr(), C, off, Tpad, dy_form, _hip.stream())), "rn_wino_input_group")
+        off += t
+
+
 def _wino_workspace(device, floats_v, floats_m):
     """V and M of the Winograd path: two scratch tensors per device, grown on demand and reused by every layer."""
     ws = _WINO_WS.get(device)
@@ -136,12 +163,8 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     V, M = _wino_workspace(dev, 0 if keep_v else 36 * Tpad * C, 36 * Tpad * cout)
     if keep_v:                                       # the caller keeps B^T d B of the inputs for the weight gradient
         V = torch.empty(36 * Tpad * C, dtype=torch.float32, device=dev)
-    off = 0
-    for x, t in zip(xs, tiles):
-        N, H, W, _ = x.shape
-        _hip.check(prof.timed("wino_input", 4.0 * (x.numel() + 36 * t * C), lambda: lib.rn_wino_input(x.data_ptr(), V.data_ptr(), N, H, W, C, off, Tpad,
-                                                                          _hip.stream())), "rn_wino_input")
-        off += t
+    assert all(x.is_contiguous() for x in xs)
+    _wino_transform_in(xs, V, C, Tpad, 0)
     # rows past T hold whatever the scratch tensor held: they produce rows of M nobody reads
     Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
     Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)
@@ -150,14 +173,18 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     if outs is None:
         outs = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in xs]
     off = 0
-    for i, (x, t) in enumerate(zip(xs, tiles)):
-        N, H, W, _ = x.shape
-        add = None if adds is None else adds[i]
-        mask = None if masks is None else masks[i]
-        nb = 4.0 * (36 * t * cout + N * H * W * cout * (1 + (add is not None) + (mask is not None)))
-        _hip.check(prof.timed("wino_output", nb, lambda: lib.rn_wino_output(
-            M.data_ptr(), outs[i].data_ptr(), N, H, W, cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), _hip.ptr(add),
-            _hip.ptr(mask), mask_mode if mask is not None else 0, act, y_batch_stride, _hip.stream())), "rn_wino_output")
+    for k in range(0, len(xs), _hip.RN_MAX_GROUP):
+        sl = slice(k, k + _hip.RN_MAX_GROUP)
+        part, t = xs[sl], sum(tiles[sl])
+        pa = None if adds is None else adds[sl]
+        pm = None if masks is None else masks[sl]
+        g = _wino_group(part, dsts=outs[sl], adds=pa, masks=pm)
+        has_mask = pm is not None and pm[0] is not None
+        nops = 1 + (pa is not None and pa[0] is not None) + has_mask
+        nb = 4.0 * (36 * t * cout + nops * sum(x.shape[0] * x.shape[1] * x.shape[2] for x in part) * cout)
+        _hip.check(prof.timed("wino_output", nb, lambda: lib.rn_wino_output_group(
+            ctypes.byref(g), M.data_ptr(), cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), mask_mode if has_mask else 0,
+            act, y_batch_stride, _hip.stream())), "rn_wino_output_group")
         off += t
     return (outs, V) if keep_v else outs
 
@@ -175,16 +202,10 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
     Vw, Z = _wino_workspace(dev, 0 if have_v else 36 * Tpad * C, 36 * Tpad * cout)
     if not have_v:
         V = Vw
-    off = 0
-    for x, g, t in zip(xs, gs, tiles):
-        N, H, W, _ = x.shape
-        assert g.shape[:3] == x.shape[:3] and g.is_contiguous() and x.is_contiguous()
-        if not have_v:
-            _hip.check(prof.timed("wino_input", 4.0 * (x.numel() + 36 * t * C), lambda: lib.rn_wino_input(
-                x.data_ptr(), V.data_ptr(), N, H, W, C, off, Tpad, _hip.stream())), "rn_wino_input")
-        _hip.check(prof.timed("wino_input", 4.0 * (g.numel() + 36 * t * cout), lambda: lib.rn_wino_dy(
-            g.data_ptr(), Z.data_ptr(), N, H, W, cout, off, Tpad, _hip.stream())), "rn_wino_dy")
-        off += t
+    assert all(g.shape[:3] == x.shape[:3] and g.is_contiguous() and x.is_contiguous() for g, x in zip(gs, xs))
+    if not have_v:
+        _wino_transform_in(xs, V, C, Tpad, 0)
+    _wino_transform_in(gs, Z, cout, Tpad, 1)
     ku = (C + 31) // 32 * 32
     dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
     rc = prof.timed("conv_wgrad", 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(    # executed FLOPs

@@ -310,6 +310,20 @@ int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, f
  *   rn_wino_weights U [36][rows][Kpad] from the OIHW parameter: mode 0 forward (rows = Cout, K = Cin), mode 1 data
  *                   gradient (rows = Cin, K = Cout, filter rotated by 180 degrees, times scale[co]); Kpad = K rounded up to 32.
  * Accuracy: ~1e-5 of the output's max magnitude (the direct kernel: ~3e-7). */
+/* Grouped forms: up to RN_MAX_GROUP problems (the pyramid levels of a head layer) in one launch; their tiles are
+ * concatenated in V / M / Z in table order starting at row tile_offset.  src: x or dy per problem (input transforms,
+ * dy_form = 1 for A dy A^T); dst / add / mask: per problem for the output transform (add, mask may be NULL). */
+typedef struct rn_wino_group {
+    int n;
+    int N[RN_MAX_GROUP], H[RN_MAX_GROUP], W[RN_MAX_GROUP];
+    const float *src[RN_MAX_GROUP];
+    float *dst[RN_MAX_GROUP];
+    const float *add[RN_MAX_GROUP];
+    const float *mask[RN_MAX_GROUP];
+} rn_wino_group;
+int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form, void *stream);
+int rn_wino_output_group(const rn_wino_group *g, const float *M, int Cout, int64_t tile_offset, int64_t Tpad,
+                         const float *scale, const float *shift, int mask_mode, int act, int64_t y_batch_stride, void *stream);
 int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);
 int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int64_t tile_offset, int64_t Tpad,
                    const float *scale, const float *shift, const float *add, const float *mask, int mask_mode, int act,
