@@ -34,13 +34,13 @@
 // e.g. 1x1 64->256 at 270x480 moves 1.33 GB per 34 GFLOP.
 #include "conv_igemm_tile.h"
 
-template <int WM, int WN, bool GENERAL, int BK, bool RELU = false>
+template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false>
 __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                             const float *__restrict__ w, float *__restrict__ y,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                                             const float *__restrict__ add, const float *__restrict__ mask,
                                                             const float *__restrict__ add2) {
-    conv_igemm_tile<WM, WN, GENERAL, BK, RELU>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_igemm_tile<WM, WN, GENERAL, BK, RELU, RAW>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch: the workgroup looks up which problem its tile belongs to (wave-uniform compare chain, static
@@ -110,7 +110,10 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G, K>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
     // K-step 16 (34-41 KB of LDS, four workgroups per CU) everywhere: with the operands arriving by direct-to-LDS loads it
     // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
-    if (d->in_relu) {
+    const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0;
+    if (raw) {                                                           // a plain GEMM: the Winograd stage
+        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, false, 16, false, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
+    } else if (d->in_relu) {
         hipLaunchKernelGGL((conv_igemm_kernel<2, 2, true, 16, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
     } else if (narrow) {
         if (dense) RN_LAUNCH_IGEMM(4, 1, false, 16); else RN_LAUNCH_IGEMM(4, 1, true, 16);

@@ -94,7 +94,7 @@ __device__ __forceinline__ int lds_swz(int row) {
     return BK == 32 ? ((row & 7) ^ ((row >> 3) & 7)) : ((row >> 2) & 3);
 }
 
-template <int WM, int WN, bool GENERAL, int BK, bool RELU = false>
+template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false>
 __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const float *__restrict__ x,
                                                 const float *__restrict__ w, float *__restrict__ y,
                                                 const float *__restrict__ scale, const float *__restrict__ shift,
@@ -291,6 +291,24 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         __syncthreads();                                    // ... and everybody's; buffer rb is free
         rb = rb == NBUF - 1 ? 0 : rb + 1;
         wb = wb == NBUF - 1 ? 0 : wb + 1;
+    }
+
+    // ---- RAW: a plain GEMM (no scale / shift / addend / mask / activation, dense output: the Winograd GEMMs) stores
+    // straight from the accumulators -- every instruction writes two full 128-byte row segments -- and skips the LDS
+    // staging with its two barriers, which is a measurable share of a 16-step K loop.
+    if constexpr (RAW) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t m = (int64_t)m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < M && col < d.Cout) y[m * d.Cout + col] = acc[tm][tn][e];
+                }
+            }
+        return;
     }
 
     // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add (+ add2); act; [mask after]

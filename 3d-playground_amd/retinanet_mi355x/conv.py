@@ -186,7 +186,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
             ctypes.byref(g), M.data_ptr(), cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), mask_mode if has_mask else 0,
             act, y_batch_stride, _hip.stream())), "rn_wino_output_group")
         off += t
-    return (outs, V) if keep_v else outs
+    return (outs, (V, tuple(tuple(x.shape) for x in xs))) if keep_v else outs   # V + the shapes it belongs to
 
 
 def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
@@ -198,7 +198,9 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
     Tpad = (T + 255) // 256 * 256
-    have_v = V is not None and V.numel() == 36 * Tpad * C      # V: B^T d B of xs kept by the forward (same grouping)
+    # V: (B^T d B of the forward's inputs, their shapes) kept by wino_conv_group(keep_v=True); used only for the same grouping
+    have_v = V is not None and V[1] == tuple(tuple(x.shape) for x in xs) and V[0].numel() == 36 * Tpad * C
+    V = V[0] if have_v else None
     Vw, Z = _wino_workspace(dev, 0 if have_v else 36 * Tpad * C, 36 * Tpad * cout)
     if not have_v:
         V = Vw
