@@ -39,6 +39,8 @@ class Layer:
         # few columns); set per step by the engine
         self.wino_layer = self.wino_ok and min(spec.cin, spec.cout) >= 64 and max(spec.cin, spec.cout) >= 128
         self.wino_active = False
+        self.keep_v = True
+        self._cache = None
         self.reset()
 
     def reset(self):
@@ -50,6 +52,7 @@ class Layer:
     # ---- per-step preparation
     def prepare(self, P, cache):
         s = self.spec
+        self._cache = cache
         w = P[s.name + ".weight"]
         self.weight = w
         self.wf = cache.get(("wf", s.name), w, lambda: cv.pack_weights(w, 0, kw_pad=self.kw_pad, c_pad=self.cin_pad))
@@ -69,7 +72,8 @@ class Layer:
         """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
         if mode == 0:
             if self.uf is None:
-                self.uf = cv.wino_weights(self.weight, 0)
+                self.uf = self._cache.get(("uf", self.spec.name), self.weight, lambda: cv.wino_weights(self.weight, 0)) \
+                    if self._cache is not None else cv.wino_weights(self.weight, 0)
             return self.uf
         if self.ud is None:
             self.ud = cv.wino_weights(self.weight, 1, scale=self.scale)
@@ -93,8 +97,8 @@ class Layer:
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
         if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
                 and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
-            ys, self.saved_v = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act,
-                                                  keep_v=True)
+            r = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, keep_v=self.keep_v)
+            ys, self.saved_v = r if self.keep_v else (r, None)
             return ys[0]
         if out is None:
             out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
@@ -109,8 +113,9 @@ class Layer:
         s = self.spec
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
-            ys, self.saved_v = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift,
-                                                  act=act, flops=fl, keep_v=True, y_batch_stride=y_batch_stride or 0)
+            r = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift, act=act, flops=fl,
+                                   keep_v=self.keep_v, y_batch_stride=y_batch_stride or 0)
+            ys, self.saved_v = r if self.keep_v else (r, None)
             return ys
         probs, ys, fl = [], [], 0.0
         for i, x in enumerate(xs):
@@ -242,6 +247,8 @@ class Engine:
         self.grad_hook = None                      # callable({name: grad}) as soon as a layer's gradients are final
         # Winograd for the head towers when activations are saved (= training); RN_WINOGRAD=0 keeps the direct kernels
         self.use_wino = os.environ.get("RN_WINOGRAD", "1") != "0"
+        # opt-in for inference as well (default off: eval keeps the ~1e-7 behaviour of the direct kernels)
+        self.wino_eval = os.environ.get("RN_WINOGRAD_EVAL", "0") == "1"
         # layers
         self.layers = {}
         self.blocks = []                            # [(prefix, [roles...])] in forward order
@@ -293,8 +300,9 @@ class Engine:
         in the stem's layout ([B,H,W,4] fp32, e.g. from ops.frame_ingest(nhwc4=True)); img is then ignored."""
         Ls = self.layers
         self._prepare(P)
-        for L in Ls.values():                              # Winograd where it pays, and only when training (save)
-            L.wino_active = bool(save and self.use_wino and L.wino_layer)
+        for L in Ls.values():                              # Winograd where it pays; in inference only on request
+            L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer)
+            L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow
         if x4 is None:
             _hip.need_gpu(img)
             x4 = cv.nchw_to_nhwc4(img)
