@@ -141,6 +141,36 @@ def test_winograd_group_fprop_and_dgrad(cv, dev):
         close(nchw(dx), ref, tol=1e-4)
 
 
+@pytest.mark.parametrize("case", [(128, 192, 1, 13, 18), (192, 64, 3, 7, 5), (64, 128, 2, 4, 4)])
+def test_winograd_single_epilogues(cv, dev, case):
+    """Winograd path on one problem with Cin != Cout: folded batch-norm scale / shift + ReLU forward; data gradient with
+    the scale folded into the weights, ReLU mask applied BEFORE the addend (mask_mode 1); weight gradient with the kept
+    input transform.  Against torch fp64."""
+    cin, cout, n, h, ww = case
+    w = rnd((cout, cin, 3, 3), 91, (2.0 / (9 * cin)) ** 0.5)
+    sc, sh = rnd((cout,), 92, 0.3).abs() + 0.5, rnd((cout,), 93, 0.1)
+    x = rnd((n, cin, h, ww), 94)
+    xg = nhwc(x).to(dev)
+    (y,), V = cv.wino_conv_group([xg], cv.wino_weights(w.to(dev), 0), scale=sc.to(dev), shift=sh.to(dev), act=cv.ACT_RELU,
+                                 keep_v=True)
+    conv = F.conv2d(x.double(), w.double(), None, 1, 1)
+    close(nchw(y), torch.relu(conv * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)), tol=1e-4)
+    g = rnd((n, cout, h, ww), 95)
+    a = rnd((n, cin, h, ww), 96)
+    (dx,) = cv.wino_conv_group([nhwc(g).to(dev)], cv.wino_weights(w.to(dev), 1, scale=sc.to(dev)), adds=[nhwc(a).to(dev)],
+                               masks=[xg], mask_mode=1)
+    ref = F.conv_transpose2d(g.double() * sc.double().view(1, -1, 1, 1), w.double(), None, 1, 1) * (x.double() > 0) + a.double()
+    close(nchw(dx), ref, tol=1e-4)
+    wr = w.double().requires_grad_(True)
+    (F.conv2d(x.double(), wr, None, 1, 1) * g.double()).sum().backward()
+    wp = cv.pack_weights(w.to(dev), 0)
+    dw = torch.zeros_like(wp)
+    cs = torch.zeros(cout, device=dev)
+    cv.wino_wgrad_group([nhwc(g).to(dev)], [xg], dw, cs, V=V)
+    close(cv.unpack_wgrad(dw, wp, tuple(w.shape))[0], wr.grad, tol=1e-4)
+    close(cs, g.double().sum(dim=(0, 2, 3)), tol=2e-5)
+
+
 def test_winograd_group_wgrad(cv, dev):
     """Winograd weight gradient + bias gradient over a small pyramid (partial tiles), against torch's fp64 conv2d backward."""
     cin, cout = 64, 128
