@@ -120,6 +120,56 @@ extern "C" int rn_bn_fold(const float *gamma, const float *beta, const float *me
     return RN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ batched preparation
+// A training step re-packs every weight tensor and re-folds every batch norm (the parameters have just changed):
+// ~230 launches of a few microseconds each.  Here they are TWO launches over a device-resident job table (the
+// optimizer's pattern, optim.hip): block b does chunk b = (job, block inside the job).  Two, because the data-gradient
+// packs read the batch-norm scale the first launch produces.
+__global__ __launch_bounds__(256) void prep_batched_kernel(const rn_prep_job *__restrict__ jobs, const int2 *__restrict__ chunks) {
+    const int2 c = chunks[blockIdx.x];
+    const rn_prep_job j = jobs[c.x];
+    const int64_t i = (int64_t)c.y * 256 + threadIdx.x;
+    if (j.kind == 0) {                                       // batch-norm folding, C = Cout
+        if (i >= j.Cout) return;
+        const float rs = 1.0f / sqrtf(j.var[i] + j.eps);
+        const float sc = j.gamma[i] * rs;
+        j.bn_scale[i] = sc;
+        j.bn_shift[i] = j.beta[i] - j.mean[i] * sc;
+        j.bn_rstd[i] = rs;
+        return;
+    }
+    if (i >= (int64_t)j.rows * j.Kpad) return;               // weight packing: the body of pack_weights_kernel
+    const int row = (int)(i / j.Kpad), k = (int)(i - (int64_t)row * j.Kpad);
+    const int tap = k / j.c_pad, ch = k - tap * j.c_pad;
+    int r = tap / j.kw_pad, s = tap - r * j.kw_pad;
+    bool in_filter = r < j.kh && s < j.kw;
+    if (j.mode == 2) {
+        r = tap / j.ns;
+        s = tap - r * j.ns;
+        in_filter = r < j.nr;
+        r = j.r0 + 2 * r;
+        s = j.s0 + 2 * s;
+    }
+    float v = 0.f;
+    if (in_filter) {
+        if (j.mode == 0) {
+            if (ch < j.Cin) v = j.src[(((int64_t)row * j.Cin + ch) * j.kh + r) * j.kw + s];
+        } else if (ch < j.Cout) {
+            v = j.src[(((int64_t)ch * j.Cin + row) * j.kh + r) * j.kw + s];
+            if (j.scale) v *= j.scale[ch];
+        }
+    }
+    j.dst[i] = v;
+}
+
+extern "C" int rn_prep_batched(const rn_prep_job *jobs_dev, const int32_t *chunks_dev, int nchunks, void *stream) {
+    if (!jobs_dev || !chunks_dev || nchunks <= 0) return RN_EINVAL;
+    hipLaunchKernelGGL(prep_batched_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, jobs_dev,
+                       reinterpret_cast<const int2 *>(chunks_dev));
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ layout
 __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ src, float4 *__restrict__ dst, int64_t HW, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // pixel index over N*H*W

@@ -77,6 +77,14 @@ class ConvGroup(ctypes.Structure):
                 ("mask", c_vp * RN_MAX_GROUP)]
 
 
+class PrepJob(ctypes.Structure):
+    """rn_prep_job of include/retinanet_mi355x.h."""
+    _fields_ = [("kind", c_i32)] + [(n, c_i32) for n in ("Cout", "Cin", "kh", "kw", "kw_pad", "c_pad", "mode", "r0", "nr", "s0",
+                                                          "ns", "rows", "Kpad")] + \
+               [("eps", c_f32), ("src", c_vp), ("dst", c_vp), ("scale", c_vp), ("gamma", c_vp), ("beta", c_vp), ("mean", c_vp),
+                ("var", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp), ("bn_rstd", c_vp)]
+
+
 class WinoGroup(ctypes.Structure):
     """rn_wino_group of include/retinanet_mi355x.h."""
     _fields_ = [("n", c_i32), ("N", c_i32 * RN_MAX_GROUP), ("H", c_i32 * RN_MAX_GROUP), ("W", c_i32 * RN_MAX_GROUP),
@@ -85,6 +93,7 @@ class WinoGroup(ctypes.Structure):
 
 
 SIGNATURES.update({
+    "rn_prep_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "rn_wino_input_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "rn_wino_output_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),

@@ -68,6 +68,23 @@ class Layer:
         self.dw = self.cs = None
         self.uf = self.ud = None
 
+    def adopt(self, P, cache, wf, bn, wd):
+        """Training step: take this step's packed weights / folded batch norm from the engine's batched preparation
+        (persistent buffers refreshed by two launches for the whole net) instead of one launch per tensor."""
+        s = self.spec
+        self._cache = cache
+        self.weight = P[s.name + ".weight"]
+        self.wf = wf
+        if s.bn:
+            self.mean = P[s.bn + ".running_mean"]
+            self.scale, self.shift, self.rstd = bn[0], bn[1], bn[2]
+        else:
+            self.scale = self.rstd = self.mean = None
+            self.shift = P[s.name + ".bias"].detach() if s.bias else None
+        self.wd = wd                                  # None: packed on demand (layers that normally take the Winograd path)
+        self.dw = self.cs = None
+        self.uf = self.ud = None
+
     def wino_weights(self, mode):
         """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
         if mode == 0:
@@ -279,6 +296,78 @@ class Engine:
         for L in self.layers.values():
             L.prepare(P, self.cache)
 
+    def _prepare_training(self, P):
+        """Per-step preparation of a TRAINING step in two launches (rn_prep_batched): every batch-norm fold and forward
+        weight pack, then every data-gradient pack (they read the folded scale).  The job tables and the destination
+        buffers persist; they are rebuilt when a parameter tensor has been replaced."""
+        key = tuple(P[n].data_ptr() for n in sorted(P) if n.endswith((".weight", ".bias", "running_mean", "running_var")))
+        prep = getattr(self, "_prep", None)
+        if prep is None or prep["key"] != key:
+            prep = self._prep = self._build_prep(P, key)
+        lib = _hip.load()
+        for jobs, chunks, n in prep["launches"]:
+            _hip.check(lib.rn_prep_batched(jobs.data_ptr(), chunks.data_ptr(), n, _hip.stream()), "rn_prep_batched")
+        for name, L in self.layers.items():
+            b = prep["bufs"][name]
+            L.adopt(P, self.cache, b["wf"], b.get("bn"), b.get("wd"))
+
+    def _build_prep(self, P, key):
+        dev = next(iter(P.values())).device
+        launches = [([], []), ([], [])]               # (jobs, chunks) of launch 0 (folds + forward packs) and 1 (dgrad packs)
+        bufs = {}
+
+        def add(which, job, nelem):
+            jobs, chunks = launches[which]
+            jobs.append(job)
+            chunks.extend((len(jobs) - 1, b) for b in range((nelem + 255) // 256))
+
+        def pack_job(w, dst, mode, kw_pad, c_pad, scale, taps=(0, 0, 0, 0)):
+            cout, cin, kh, kw = w.shape
+            j = _hip.PrepJob()
+            j.kind, j.Cout, j.Cin, j.kh, j.kw, j.kw_pad, j.c_pad, j.mode = 1, cout, cin, kh, kw, kw_pad, c_pad, mode
+            j.r0, j.nr, j.s0, j.ns = taps
+            j.rows, j.Kpad = dst.shape
+            j.src, j.dst, j.scale = w.data_ptr(), dst.data_ptr(), None if scale is None else scale.data_ptr()
+            return j
+
+        for name, L in self.layers.items():
+            s = L.spec
+            w = P[s.name + ".weight"]
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
+            cout, cin, kh, kw = w.shape
+            b = bufs[name] = {}
+            b["wf"] = torch.empty((cout, (kh * L.kw_pad * L.cin_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
+            add(0, pack_job(w, b["wf"], 0, L.kw_pad, L.cin_pad, None), b["wf"].numel())
+            scale = None
+            if s.bn:
+                bn = b["bn"] = torch.empty((3, cout), dtype=torch.float32, device=dev)
+                j = _hip.PrepJob()
+                j.kind, j.Cout, j.eps = 0, cout, arch.BN_EPS
+                j.gamma, j.beta = P[s.bn + ".weight"].data_ptr(), P[s.bn + ".bias"].data_ptr()
+                j.mean, j.var = P[s.bn + ".running_mean"].data_ptr(), P[s.bn + ".running_var"].data_ptr()
+                j.bn_scale, j.bn_shift, j.bn_rstd = bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr()
+                add(0, j, cout)
+                scale = bn[0]
+            if name == "conv1" or (self.use_wino and L.wino_layer):
+                continue                              # the stem has no data gradient; Winograd layers transform their own weights
+            if s.stride == 2 and s.k > 1:
+                b["wd"] = []
+                for c in cv.s2_classes(s.k, s.pad):
+                    r0, nr, s0, ns = c[2]
+                    d = torch.empty((cin, (nr * ns * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
+                    add(1, pack_job(w, d, 2, kw, L.cout_pad, scale, c[2]), d.numel())
+                    b["wd"].append(d)
+            else:
+                d = b["wd"] = torch.empty((cin, (kh * kw * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
+                add(1, pack_job(w, d, 1, kw, L.cout_pad, scale), d.numel())
+        out = []
+        for jobs, chunks in launches:
+            arr = (_hip.PrepJob * len(jobs))(*jobs)
+            jt = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            ct = torch.tensor(chunks, dtype=torch.int32).to(dev)
+            out.append((jt, ct, len(chunks)))
+        return {"key": key, "launches": out, "bufs": bufs}
+
     def _zero_grad_accumulators(self, device):
         """Weight-gradient and column-sum accumulators of every layer as views of ONE buffer, zeroed by one fill per step
         (they are atomically accumulated into: ~140 separate zero-fills per step otherwise)."""
@@ -299,7 +388,10 @@ class Engine:
         """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None).  x4: the input already
         in the stem's layout ([B,H,W,4] fp32, e.g. from ops.frame_ingest(nhwc4=True)); img is then ignored."""
         Ls = self.layers
-        self._prepare(P)
+        if save and os.environ.get("RN_BATCHED_PREP", "1") != "0":
+            self._prepare_training(P)
+        else:
+            self._prepare(P)
         for L in Ls.values():                              # Winograd where it pays; in inference only on request
             L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer)
             L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow

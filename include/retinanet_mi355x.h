@@ -338,6 +338,23 @@ int rn_wino_weights(const float *w, float *U, int Cout, int Cin, int mode, const
 int rn_wino_dy(const float *dy, float *Z, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);
 int rn_wino_dw(const float *dU, float *dw, int Cout, int Cin, void *stream);
 
+/* Batched per-step preparation: batch-norm folding (kind 0: bn_scale = gamma / sqrt(var + eps), bn_shift = beta - mean *
+ * bn_scale, bn_rstd) and weight packing (kind 1: the arguments of rn_pack_weights, rows / Kpad as it derives them) for
+ * many layers in one launch.  jobs_dev: device array of rn_prep_job; chunks_dev: device array of nchunks (job index,
+ * 256-element block inside the job) pairs.  Jobs of one launch must not depend on each other: the data-gradient packs
+ * (which read bn_scale) go in a second launch. */
+typedef struct rn_prep_job {
+    int kind;
+    int Cout, Cin, kh, kw, kw_pad, c_pad, mode, r0, nr, s0, ns, rows, Kpad;
+    float eps;
+    const float *src;
+    float *dst;
+    const float *scale;
+    const float *gamma, *beta, *mean, *var;
+    float *bn_scale, *bn_shift, *bn_rstd;
+} rn_prep_job;
+int rn_prep_batched(const rn_prep_job *jobs_dev, const int32_t *chunks_dev, int nchunks, void *stream);
+
 /* Weight packing.  src is the reference's OIHW parameter [Cout][Cin][kh][kw] (state_dict layout).
  *   mode 0 (forward):  dst[co][r][s][ci]          = src[co][ci][r][s]
  *   mode 1 (dgrad):    dst[ci][r][s][co]          = src[co][ci][r][s] * scale[co]   (scale NULL = 1)
