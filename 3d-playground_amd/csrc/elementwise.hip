@@ -138,7 +138,45 @@ __global__ __launch_bounds__(256) void prep_batched_kernel(const rn_prep_job *__
         j.bn_rstd[i] = rs;
         return;
     }
-    if (i >= (int64_t)j.rows * j.Kpad) return;               // weight packing: the body of pack_weights_kernel
+    if (i >= (int64_t)j.rows * j.Kpad) return;
+    if (j.kind == 2) {                                       // Winograd weight transform U = G g G^T (conv_wino.hip), mode 0 / 1
+        const int row = (int)(i / j.Kpad), k = (int)(i - (int64_t)row * j.Kpad);
+        const int kdim = j.mode == 0 ? j.Cin : j.Cout;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float v = 0.f;
+                if (k < kdim) {
+                    if (j.mode == 0) v = j.src[(((int64_t)row * j.Cin + k) * 3 + r) * 3 + s];
+                    else v = j.src[(((int64_t)k * j.Cin + row) * 3 + (2 - r)) * 3 + (2 - s)] * (j.scale ? j.scale[k] : 1.f);
+                }
+                g[r][s] = v;
+            }
+        float t[6][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float a = g[0][s], b = g[1][s], c = g[2][s];
+            t[0][s] = a * (1.f / 4.f);
+            t[1][s] = -(a + b + c) * (1.f / 6.f);
+            t[2][s] = (b - a - c) * (1.f / 6.f);
+            t[3][s] = a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f);
+            t[4][s] = a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f);
+            t[5][s] = c;
+        }
+#pragma unroll
+        for (int a6i = 0; a6i < 6; ++a6i) {
+            const float a = t[a6i][0], b = t[a6i][1], c = t[a6i][2];
+            const float o[6] = {a * (1.f / 4.f), -(a + b + c) * (1.f / 6.f), (b - a - c) * (1.f / 6.f),
+                                a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f),
+                                a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f), c};
+#pragma unroll
+            for (int b6 = 0; b6 < 6; ++b6) j.dst[((int64_t)(a6i * 6 + b6) * j.rows + row) * j.Kpad + k] = o[b6];
+        }
+        return;
+    }
+    // weight packing: the body of pack_weights_kernel
     const int row = (int)(i / j.Kpad), k = (int)(i - (int64_t)row * j.Kpad);
     const int tap = k / j.c_pad, ch = k - tap * j.c_pad;
     int r = tap / j.kw_pad, s = tap - r * j.kw_pad;

@@ -68,7 +68,7 @@ class Layer:
         self.dw = self.cs = None
         self.uf = self.ud = None
 
-    def adopt(self, P, cache, wf, bn, wd):
+    def adopt(self, P, cache, wf, bn, wd, wino=None):
         """Training step: take this step's packed weights / folded batch norm from the engine's batched preparation
         (persistent buffers refreshed by two launches for the whole net) instead of one launch per tensor."""
         s = self.spec
@@ -83,7 +83,7 @@ class Layer:
             self.shift = P[s.name + ".bias"].detach() if s.bias else None
         self.wd = wd                                  # None: packed on demand (layers that normally take the Winograd path)
         self.dw = self.cs = None
-        self.uf = self.ud = None
+        self.uf, self.ud = wino if wino is not None else (None, None)
 
     def wino_weights(self, mode):
         """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
@@ -309,7 +309,7 @@ class Engine:
             _hip.check(lib.rn_prep_batched(jobs.data_ptr(), chunks.data_ptr(), n, _hip.stream()), "rn_prep_batched")
         for name, L in self.layers.items():
             b = prep["bufs"][name]
-            L.adopt(P, self.cache, b["wf"], b.get("bn"), b.get("wd"))
+            L.adopt(P, self.cache, b["wf"], b.get("bn"), b.get("wd"), b.get("wino"))
 
     def _build_prep(self, P, key):
         dev = next(iter(P.values())).device
@@ -348,8 +348,19 @@ class Engine:
                 j.bn_scale, j.bn_shift, j.bn_rstd = bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr()
                 add(0, j, cout)
                 scale = bn[0]
-            if name == "conv1" or (self.use_wino and L.wino_layer):
-                continue                              # the stem has no data gradient; Winograd layers transform their own weights
+            if self.use_wino and L.wino_layer:            # Winograd layers: transformed weights instead of dgrad packs
+                uf = torch.empty((36, cout, (cin + 31) // 32 * 32), dtype=torch.float32, device=dev)
+                ud = torch.empty((36, cin, (cout + 31) // 32 * 32), dtype=torch.float32, device=dev)
+                for which, mode, dst in ((0, 0, uf), (1, 1, ud)):
+                    j = _hip.PrepJob()
+                    j.kind, j.Cout, j.Cin, j.mode = 2, cout, cin, mode
+                    j.rows, j.Kpad = dst.shape[1], dst.shape[2]
+                    j.src, j.dst, j.scale = w.data_ptr(), dst.data_ptr(), None if (mode == 0 or scale is None) else scale.data_ptr()
+                    add(which, j, dst.shape[1] * dst.shape[2])
+                b["wino"] = (uf, ud)
+                continue
+            if name == "conv1":
+                continue                              # the stem has no data gradient
             if s.stride == 2 and s.k > 1:
                 b["wd"] = []
                 for c in cv.s2_classes(s.k, s.pad):
