@@ -149,10 +149,11 @@ def _wino_workspace(device, floats_v, floats_m):
 
 
 def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
-                    flops=0.0, keep_v=False, cout=None, y_batch_stride=0):
+                    flops=0.0, keep_v=False, y_batch_stride=0):
     """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
-    [36, Cout, Kpad]: input transform per problem into one V, ONE batched GEMM launch, output transform + epilogue
-    per problem (dense outputs).  Returns the outputs."""
+    [36, Cout, Kpad]: one grouped input transform into V, ONE batched GEMM launch, one grouped output transform with
+    the epilogue (outs: dense tensors, or slices with y_batch_stride).  Returns the outputs (and, with keep_v, the
+    (V, shapes) pair wino_wgrad_group accepts).  flops is informational (the GEMM is priced by its executed FLOPs)."""
     lib = _hip.load()
     dev = xs[0].device
     C = xs[0].shape[3]
