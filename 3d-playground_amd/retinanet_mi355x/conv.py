@@ -308,15 +308,21 @@ def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0
 
 
 def unpack_wgrad(dw, w_packed, weight_shape, kw_pad=None, c_pad=None, scale=None, mean=None, rstd=None, colsum=None,
-                 want_bn=False):
-    """-> (dweight OIHW, dgamma or None, dbeta or None)."""
+                 want_bn=False, out=None):
+    """-> (dweight OIHW, dgamma or None, dbeta or None); out = the same triple as destination tensors (contiguous fp32
+    of the right sizes, e.g. views of a flat gradient buffer) instead of fresh ones."""
     lib = _hip.load()
     cout, cin, kh, kw = weight_shape
     kw_pad = kw if kw_pad is None else kw_pad
     c_pad = (cin + 3) // 4 * 4 if c_pad is None else c_pad
-    dweight = torch.empty(weight_shape, dtype=torch.float32, device=dw.device)
-    dgamma = torch.empty(cout, dtype=torch.float32, device=dw.device) if want_bn else None
-    dbeta = torch.empty(cout, dtype=torch.float32, device=dw.device) if colsum is not None else None
+    if out is not None:
+        dweight, dgamma, dbeta = out
+        assert tuple(dweight.shape) == tuple(weight_shape) and dweight.is_contiguous() and dweight.dtype == torch.float32
+        assert (dgamma is not None) == bool(want_bn) and (dbeta is not None) == (colsum is not None)
+    else:
+        dweight = torch.empty(weight_shape, dtype=torch.float32, device=dw.device)
+        dgamma = torch.empty(cout, dtype=torch.float32, device=dw.device) if want_bn else None
+        dbeta = torch.empty(cout, dtype=torch.float32, device=dw.device) if colsum is not None else None
     _hip.check(lib.rn_unpack_wgrad(dw.data_ptr(), _hip.ptr(w_packed), dweight.data_ptr(), cout, cin, kh, kw, kw_pad,
                                    c_pad, _hip.ptr(scale), _hip.ptr(mean), _hip.ptr(rstd), _hip.ptr(colsum),
                                    _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.stream()), "rn_unpack_wgrad")

@@ -3,34 +3,98 @@ RCCL / xGMI (``torch.distributed`` backend "nccl" is RCCL on ROCm), overlapped w
 
 The reference uses ``torch.nn.DataParallel`` (train_detector_3D_angle.py:317): one process scatters the batch,
 replicates the weights every step and reduces gradients onto GPU 0.  Here every rank owns its images and its
-replica; the only exchange is the gradient average (36.6 M parameters, 146.6 MB fp32 for ResNet-50).  The engine's
-backward runs layers in a fixed reverse order (heads -> FPN -> layer4 .. stem) and reports each layer's finished
-gradients through ``Engine.grad_hook``; ``GradReducer`` packs them into flat buckets and starts an asynchronous
-all-reduce per bucket while the remaining dgrad / wgrad kernels keep the compute stream busy.  Buckets are large
-(default 32 MB: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large ring steps beat many small
-ones) and the frozen batch-norm needs no statistics traffic.  Per-image losses are self-normalised, so the mean
-of per-rank losses equals the global mean for equal shards.
+replica; the only exchange is the gradient average (36.6 M parameters, 146.6 MB fp32 for ResNet-50).
 
-Device agnostic: with the "gloo" backend the same class averages CPU tensors (used by the CPU tests).
+The engine's backward runs layers in a fixed reverse order (heads -> FPN -> layer4 .. stem).  With a reducer attached
+(``ResNet.set_gradient_reducer``) the engine writes every parameter gradient straight into its slot of ONE persistent
+flat buffer laid out in that order (``Engine.set_flat_grads``); a bucket is a contiguous slice of the buffer, and the
+moment the last layer of a slice has retired the engine hands the slice to ``GradReducer.bucket_ready``, which starts an
+asynchronous all-reduce on it IN PLACE while the remaining dgrad / wgrad kernels keep the compute stream busy.  No
+packing copy, no per-step allocation, and the gradient pointers the optimizer sees never change.  Buckets are large
+(default 32 MB: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large ring steps beat many small ones)
+and the frozen batch-norm needs no statistics traffic.  Per-image losses are self-normalised, so the mean of per-rank
+losses equals the global mean for equal shards.
+
+``hook`` / ``finalize`` are the generic form of the same thing for gradients that arrive as separate tensors (used by
+the CPU tests over "gloo"; it packs them with one copy per bucket).
 """
+import time
+
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, bucket_bytes=32 << 20, group=None):
+    def __init__(self, bucket_bytes=32 << 20, group=None, timeline=False):
         self.bucket_bytes = bucket_bytes
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.timeline = [] if timeline else None      # per step: [{bucket, bytes, launch_ms, done_ms}], backward_ms
         self._reset()
 
     def _reset(self):
         self.pending = []            # [(name, grad)] not yet flushed
         self.pending_bytes = 0
         self.flights = []            # [(work, flat, [(name, shape, offset, numel)])]
+        self.flat_flights = []       # [(bucket, work, slice, launch event or None)]
+        self.t0 = None
 
+    # ---- flat path: slices of the engine's persistent gradient buffer
+    def attach(self, engine):
+        engine.set_flat_grads(self.bucket_bytes)
+        engine.bucket_hook = self.bucket_ready
+
+    def backward_begins(self):
+        if self.timeline is not None and torch.cuda.is_available():
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+            self.t0_host = time.perf_counter()
+
+    def bucket_ready(self, index, flat_slice):
+        """Engine.bucket_hook: every gradient inside flat_slice is final (kernels enqueued on the current stream)."""
+        if self.world == 1:
+            return
+        ev = None
+        if self.t0 is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                               # retires when the bucket's last unpack kernel has retired
+        work = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.flat_flights.append([index, work, flat_slice, ev, time.perf_counter(), None])
+        self._poll()
+
+    def _poll(self):
+        if self.t0 is None:
+            return
+        for f in self.flat_flights:
+            if f[5] is None and f[1].is_completed():
+                f[5] = time.perf_counter()
+
+    def finalize_flat(self, arena):
+        """Wait for every bucket and scale the whole buffer by 1/world (one launch)."""
+        if self.world == 1:
+            return
+        end = None
+        if self.t0 is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()                              # the backward's last kernel
+        for f in self.flat_flights:
+            f[1].wait()
+            if f[5] is None:
+                f[5] = time.perf_counter()
+        arena.mul_(1.0 / self.world)
+        if self.t0 is not None:
+            torch.cuda.synchronize()
+            self.timeline.append({
+                "backward_gpu_ms": self.t0.elapsed_time(end),
+                "buckets": [{"bucket": f[0], "mbytes": round(f[2].numel() * 4 / 1e6, 1),
+                             "ready_gpu_ms": round(self.t0.elapsed_time(f[3]), 2),      # when its gradients were final
+                             "launch_host_ms": round(1e3 * (f[4] - self.t0_host), 2),   # when the host issued the all-reduce
+                             "done_host_ms": round(1e3 * (f[5] - self.t0_host), 2)} for f in self.flat_flights]})
+        self._reset()
+
+    # ---- generic path: separate gradient tensors
     def hook(self, grads):
-        """Engine.grad_hook: called with {name: grad} as soon as a layer's gradients are final."""
+        """Called with {name: grad} as soon as a layer's gradients are final."""
         if self.world == 1:
             return
         for name, g in grads.items():
@@ -80,5 +144,7 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)              # RCCL binds the communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world

@@ -219,12 +219,24 @@ class Layer:
         out = torch.empty((N, Ho, Wo, s.cin), dtype=torch.float32, device=g.device)
         return cv.conv_igemm(g, self.dgrad_weights(), out, (Ho, Wo, s.cin, 1, 1, 1, -1, 0, 0), flops=self.flops(N, Ho, Wo))
 
-    def finish(self):
-        """-> {param name: gradient} once every contribution has been accumulated."""
+    def grad_names(self):
+        """Names of the parameters this layer produces gradients for, in the order finish() reports them."""
         s = self.spec
+        if s.bn:
+            return [s.name + ".weight", s.bn + ".weight", s.bn + ".bias"]
+        return [s.name + ".weight"] + ([s.name + ".bias"] if s.bias else [])
+
+    def finish(self, out=None):
+        """-> {param name: gradient} once every contribution has been accumulated.  out: {param name: destination
+        tensor} (views of the engine's flat gradient buffer) or None for fresh tensors."""
+        s = self.spec
+        dst = None
+        if out is not None:
+            names = self.grad_names()
+            dst = (out[names[0]], out[names[1]] if s.bn else None, out[names[-1]] if len(names) > 1 else None)
         dweight, dgamma, dbeta = cv.unpack_wgrad(
             self.dw, self.wf, tuple(self.weight.shape), kw_pad=self.kw_pad, c_pad=self.cin_pad, scale=self.scale,
-            mean=self.mean, rstd=self.rstd, colsum=self.cs, want_bn=bool(s.bn))
+            mean=self.mean, rstd=self.rstd, colsum=self.cs, want_bn=bool(s.bn), out=dst)
         out = {s.name + ".weight": dweight}
         if s.bn:
             out[s.bn + ".weight"] = dgamma
@@ -262,6 +274,13 @@ class Engine:
         self.cache = _Cache()
         self.anchor_cache = {}
         self.grad_hook = None                      # callable({name: grad}) as soon as a layer's gradients are final
+        # Persistent flat gradient buffer (set_flat_grads): every parameter gradient is written straight into its slot of
+        # ONE device buffer laid out in the order the backward finishes layers, so (a) the all-reduce buckets are plain
+        # slices of it (no packing copy) handed to bucket_hook the moment their last layer retires, and (b) gradient
+        # pointers are the same every step (the optimizer's pointer table is uploaded once).
+        self.flat_bucket_bytes = None
+        self.bucket_hook = None                    # callable(bucket index, flat slice) when a bucket is complete
+        self._flat = None
         # Winograd for the head towers when activations are saved (= training); RN_WINOGRAD=0 keeps the direct kernels
         self.use_wino = os.environ.get("RN_WINOGRAD", "1") != "0"
         # opt-in for inference as well (default off: eval keeps the ~1e-7 behaviour of the direct kernels)
@@ -284,6 +303,64 @@ class Engine:
             self.layers[spec.name] = Layer(spec)
         self.param_names = [k for k, shp in arch.state_dict_shapes(arch_name, num_classes, n_reg).items()
                             if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+
+    # ------------------------------------------------------------------------------------------- flat gradients
+    def finish_order(self):
+        """Layer names in the order backward() finishes them (heads -> FPN -> layer4 ... layer1 -> stem)."""
+        order = []
+        for prefix in ("regressionModel", "classificationModel"):
+            order += [prefix + ".output"] + ["%s.conv%d" % (prefix, i) for i in (4, 3, 2, 1)]
+        order += ["fpn." + n for n in ("P7_2", "P6", "P3_2", "P3_1", "P4_2", "P4_1", "P5_2", "P5_1")]
+        for pre, roles in reversed(self.blocks):
+            seq = ["conv2"] if self.kind == "basic" else ["conv3", "conv2"]
+            seq += (["down"] if "down" in roles else []) + ["conv1"]
+            order += [roles[r].spec.name for r in seq]
+        order.append("conv1")
+        assert sorted(order) == sorted(self.layers), "finish_order does not cover the layer set"
+        return order
+
+    def set_flat_grads(self, bucket_bytes=32 << 20):
+        """Turn the persistent flat gradient buffer on (bucket_bytes: all-reduce bucket size; None turns it off)."""
+        self.flat_bucket_bytes = bucket_bytes
+        self._flat = None
+
+    def _flat_plan(self, device):
+        """Slots (64-float aligned) of every parameter gradient in finish order + the buckets: [start, end, last layer]."""
+        slots, buckets, off, start = {}, [], 0, 0
+        for lname in self.finish_order():
+            L = self.layers[lname]
+            shapes = [tuple(L.weight.shape)] + [(L.spec.cout,)] * (len(L.grad_names()) - 1)
+            for pname, shp in zip(L.grad_names(), shapes):
+                n = 1
+                for d in shp:
+                    n *= d
+                slots[pname] = (off, n, shp)
+                off += (n + 63) // 64 * 64
+            if 4 * (off - start) >= self.flat_bucket_bytes:
+                buckets.append((start, off, lname))
+                start = off
+        if off > start:
+            buckets.append((start, off, self.finish_order()[-1]))
+        return {"slots": slots, "buckets": buckets, "total": off, "device": device, "arena": None}
+
+    def _flat_views(self, device):
+        """{param name: view} of the flat buffer for this backward.  The buffer is reused from step to step unless a
+        parameter's .grad still lives in it (gradient accumulation over several backward calls, or zero_grad without
+        set_to_none): then this call gets a fresh one and the old one stays with those .grad tensors."""
+        f = self._flat
+        if f is None or f["device"] != device:
+            f = self._flat = self._flat_plan(device)
+        arena = f["arena"]
+        if arena is not None:
+            base = arena.untyped_storage().data_ptr()
+            for L in self.layers.values():
+                g = L.weight.grad
+                if g is not None and g.untyped_storage().data_ptr() == base:
+                    arena = None
+                    break
+        if arena is None:
+            arena = f["arena"] = torch.zeros(f["total"], dtype=torch.float32, device=device)   # alignment gaps stay zero
+        return arena, {n: arena[o:o + k].view(shp) for n, (o, k, shp) in f["slots"].items()}
 
     # ------------------------------------------------------------------------------------------- helpers
     def anchors(self, H, W, device):
@@ -471,6 +548,12 @@ class Engine:
             Ls[prefix + ".output"].fwd_group(ts, act=act, outs=views, y_batch_stride=A * width)
             if save:
                 S["towers"][prefix] = [[acts[i][li] for i in range(4)] for li in range(5)]
+        if save:
+            # The Winograd input transforms kept for the weight gradients belong to THIS call: a second forward before
+            # this one's backward must not replace them (the Layer objects are shared between calls).
+            S["wino_v"] = {n: L.saved_v for n, L in Ls.items() if L.saved_v is not None}
+        for L in Ls.values():
+            L.saved_v = None
         return reg, cls, S
 
     # ------------------------------------------------------------------------------------------- backward
@@ -479,12 +562,27 @@ class Engine:
         Ls = self.layers
         grads = {}
         self._zero_grad_accumulators(dreg.device)
+        for L in Ls.values():
+            L.saved_v = None
+        for n, v in S.pop("wino_v", {}).items():          # this call's Winograd input transforms (see forward)
+            Ls[n].saved_v = v
+
+        flat = views = None
+        next_bucket = 0
+        if self.flat_bucket_bytes:
+            flat, views = self._flat_views(dreg.device)
+            buckets = self._flat["buckets"]
 
         def done(layer):
-            g = layer.finish()
+            nonlocal next_bucket
+            g = layer.finish(views)
             grads.update(g)
             if self.grad_hook is not None:
                 self.grad_hook(g)
+            if flat is not None and layer.spec.name == buckets[next_bucket][2]:
+                if self.bucket_hook is not None:             # every gradient of this slice is final: release it
+                    self.bucket_hook(next_bucket, flat[buckets[next_bucket][0]:buckets[next_bucket][1]])
+                next_bucket += 1
 
         pyramid, counts = S["pyramid"], S["counts"]
         B = dreg.shape[0]
@@ -599,4 +697,5 @@ class Engine:
         gstem = cv.maxpool_bwd(S["stem"], g, S["pool_arg"], relu_mask=True)
         Ls["conv1"].bwd_params(gstem, S["x4"])
         done(Ls["conv1"])
+        assert flat is None or next_bucket == len(buckets), "backward finished layers in an order finish_order() does not describe"
         return grads

@@ -175,11 +175,13 @@ class _NetFn(torch.autograd.Function):
                                          ann_c.shape[1], int(net.directional), ws.data_ptr(), g.data_ptr(),
                                          dcls.data_ptr(), dreg.data_ptr(), _hip.stream()), "rn_focal_loss_bwd")
         red = net.__dict__.get("_reducer")
-        net._engine.grad_hook = red.hook if red is not None else None
-        grads = net._engine.backward(S, dreg, dcls, cls)
+        eng = net._engine
         if red is not None:
-            grads = red.finalize(grads)
-        return (None, None, None) + tuple(grads[n] for n in net._engine.param_names)
+            red.backward_begins()
+        grads = eng.backward(S, dreg, dcls, cls)
+        if red is not None:
+            red.finalize_flat(eng._flat["arena"])          # waits for the buckets; grads are views of that buffer
+        return (None, None, None) + tuple(grads[n] for n in eng.param_names)
 
 
 class ResNet(nn.Module):
@@ -249,8 +251,28 @@ class ResNet(nn.Module):
     def set_gradient_reducer(self, reducer):
         """Attach a ``ddp.GradReducer``: gradients are then averaged over the process group inside backward,
         bucket by bucket as the reverse schedule finishes layers (replaces nn.DataParallel,
-        train_detector_3D_angle.py:317)."""
+        train_detector_3D_angle.py:317).  None detaches it."""
         self.__dict__["_reducer"] = reducer
+        if reducer is not None:
+            reducer.attach(self._engine)
+        else:
+            self._engine.bucket_hook = None
+            self._engine.set_flat_grads(None)
+
+    def use_flat_gradients(self, on=True):
+        """Write parameter gradients into one persistent device buffer (stable ``p.grad`` pointers from step to step,
+        no per-step allocations; see Engine.set_flat_grads).  Implied by set_gradient_reducer.  Leave it off if your
+        loop keeps references to ``p.grad`` tensors across ``zero_grad(set_to_none=True)``: the next backward
+        overwrites that memory."""
+        self._engine.set_flat_grads((32 << 20) if on else None)
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel (train_detector_3D_angle.py:317) replicates the module onto device threads; the replicas
+        # would share ONE engine (packed-weight caches, gradient arena, Winograd workspaces) across devices.
+        raise RuntimeError(
+            "this drop-in does not run under torch.nn.DataParallel: its HIP engine keeps per-device state and would be "
+            "shared by the replica threads.  Use one process per GPU instead: retinanet_mi355x.ddp.init_from_env() + "
+            "net.set_gradient_reducer(ddp.GradReducer()) (see INTEGRATION.md, 'Multi-GPU').")
 
     def _tensor_dict(self):
         d = dict(self.named_parameters())
@@ -261,7 +283,7 @@ class ResNet(nn.Module):
         eng = self._engine
         if self.training:
             img_batch, annotations = inputs
-            ops._check_labels(annotations, self.directional)
+            ops.check_labels(annotations, self.directional)
             P = dict(self.named_parameters())
             params = [P[n] for n in eng.param_names]
             out = _NetFn.apply(self, img_batch, annotations, *params)

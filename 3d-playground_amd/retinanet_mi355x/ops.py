@@ -4,6 +4,8 @@ Each function mirrors one piece of the reference's Python surface (file:line in 
 or a few entry points of ``libretinanet_mi355x.so`` on the current HIP stream.  torch supplies device memory,
 streams and autograd bookkeeping only.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -114,15 +116,56 @@ class _FocalLossFn(torch.autograd.Function):
         return dcls, dreg, None, None, None
 
 
-def _check_labels(ann, directional):
-    """The reference stacks an empty list when no image of the batch has a label (D/losses.py:362) and raises;
-    keep that contract (one tiny D2H read of the label classes)."""
-    col = 20 if directional else 4
-    if directional and ann.shape[1] > 0 and not bool((ann[:, :, col] != -1).any()):
-        raise RuntimeError("stack expects a non-empty TensorList (no image in the batch has a label; "
-                           "the reference's FocalLoss raises here, D/losses.py:362)")
-    if directional and ann.shape[1] == 0:
+_LABEL_FLAGS = []             # [(pinned flag tensor, event)] of training forwards whose label check has not been read yet
+
+
+def check_labels(ann, directional, eager=None):
+    """The reference stacks an empty list when no image of the batch has a label (D/losses.py:362) and raises.
+    Testing that needs one word from the device.  Read on the spot it stalls the host once per training step (nothing of
+    step k+1 can be enqueued while step k drains), so by default the word travels asynchronously and is looked at when the
+    NEXT call comes by (or in ``flush_label_checks``): the same RuntimeError, one call late -- that step's vp loss is NaN
+    (the kernel's 0/0 over zero labelled images) and its gradients must not be applied, which is what the reference's
+    trainer does with any exception in an iteration (train_detector_3D_angle.py:406-408).  RN_EAGER_LABEL_CHECK=1 (or
+    eager=True) reads it immediately, exactly like the reference."""
+    if not directional:
+        return
+    if ann.shape[1] == 0:
         raise RuntimeError("stack expects a non-empty TensorList (no labels in the batch)")
+    if eager is None:
+        eager = os.environ.get("RN_EAGER_LABEL_CHECK", "0") == "1"
+    flush_label_checks(block=False)
+    any_label = (ann[:, :, 20] != -1).any().reshape(1).to(torch.uint8)
+    if eager or not ann.is_cuda:
+        if not bool(any_label.item()):
+            raise RuntimeError(_NO_LABEL_MSG)
+        return
+    flag = torch.empty(1, dtype=torch.uint8).pin_memory()
+    flag.copy_(any_label, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _LABEL_FLAGS.append((flag, ev))
+
+
+_NO_LABEL_MSG = ("stack expects a non-empty TensorList (no image in the batch has a label; the reference's FocalLoss "
+                 "raises here, D/losses.py:362)")
+
+
+def flush_label_checks(block=True):
+    """Look at the label checks that have arrived (block: wait for all of them); raise if one found no label."""
+    bad = False
+    while _LABEL_FLAGS:
+        flag, ev = _LABEL_FLAGS[0]
+        if not block and not ev.query():
+            break
+        ev.synchronize()
+        _LABEL_FLAGS.pop(0)
+        bad |= not bool(flag.item())
+    if bad:
+        raise RuntimeError(_NO_LABEL_MSG + " [reported by the deferred check of an earlier training call]")
+
+
+def _check_labels(ann, directional):
+    check_labels(ann, directional, eager=True)
 
 
 def focal_loss(cls, reg, anchor_boxes, ann, directional=True, check_labels=True):

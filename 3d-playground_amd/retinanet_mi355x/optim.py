@@ -38,8 +38,16 @@ class ClipAdam(torch.optim.Optimizer):
             chunks += [(ti, c) for c in range((p.numel() + CHUNK - 1) // CHUNK)]
         self.n_chunks = len(chunks)
         self.chunk_table = torch.tensor(chunks, dtype=torch.int32, device=dev)
-        self.table_host = torch.empty(len(self.params) * 5, dtype=torch.int64).pin_memory()
-        self.table_dev = torch.empty(len(self.params) * 5, dtype=torch.int64, device=dev)
+        # Pointer table (param, grad, m, v, numel per tensor).  The upload is asynchronous, so a pinned host table may be
+        # rewritten only after the copy that read it has completed, and a device table only after the kernels that read
+        # it have run: two (host, device) pairs used in turn, each guarded by the event recorded after its last use; the
+        # upload is skipped altogether while the pointers stay what the device table already holds (persistent
+        # gradients: Engine.flat_grads).
+        n5 = len(self.params) * 5
+        self.tables = [{"host": torch.empty(n5, dtype=torch.int64).pin_memory(),
+                        "dev": torch.empty(n5, dtype=torch.int64, device=dev), "event": None, "ptrs": None}
+                       for _ in range(2)]
+        self.turn = 0
         lib = _hip.load()
         self.ws = torch.empty(lib.rn_opt_workspace_bytes(self.n_chunks), dtype=torch.uint8, device=dev)
         self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -55,24 +63,31 @@ class ClipAdam(torch.optim.Optimizer):
     def step(self):
         """-> device tensor [1] with the pre-clip global gradient norm (clip_grad_norm_'s return value)."""
         lib = _hip.load()
-        t = self.table_host
+        ptrs = []
         for i, p in enumerate(self.params):
             g = p.grad
             if g is None:
                 raise RuntimeError("parameter without gradient")
-            if not g.is_contiguous():
-                g = p.grad = g.contiguous()
-            t[5 * i + 0] = p.data_ptr()
-            t[5 * i + 1] = g.data_ptr()
-            t[5 * i + 2] = self.m[i].data_ptr()
-            t[5 * i + 3] = self.v[i].data_ptr()
-            t[5 * i + 4] = p.numel()
-        self.table_dev.copy_(t, non_blocking=True)
+            if not g.is_contiguous() or g.dtype != torch.float32:
+                g = p.grad = g.float().contiguous()
+            ptrs += (p.data_ptr(), g.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel())
+        tab = self.tables[self.turn]
+        if tab["ptrs"] != ptrs:
+            tab = self.tables[self.turn ^ 1]
+            self.turn ^= 1
+            if tab["event"] is not None:
+                tab["event"].synchronize()            # the step that last used this pair has left the device
+            tab["host"].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            tab["dev"].copy_(tab["host"], non_blocking=True)
+            tab["ptrs"] = ptrs
         self.step_count += 1
-        _hip.check(lib.rn_opt_clip_adam(self.table_dev.data_ptr(), self.chunk_table.data_ptr(), self.n_chunks,
+        _hip.check(lib.rn_opt_clip_adam(tab["dev"].data_ptr(), self.chunk_table.data_ptr(), self.n_chunks,
                                         float(self.max_norm if self.max_norm else 0.0), float(self.param_groups[0]["lr"]),
                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, 1,
                                         self.ws.data_ptr(), self.total_norm.data_ptr(), _hip.stream()), "rn_opt_clip_adam")
+        if tab["event"] is None:
+            tab["event"] = torch.cuda.Event()
+        tab["event"].record()
         # the kernel updated the parameters through raw pointers: bump their version counters so that caches
         # keyed on (data_ptr, _version) -- the engine's packed weights -- see the change
         setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)

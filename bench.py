@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--ddp-timeline", action="store_true",
+                    help="N > 1: rank 0 also prints the per-bucket all-reduce timeline of the last step (stderr)")
     return ap.parse_args()
 
 
@@ -138,12 +140,36 @@ def cpu_baseline(arch, H, W):
             "sample": "1 image %dx%d, %s forward+loss+backward, torch CPU fp32 (%.1f s)" % (W, H, arch, dt)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N rank processes ourselves -- as a
+    torch.distributed.run CHILD, before this process has touched the GPU (never re-exec a process that has) -- relay
+    their output (rank 0 prints the JSON line) and exit with their code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                       # does not initialise the GPU on this image
+    if have < args.gpus and not os.environ.get("RN_REHEARSE_ONE_GPU"):
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); not reporting a smaller run as n_gpus=%d"
+                         % (args.gpus, have, args.gpus))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     from retinanet_mi355x import ddp, modules, optim, prof, synth
     rank, local, world = ddp.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        world = dist.get_world_size()                      # what RCCL / gloo actually formed
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     B, H, W = args.batch, args.height, args.width
@@ -154,7 +180,9 @@ def main():
     net.train()
     net.freeze_bn()
     if world > 1:
-        net.set_gradient_reducer(ddp.GradReducer())
+        net.set_gradient_reducer(ddp.GradReducer(timeline=args.ddp_timeline))   # bucketed all-reduce inside backward, in place on the flat buffer
+    else:
+        net.use_flat_gradients()                             # same persistent gradient buffer, no exchange
     params = [p for p in net.parameters() if p.requires_grad]
     # clip_grad_norm_(0.1) + Adam(lr 1e-4) (train_detector_3D_angle.py:337, 385-387) as one fused native step
     opt = optim.ClipAdam(params, lr=1e-4, max_norm=0.1)
@@ -187,7 +215,7 @@ def main():
     barrier()
     dt = time.time() - t0
     prof.ACTIVE = None
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,6 +285,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
         print(json.dumps(line), flush=True)
     if world > 1:
+        if args.ddp_timeline and rank == 0:
+            tl = net.__dict__["_reducer"].timeline[-1]
+            print("ddp timeline (last step, ms since backward began): backward's last kernel retired at %.2f"
+                  % tl["backward_gpu_ms"], file=sys.stderr)
+            for b in tl["buckets"]:
+                print("  bucket %(bucket)d  %(mbytes)6.1f MB  gradients final %(ready_gpu_ms)8.2f (GPU)  all-reduce issued "
+                      "%(launch_host_ms)8.2f  done %(done_host_ms)8.2f (host)" % b, file=sys.stderr)
         dist.destroy_process_group()
 
 

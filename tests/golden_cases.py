@@ -78,9 +78,22 @@ def post_2d_inputs():
     return synth.scores_portable(1, A, 3, 45, power=6), torch.from_numpy(synth.normal((1, A, 4), 46, 1.0))
 
 
-def model_inputs(arch, directional=True):
-    H, W = MODEL_HW
-    B = 2 if arch == "resnet18" else 1
+CROP_HW = (112, 112)         # the tracker's crop detector input (train_crop_detector.py CROP=112, MC3D_crop_tracker.py:1185)
+
+
+# architecture -> (golden file, input size, batch) of the whole-model fixtures (tools/make_golden.py gen_model / gen_model_deep)
+MODEL_CASES = {"resnet18": ("model", None, None), "resnet50": ("model", None, None),
+               "resnet34": ("model_deep", CROP_HW, 2), "resnet101": ("model_deep", MODEL_HW, 1)}
+
+
+def model_case(arch, directional=True):
+    fn, hw, batch = MODEL_CASES[arch]
+    return (fn,) + model_inputs(arch, directional, hw=hw, batch=batch)
+
+
+def model_inputs(arch, directional=True, hw=None, batch=None):
+    H, W = MODEL_HW if hw is None else hw
+    B = (2 if arch == "resnet18" else 1) if batch is None else batch
     sd = synth.state_dict(arch, num_classes=4, n_reg=12 if directional else 4, seed=7, head_scale=3e-4)
     img = synth.frames(B, H, W, seed=8)
     if directional:

@@ -49,6 +49,14 @@ def _worker(rank, world, port, out):
     red.hook({"a.bias": torch.full((7,), float(rank))})
     again = red.finalize({"a.bias": None})
     ok &= torch.allclose(again["a.bias"], torch.full((7,), (world - 1) / 2.0))
+    # flat path: the engine's persistent buffer, buckets = slices reduced in place as they complete
+    arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red.backward_begins()
+    red.bucket_ready(0, arena[0:300])
+    red.bucket_ready(1, arena[300:1000])
+    red.finalize_flat(arena)
+    ok &= torch.allclose(arena, torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+    ok &= not red.flat_flights
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -1,12 +1,17 @@
 """GPU parity of the whole detector (drop-in ResNet on the HIP engine) against the golden vectors the
-REFERENCE produced on CPU (tests/golden/model.npz) and against the oracle.
+REFERENCE produced on CPU (tests/golden/model.npz, model_deep.npz) and against the oracle.
 
-Tolerances: fp32 losses / boxes / scores within 1e-4 relative (north_star).  Parameter gradients: L2 norm within
-1e-3, and element-wise L2-relative error <= 2e-3 with no element further than 1e-2 of the gradient's max
-magnitude.  (Measured: ~1e-6 everywhere, except where ONE pre-activation lies within fp32 rounding of zero and
-the different summation order of the MFMA tiles flips its ReLU mask -- that moves a single bias-gradient element
-by ~3e-3 of the max; seen once on ResNet-18 layer1.1.bn1.bias, see tools/dbg_grad.py.)
+Tolerances: fp32 losses / boxes / scores within 1e-4 relative (north_star).  Parameter gradients (``grad_close``):
+L2-relative error of the whole tensor <= GRAD_L2[mode] -- 10x what was measured on the GPU box (direct kernels ~2e-6,
+Winograd F(4x4,3x3) layers on ~2e-5; tests/gpu_stats.json holds the last measured values) -- and no element further
+than GRAD_MAX of the gradient's max magnitude.  The element-wise bound stays looser than the L2 one because of one known
+effect: where ONE pre-activation lies within fp32 rounding of zero, the different summation order of the MFMA tiles flips
+its ReLU mask, which moves a single bias-gradient element by ~3e-3 of the max (seen once on ResNet-18
+layer1.1.bn1.bias); a systematic error of that size would blow the L2 bound.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,13 +20,33 @@ import golden_cases as gc
 
 pytestmark = pytest.mark.gpu
 
+GRAD_L2 = {"direct": 3e-5, "wino": 3e-4}
+GRAD_MAX = 5e-3
+NORM_TOL = {"direct": 2e-5, "wino": 2e-4}
+STATS = {}
 
-def _build(arch, directional, dev):
+
+def _note(test, name, l2, mx):
+    w = STATS.setdefault(test, {"worst_l2": 0.0, "worst_max": 0.0, "n": 0})
+    if l2 >= w["worst_l2"]:
+        w["worst_l2"], w["worst_l2_name"] = l2, name
+    if mx >= w["worst_max"]:
+        w["worst_max"], w["worst_max_name"] = mx, name
+    w["n"] += 1
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "gpu_stats.json"), "w") as f:
+            json.dump(STATS, f, indent=1, sort_keys=True)
+
+
+def _build(arch, directional, dev, wino=None):
     from retinanet_mi355x import modules
-    sd, img, ann = gc.model_inputs(arch, directional)
+    fn, sd, img, ann = gc.model_case(arch, directional)
     net = getattr(modules, arch)(num_classes=4, directional=directional)
     missing = net.load_state_dict(sd)
     assert not missing.missing_keys and not missing.unexpected_keys
+    if wino is not None:
+        net._engine.use_wino = wino
     return net.to(dev), img.to(dev), ann.to(dev), sd
 
 
@@ -31,11 +56,12 @@ def rel_close(got, want, tol):
     assert err <= tol * (np.abs(want).max() + 1e-12), "max err %.3e vs max|ref| %.3e" % (err, np.abs(want).max())
 
 
-def grad_close(got, want, name):
+def grad_close(got, want, name, mode="wino", test="?"):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     l2 = np.sqrt(((got - want) ** 2).sum()) / (np.sqrt((want ** 2).sum()) + 1e-30)
     mx = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
-    assert l2 <= 2e-3 and mx <= 1e-2, "%s: L2-rel %.3e, max-rel %.3e" % (name, l2, mx)
+    _note(test, name, float(l2), float(mx))
+    assert l2 <= GRAD_L2[mode] and mx <= GRAD_MAX, "%s [%s]: L2-rel %.3e, max-rel %.3e" % (name, mode, l2, mx)
 
 
 def test_state_dict_keys_match_reference_layout(dev):
@@ -52,9 +78,12 @@ def test_state_dict_keys_match_reference_layout(dev):
                         "regressionModel", "classificationModel", "anchors", "regressBoxes", "clipBoxes", "focalLoss"]
 
 
-@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+ARCHS = ["resnet18", "resnet50", "resnet34", "resnet101"]
+
+
+@pytest.mark.parametrize("arch", ARCHS)
 def test_directional_eval_localize(dev, golden, arch):
-    z = golden("model")
+    z = golden(gc.MODEL_CASES[arch][0])
     net, img, ann, _ = _build(arch, True, dev)
     net.eval()
     boxes, cls = net(img, LOCALIZE=True)
@@ -62,14 +91,15 @@ def test_directional_eval_localize(dev, golden, arch):
     rel_close(boxes.cpu().numpy(), z["%s_dir_boxes" % arch], 1e-4)
 
 
-@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
-def test_directional_train_losses_and_gradients(dev, golden, arch):
-    z = golden("model")
-    net, img, ann, _ = _build(arch, True, dev)
+@pytest.mark.parametrize("mode", ["wino", "direct"])
+@pytest.mark.parametrize("arch", ARCHS)
+def test_directional_train_losses_and_gradients(dev, golden, arch, mode):
+    z = golden(gc.MODEL_CASES[arch][0])
+    net, img, ann, _ = _build(arch, True, dev, wino=(mode == "wino"))
     net.train()
     net.freeze_bn()
     cls_l, reg_l, vp_l = net([img, ann])
-    got = [float(cls_l), float(reg_l), float(vp_l)]
+    got = [float(cls_l.detach()), float(reg_l.detach()), float(vp_l.detach())]
     assert np.allclose(got, z["%s_dir_losses" % arch], rtol=1e-4), (got, z["%s_dir_losses" % arch])
     (cls_l + reg_l + vp_l).sum().backward()
     checked = 0
@@ -78,10 +108,10 @@ def test_directional_train_losses_and_gradients(dev, golden, arch):
         key = "%s_dir_gsum_%s" % (arch, name)
         g = p.grad.detach().cpu().numpy().astype(np.float64)
         ref_norm = z[key][2]
-        assert abs(np.sqrt((g ** 2).sum()) - ref_norm) <= 1e-3 * ref_norm + 1e-9, (name, np.sqrt((g ** 2).sum()), ref_norm)
+        assert abs(np.sqrt((g ** 2).sum()) - ref_norm) <= NORM_TOL[mode] * ref_norm + 1e-9, (name, np.sqrt((g ** 2).sum()), ref_norm)
         full = "%s_dir_g_%s" % (arch, name)
         if full in z.files:
-            grad_close(g, z[full], name)
+            grad_close(g, z[full], name, mode, "train_%s_%s" % (arch, mode))
             checked += 1
     assert checked > 30
 
@@ -93,12 +123,12 @@ def test_flat2d_train_and_eval(dev, golden):
     net.freeze_bn()
     out = net([img, ann])
     assert len(out) == 2
-    assert np.allclose([float(x) for x in out], z["resnet18_2d_losses"], rtol=1e-4)
+    assert np.allclose([float(x.detach()) for x in out], z["resnet18_2d_losses"], rtol=1e-4)
     (out[0] + out[1]).sum().backward()
     for name, p in net.named_parameters():
         ref_norm = z["resnet18_2d_gsum_" + name][2]
         gn = float(p.grad.double().norm())
-        assert abs(gn - ref_norm) <= 1e-3 * ref_norm + 1e-9, (name, gn, ref_norm)
+        assert abs(gn - ref_norm) <= NORM_TOL["wino"] * ref_norm + 1e-9, (name, gn, ref_norm)
     net.eval()
     boxes, cls = net(img, LOCALIZE=True)
     rel_close(cls.cpu().numpy(), z["resnet18_2d_cls"], 1e-4)
@@ -152,8 +182,8 @@ def test_training_step_changes_loss(dev):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(net.parameters(), 0.1)
         opt.step()
-        first = float(loss) if first is None else first
-    assert float(loss) < first
+        first = float(loss.detach()) if first is None else first
+    assert float(loss.detach()) < first
 
 
 def test_fused_clip_adam_matches_torch(dev):
@@ -200,4 +230,162 @@ def test_cfg1_resnet18_2d_512(dev):
     net = net.to(dev).train()
     got = net([img.to(dev), ann.to(dev)])
     assert len(got) == 2
-    assert np.allclose([float(x) for x in got], [float(x) for x in want], rtol=1e-4), (got, want)
+    assert np.allclose([float(x.detach()) for x in got], [float(x) for x in want], rtol=1e-4), (got, want)
+
+
+# ------------------------------------------------------------------------------------------------ per-call state
+def _grads(net, img, ann):
+    for p in net.parameters():
+        p.grad = None
+    losses = net([img, ann])
+    sum(l.mean() for l in losses).backward()
+    return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+
+def test_second_forward_before_backward_does_not_leak_state(dev):
+    """forward(b1); forward(b2); backward(b1) must give the gradients of a lone step on b1: the Winograd input transforms
+    kept for the weight gradients belong to the call, not to the (shared) layer objects."""
+    from retinanet_mi355x import synth
+    net, img, ann, _ = _build("resnet50", True, dev, wino=True)
+    net.train()
+    net.freeze_bn()
+    H, W = gc.MODEL_HW
+    img2 = synth.frames(1, H, W, seed=77).to(dev)
+    ann2 = synth.labels_dir(1, 5, H, W, num_classes=4, seed=78, size_px=(24, 60)).to(dev)
+    want = _grads(net, img, ann)
+    for p in net.parameters():
+        p.grad = None
+    l1 = net([img, ann])
+    l2 = net([img2, ann2])                                   # same shapes, other data, before l1's backward
+    with torch.no_grad():
+        net([img2, ann2])                                    # and a train-mode pass that will never run backward
+    sum(l.mean() for l in l1).backward()
+    worst = 0.0
+    for n, p in net.named_parameters():
+        err = float((p.grad - want[n]).norm() / (want[n].norm() + 1e-30))
+        worst = max(worst, err)
+    assert worst <= 1e-4, worst                              # fp32 atomics in wgrad: order-dependent last bits only
+    del l2
+
+
+def test_flat_gradient_buffer(dev):
+    """Engine.set_flat_grads: same gradients, p.grad pointers stable from step to step, and gradient accumulation over two
+    backward calls (p.grad still living in the buffer) is not corrupted by the second backward."""
+    net, img, ann, _ = _build("resnet18", True, dev)
+    net.train()
+    net.freeze_bn()
+    want = _grads(net, img, ann)
+    net.use_flat_gradients()
+    got = _grads(net, img, ann)
+    ptr1 = {n: p.grad.data_ptr() for n, p in net.named_parameters()}
+    for n in want:
+        assert float((got[n] - want[n]).norm()) <= 1e-4 * float(want[n].norm()) + 1e-12, n
+    got2 = _grads(net, img, ann)                              # second step: zero_grad(set_to_none) happened inside
+    ptr2 = {n: p.grad.data_ptr() for n, p in net.named_parameters()}
+    assert ptr1 == ptr2, "gradient pointers moved between steps"
+    arena = net._engine._flat["arena"]
+    lo, hi = arena.data_ptr(), arena.data_ptr() + 4 * arena.numel()
+    assert all(lo <= q < hi for q in ptr2.values())
+    # accumulation: backward again WITHOUT clearing p.grad -> p.grad must become 2x
+    losses = net([img, ann])
+    sum(l.mean() for l in losses).backward()
+    for n, p in net.named_parameters():
+        assert float((p.grad - 2 * got2[n]).norm()) <= 2e-4 * float(got2[n].norm()) + 1e-12, n
+    net.use_flat_gradients(False)
+
+
+def test_data_parallel_is_refused_clearly(dev):
+    net, img, ann, _ = _build("resnet18", True, dev)
+    net.eval()
+    dp = torch.nn.DataParallel(net, device_ids=[0, 0])
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        dp(torch.cat([img, img]))
+
+
+def test_deferred_label_check(dev):
+    """A training batch without any label: the reference raises inside FocalLoss (D/losses.py:362).  The model's hot path
+    reports it one call late by default (no host sync per step), immediately with RN_EAGER_LABEL_CHECK=1."""
+    from retinanet_mi355x import ops
+    net, img, ann, _ = _build("resnet18", True, dev)
+    net.train()
+    empty = torch.full_like(ann, -1.0)
+    out = net([img, empty])
+    assert torch.isnan(out[2]).all()                          # vp loss 0/0 over zero labelled images
+    with pytest.raises(RuntimeError, match="non-empty TensorList"):
+        ops.flush_label_checks()
+    os.environ["RN_EAGER_LABEL_CHECK"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="non-empty TensorList"):
+            net([img, empty])
+    finally:
+        del os.environ["RN_EAGER_LABEL_CHECK"]
+    net([img, ann])                                           # and a good batch goes through
+    ops.flush_label_checks()
+
+
+# ------------------------------------------------------------------------------------------------ cfg2 at full size
+CFG2 = {}
+
+
+def _cfg2_oracle():
+    """ResNet-50, 1080x1920, batch 1, the benchmark's synthetic inputs: oracle forward + three losses + backward on the
+    CPU (about 16 s on the GPU box's cores), once per session."""
+    if not CFG2:
+        from oracle import model as omodel
+        from retinanet_mi355x import synth
+        H, W = 1080, 1920
+        sd = synth.state_dict("resnet50", 8, 12, seed=2)
+        img = synth.frames(1, H, W, seed=0)
+        ann = synth.labels_dir(1, 10, H, W, 8, seed=1)
+        params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+                  for k, v in sd.items()}
+        losses = omodel.train_forward(img, ann, params, "resnet50")
+        sum(l.mean() for l in losses).backward()
+        with torch.no_grad():
+            boxes, cls = omodel.eval_forward(img, sd, "resnet50", LOCALIZE=True)
+        CFG2.update(sd=sd, img=img, ann=ann, losses=[float(l.detach()) for l in losses], boxes=boxes, cls=cls,
+                    grads={k: p.grad for k, p in params.items() if getattr(p, "grad", None) is not None})
+    return CFG2
+
+
+CFG2_PARAMS = (["conv1.weight", "bn1.weight", "bn1.bias"]
+               + ["layer%d.%d.conv2.weight" % (l, b) for l, b in ((1, 0), (2, 0), (2, 3), (3, 0), (3, 5), (4, 0), (4, 2))]
+               + ["layer2.0.downsample.0.weight", "layer3.0.conv1.weight", "layer4.2.conv3.weight", "layer4.2.bn3.weight",
+                  "layer3.2.bn2.bias", "layer1.2.bn3.weight"]
+               + ["fpn.%s.%s" % (n, t) for n in ("P3_1", "P3_2", "P4_1", "P4_2", "P5_1", "P5_2", "P6", "P7_2") for t in ("weight", "bias")]
+               + ["%s.%s.%s" % (m, c, t) for m in ("regressionModel", "classificationModel")
+                  for c in ("conv1", "conv2", "conv3", "conv4", "output") for t in ("weight", "bias")])
+
+
+@pytest.mark.parametrize("mode", ["wino", "direct"])
+def test_cfg2_full_size_against_oracle(dev, mode):
+    """BASELINE configs[1] at its real size (ResNet-50, 1920x1080, the benchmark's inputs, batch 1): HIP training forward +
+    three losses + backward against the oracle on CPU -- the five real pyramid sizes 135x240 ... 9x15, both FPN crop
+    branches, the grouped Winograd path with its padded tile count (mode "wino", what bench.py runs) and the direct
+    kernels (mode "direct" = RN_WINOGRAD=0).  D/model.py:284-309, D/losses.py:27-362."""
+    from retinanet_mi355x import modules
+    o = _cfg2_oracle()
+    net = modules.resnet50(num_classes=8)
+    net.load_state_dict(o["sd"])
+    net = net.to(dev)
+    net._engine.use_wino = mode == "wino"
+    net.train()
+    net.freeze_bn()
+    img, ann = o["img"].to(dev), o["ann"].to(dev)
+    losses = net([img, ann])
+    got = [float(l.detach()) for l in losses]
+    assert np.allclose(got, o["losses"], rtol=1e-4), (got, o["losses"])
+    sum(l.mean() for l in losses).backward()
+    assert len(CFG2_PARAMS) >= 30
+    named = dict(net.named_parameters())
+    for name in CFG2_PARAMS:
+        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, mode, "cfg2_full_%s" % mode)
+    for name, p in named.items():                              # and every other gradient by its norm
+        want = float(o["grads"][name].double().norm())
+        assert abs(float(p.grad.double().norm()) - want) <= 10 * NORM_TOL[mode] * want + 1e-12, name
+    for p in net.parameters():
+        p.grad = None
+    net.eval()
+    boxes, cls = net(img, LOCALIZE=True)
+    rel_close(cls.cpu().numpy(), o["cls"].numpy(), 1e-4)
+    rel_close(boxes.cpu().numpy(), o["boxes"].numpy(), 1e-4)

@@ -145,10 +145,10 @@ def test_adaptive_threshold_can_return_nothing():
 
 
 # ------------------------------------------------------------------ whole model (torch CPU kernels underneath)
-@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50", "resnet34", "resnet101"])
 def test_model_dir(golden, arch):
-    z = golden("model")
-    sd, img, ann = gc.model_inputs(arch, True)
+    fn, sd, img, ann = gc.model_case(arch, True)
+    z = golden(fn)
     params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
     l = omodel.train_forward(img, ann, params, arch)
     assert np.allclose([float(x) for x in l], z["%s_dir_losses" % arch], rtol=2e-5)

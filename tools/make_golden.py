@@ -15,7 +15,8 @@ Inputs come from ``retinanet_mi355x.synth`` (portable integer-hash generators), 
 hold OUTPUTS (and the few inputs built with libm/LAPACK).  This script refuses to run without
 /root/reference and is never executed on the GPU box.
 
-    python tools/make_golden.py            # writes tests/golden/*.npz
+    python tools/make_golden.py                     # writes tests/golden/*.npz
+    python tools/make_golden.py --out DIR [names]   # elsewhere (tests/test_golden_regen.py compares with the committed set)
 """
 import hashlib
 import importlib
@@ -244,12 +245,30 @@ def gen_model(model_dir, model_2d):
     np.savez_compressed(os.path.join(OUT, "model.npz"), **out)
 
 
+def gen_model_deep(model_dir):
+    """The other two architectures callers build: resnet34 = the tracker's crop detector (MC3D_crop_tracker.py:1535, at its
+    112x112 crop size, batch 2) and resnet101 (BASELINE configs[4]).  Own file so that model.npz stays as it was."""
+    out = {}
+    for arch, hw, batch in (("resnet34", gc.CROP_HW, 2), ("resnet101", gc.MODEL_HW, 1)):
+        sd, img, ann = gc.model_inputs(arch, directional=True, hw=hw, batch=batch)
+        net = getattr(model_dir, arch)(num_classes=4)
+        net.load_state_dict(sd)
+        net.train()
+        net.freeze_bn()
+        l = net([img, ann.clone()])
+        (l[0] + l[1] + l[2]).sum().backward()
+        out["%s_dir_losses" % arch] = np.array([float(x.detach()) for x in l], dtype=np.float32)
+        _grad_summary(net, out, "%s_dir" % arch, full_limit=2048)
+        net.eval()
+        with torch.no_grad():
+            boxes, cls = net(img, LOCALIZE=True)
+        out["%s_dir_boxes" % arch] = t2n(boxes)
+        out["%s_dir_cls" % arch] = t2n(cls)
+    np.savez_compressed(os.path.join(OUT, "model_deep.npz"), **out)
+
+
 def gen_homography():
-    sys.path.insert(0, REF)
-    try:
-        hgmod = importlib.import_module("homography")
-    finally:
-        sys.path.remove(REF)
+    hgmod = ref_module_from_file("_reference_homography", "homography.py")
     out = {}
     names, state, cam_index, (Ps, Hs), (Ps2, Hs2) = gc.homography_inputs()
     out["P"], out["H"] = Ps, Hs
@@ -332,6 +351,15 @@ def tracker_import_shims():
     def _no_roi_align(*a, **k):
         raise NotImplementedError("roi_align is not on this path")
     sys.modules["torchvision.ops"].roi_align = _no_roi_align
+    matplotlib_stub()
+
+
+def matplotlib_stub():
+    """util_track/kf.py imports matplotlib.pyplot at the top (unused by the class, absent here)."""
+    if "matplotlib" not in sys.modules:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, mpl.pyplot
 
 
 def gen_tracker_post():
@@ -340,12 +368,7 @@ def gen_tracker_post():
     phi_nms_*, cameras, est_ts, hg = the reference's own Homography_Wrapper filled with the fixture's matrices).
     The module imports behind two more stub attributes (torchvision.transforms.functional, torchvision.ops.roi_align);
     constructing the tracker itself needs videos and checkpoints the reference does not ship."""
-    sys.path.insert(0, REF)
-    try:
-        trk = importlib.import_module("MC3D_crop_tracker")
-        hgmod = importlib.import_module("homography")
-    finally:
-        sys.path.remove(REF)
+    trk, hgmod = import_reference_tracker()
     T = trk.MC_Crop_Tracker
     scores, labels, boxes, cams, names, (Ps, Hs), (Ps2, Hs2) = gc.tracker_post_inputs()
 
@@ -383,12 +406,7 @@ def gen_tracker_post():
 def gen_crop_refine():
     """MC_Crop_Tracker.get_crop_boxes / local_to_global / select_best_box (MC3D_crop_tracker.py:920-1028) run unbound
     on a stand-in ``self`` (b, cs, W, device, hg, md_iou); same import shims as gen_tracker_post."""
-    sys.path.insert(0, REF)
-    try:
-        trk = importlib.import_module("MC3D_crop_tracker")
-        hgmod = importlib.import_module("homography")
-    finally:
-        sys.path.remove(REF)
+    trk, hgmod = import_reference_tracker()
     T = trk.MC_Crop_Tracker
     from oracle import crop_refine as ocr          # only for the roi-free middle of the pipeline (top-k, homographies)
     pre_loc, cam, im_objs, names, (Ps, Hs), (Ps2, Hs2) = gc.crop_refine_inputs()
@@ -428,18 +446,41 @@ def gen_crop_refine():
     np.savez_compressed(os.path.join(OUT, "crop_refine.npz"), **out)
 
 
+def ref_module_from_file(alias, relpath):
+    """A reference module loaded from its file, under a private name: this repository ships same-named drop-ins
+    (util_track/kf.py, homography.py) that come first on sys.path, and a golden must come from the REFERENCE's code."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(alias, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert os.path.realpath(mod.__file__).startswith(os.path.realpath(REF) + os.sep)
+    return mod
+
+
+def import_reference_tracker():
+    """MC3D_crop_tracker + homography with the reference checkout FIRST on sys.path, so that its own
+    `from util_track.kf import ...` / `util_track.mp_loader` / `homography` resolve inside the reference (util_track is a
+    namespace package there and a namespace portion here: whichever root comes first wins per submodule)."""
+    for k in [k for k in sys.modules if k in ("homography", "MC3D_crop_tracker") or k == "util_track" or k.startswith("util_track.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        trk = importlib.import_module("MC3D_crop_tracker")
+        hgmod = importlib.import_module("homography")
+    finally:
+        sys.path.remove(REF)
+    for m in (trk, hgmod, sys.modules["util_track.kf"]):
+        assert os.path.realpath(m.__file__).startswith(os.path.realpath(REF) + os.sep), m.__file__
+    for k in [k for k in sys.modules if k == "util_track" or k.startswith("util_track.") or k == "homography"]:
+        del sys.modules[k]                          # later imports of these names are not to find the reference's
+    return trk, hgmod
+
+
 def gen_kf():
     """Torch_KF (util_track/kf.py) itself: add, predict with the default dt / a float dt / a per-object dt tensor, view,
     update.  The module imports matplotlib.pyplot at the top (unused by the class, absent here): stubbed."""
-    if "matplotlib" not in sys.modules:
-        mpl = types.ModuleType("matplotlib")
-        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
-        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, mpl.pyplot
-    sys.path.insert(0, REF)
-    try:
-        kfmod = importlib.import_module("util_track.kf")
-    finally:
-        sys.path.remove(REF)
+    matplotlib_stub()
+    kfmod = ref_module_from_file("_reference_util_track_kf", "util_track/kf.py")
     INIT, det, directions, times, speed, upd_ids, z, dts = gc.kf_inputs()
     out = {}
 
@@ -477,6 +518,12 @@ def gen_kf():
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at %s (build container only)" % REF)
+    global OUT
+    argv = sys.argv[1:]
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -484,7 +531,7 @@ def main():
     m_dir, l_dir, u_dir, a_dir = import_variant("dir")
     dir_mods = (m_dir, l_dir, u_dir, a_dir)
     m_2d, l_2d, u_2d, a_2d = import_variant("2d")
-    which = set(sys.argv[1:]) or {"anchors", "losses", "boxes", "model", "homography", "csv", "tracker_post", "crop_refine", "kf"}
+    which = set(argv) or {"anchors", "losses", "boxes", "model", "model_deep", "homography", "csv", "tracker_post", "crop_refine", "kf"}
     if "anchors" in which:
         gen_anchors(a_dir)
     if "losses" in which:
@@ -493,6 +540,8 @@ def main():
         gen_boxes(m_dir, u_dir, m_2d, u_2d)
     if "model" in which:
         gen_model(m_dir, m_2d)
+    if "model_deep" in which:
+        gen_model_deep(m_dir)
     if "homography" in which:
         gen_homography()
     if "csv" in which:
