@@ -1,13 +1,18 @@
 """GPU parity of the whole detector (drop-in ResNet on the HIP engine) against the golden vectors the
 REFERENCE produced on CPU (tests/golden/model.npz, model_deep.npz) and against the oracle.
 
-Tolerances: fp32 losses / boxes / scores within 1e-4 relative (north_star).  Parameter gradients (``grad_close``):
-L2-relative error of the whole tensor <= GRAD_L2[mode] -- 10x what was measured on the GPU box (direct kernels ~2e-6,
-Winograd F(4x4,3x3) layers on ~2e-5; tests/gpu_stats.json holds the last measured values) -- and no element further
-than GRAD_MAX of the gradient's max magnitude.  The element-wise bound stays looser than the L2 one because of one known
-effect: where ONE pre-activation lies within fp32 rounding of zero, the different summation order of the MFMA tiles flips
-its ReLU mask, which moves a single bias-gradient element by ~3e-3 of the max (seen once on ResNet-18
-layer1.1.bn1.bias); a systematic error of that size would blow the L2 bound.
+Tolerances: fp32 losses / boxes / scores within 1e-4 relative (north_star).  Parameter gradients are compared tensor by
+tensor (L2-relative error, and the largest element error relative to the gradient's max magnitude).  Measured on the
+MI355X (profiles/r02_gradient_errors.txt): at the goldens' small sizes 3e-7..2e-6 with the direct kernels and 1e-6..1e-5
+with the Winograd F(4x4,3x3) layers on; the bounds are ~10x that (GRAD_L2).  ONE effect is outside them and is not an
+error of the kernels: an activation that lies within rounding of zero (|x| ~ 1e-6 of the layer's max) comes out on the
+other side of the ReLU than in the CPU run, its mask flips, and everything upstream of that element moves -- measured:
+ResNet-18, batch 2, ONE flipped mask in 17 920 (regressionModel.conv3 at the P4 level, activation 1.4e-6 against a max of
+27) puts fpn.P4_2.bias at 3.8e-4 (tools/dbg/wino_bias.py).  So: at least 90 % of the compared tensors must meet the tight
+bound and every tensor the loose one (GRAD_L2_FLIP / GRAD_MAX); a systematic error 10x the measured one fails the first.
+At the full benchmark size (test_cfg2_full_size_against_oracle: 1e8 activations, hundreds of such flips, accumulating
+towards the stem) heads and FPN stay at <= 1.1e-5 and the backbone reaches 1e-4 .. 6e-4 with EITHER kernel family, so
+that test has its own bounds per group, again ~10x the measured values.
 """
 import json
 import os
@@ -20,9 +25,10 @@ import golden_cases as gc
 
 pytestmark = pytest.mark.gpu
 
-GRAD_L2 = {"direct": 3e-5, "wino": 3e-4}
-GRAD_MAX = 5e-3
+GRAD_L2 = {"direct": 3e-5, "wino": 5e-5}             # tight: ~10x measured, >= 90 % of the tensors
+GRAD_L2_FLIP, GRAD_MAX = 2e-3, 5e-3                   # loose: a flipped ReLU mask upstream (see above), every tensor
 NORM_TOL = {"direct": 2e-5, "wino": 2e-4}
+CFG2_L2 = {"head": 1e-4, "backbone": 5e-3}            # measured 1.1e-5 / 6.1e-4
 STATS = {}
 
 
@@ -33,6 +39,7 @@ def _note(test, name, l2, mx):
     if mx >= w["worst_max"]:
         w["worst_max"], w["worst_max_name"] = mx, name
     w["n"] += 1
+    w.setdefault("all", {})[name] = [l2, mx]
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "gpu_stats.json"), "w") as f:
@@ -56,12 +63,23 @@ def rel_close(got, want, tol):
     assert err <= tol * (np.abs(want).max() + 1e-12), "max err %.3e vs max|ref| %.3e" % (err, np.abs(want).max())
 
 
-def grad_close(got, want, name, mode="wino", test="?"):
+MEASURE_ONLY = os.environ.get("RN_TEST_MEASURE") == "1"       # collect the statistics, assert nothing about gradients
+
+
+def grad_close(got, want, name, test, l2_tol=GRAD_L2_FLIP, max_tol=GRAD_MAX):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     l2 = np.sqrt(((got - want) ** 2).sum()) / (np.sqrt((want ** 2).sum()) + 1e-30)
     mx = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
     _note(test, name, float(l2), float(mx))
-    assert l2 <= GRAD_L2[mode] and mx <= GRAD_MAX, "%s [%s]: L2-rel %.3e, max-rel %.3e" % (name, mode, l2, mx)
+    if not MEASURE_ONLY:
+        assert l2 <= l2_tol and mx <= max_tol, "%s [%s]: L2-rel %.3e, max-rel %.3e" % (name, test, l2, mx)
+
+
+def most_within(test, tol, frac=0.9):
+    vals = [v[0] for v in STATS[test]["all"].values()]
+    ok = sum(v <= tol for v in vals)
+    if not MEASURE_ONLY:
+        assert ok >= frac * len(vals), "%s: only %d of %d gradients within %.1e (worst %.2e)" % (test, ok, len(vals), tol, max(vals))
 
 
 def test_state_dict_keys_match_reference_layout(dev):
@@ -111,9 +129,10 @@ def test_directional_train_losses_and_gradients(dev, golden, arch, mode):
         assert abs(np.sqrt((g ** 2).sum()) - ref_norm) <= NORM_TOL[mode] * ref_norm + 1e-9, (name, np.sqrt((g ** 2).sum()), ref_norm)
         full = "%s_dir_g_%s" % (arch, name)
         if full in z.files:
-            grad_close(g, z[full], name, mode, "train_%s_%s" % (arch, mode))
+            grad_close(g, z[full], name, "train_%s_%s" % (arch, mode))
             checked += 1
     assert checked > 30
+    most_within("train_%s_%s" % (arch, mode), GRAD_L2[mode])
 
 
 def test_flat2d_train_and_eval(dev, golden):
@@ -379,10 +398,12 @@ def test_cfg2_full_size_against_oracle(dev, mode):
     assert len(CFG2_PARAMS) >= 30
     named = dict(net.named_parameters())
     for name in CFG2_PARAMS:
-        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, mode, "cfg2_full_%s" % mode)
+        group = "head" if name.startswith(("fpn.", "regressionModel.", "classificationModel.")) else "backbone"
+        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, "cfg2_full_%s" % mode,
+                   l2_tol=CFG2_L2[group], max_tol=2 * GRAD_MAX)
     for name, p in named.items():                              # and every other gradient by its norm
         want = float(o["grads"][name].double().norm())
-        assert abs(float(p.grad.double().norm()) - want) <= 10 * NORM_TOL[mode] * want + 1e-12, name
+        assert abs(float(p.grad.double().norm()) - want) <= 2e-3 * want + 1e-12, name
     for p in net.parameters():
         p.grad = None
     net.eval()
