@@ -82,6 +82,10 @@ def test_golden_recipe_regenerates_the_committed_fixtures(tmp_path):
     committed = os.path.join(REPO, "tests", "golden")
     names = sorted(f for f in os.listdir(committed) if f.endswith(".npz"))
     assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    texts = sorted(f for f in os.listdir(committed) if f.endswith(".csv"))
+    assert texts == sorted(f for f in os.listdir(tmp_path) if f.endswith(".csv")) and texts
+    for fn in texts:
+        assert open(os.path.join(tmp_path, fn), "rb").read() == open(os.path.join(committed, fn), "rb").read(), fn
     for fn in names:
         a, b = np.load(os.path.join(tmp_path, fn)), np.load(os.path.join(committed, fn))
         assert sorted(a.files) == sorted(b.files), fn

@@ -338,6 +338,18 @@ def gen_csv_kat():
                         columns=np.array(["cam_code"] + keep))
 
 
+def gen_csv_rows():
+    """A strided sample of the reference's shipped result files AS TEXT (data files, not source): the byte-level fixture
+    for the row formatting of write_results_csv (MC3D_crop_tracker.py:1318-1453).  One header + sample per file."""
+    for fn, stride, out_name in (("3D_tracking_results.csv", 59, "results_rows_3D_tracking_results.csv"),
+                                 ("working_3D_tracking_data.csv", 3, "results_rows_working_3D_tracking_data.csv")):
+        with open(os.path.join(REF, fn), newline="") as f:
+            lines = f.read().split("\r\n")
+        keep = [lines[0]] + [l for i, l in enumerate(lines[1:]) if l and i % stride == 0]
+        with open(os.path.join(OUT, out_name), "w", newline="") as f:
+            f.write("\r\n".join(keep) + "\r\n")
+
+
 def tracker_import_shims():
     """Two more stub attributes the tracker module needs at import time."""
     tv = sys.modules["torchvision"]
@@ -531,7 +543,7 @@ def main():
     m_dir, l_dir, u_dir, a_dir = import_variant("dir")
     dir_mods = (m_dir, l_dir, u_dir, a_dir)
     m_2d, l_2d, u_2d, a_2d = import_variant("2d")
-    which = set(argv) or {"anchors", "losses", "boxes", "model", "model_deep", "homography", "csv", "tracker_post", "crop_refine", "kf"}
+    which = set(argv) or {"anchors", "losses", "boxes", "model", "model_deep", "homography", "csv", "csv_rows", "tracker_post", "crop_refine", "kf"}
     if "anchors" in which:
         gen_anchors(a_dir)
     if "losses" in which:
@@ -546,6 +558,8 @@ def main():
         gen_homography()
     if "csv" in which:
         gen_csv_kat()
+    if "csv_rows" in which:
+        gen_csv_rows()
     if "tracker_post" in which or "crop_refine" in which:
         tracker_import_shims()
     if "tracker_post" in which:
