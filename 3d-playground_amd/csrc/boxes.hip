@@ -16,14 +16,11 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ decode
-__global__ __launch_bounds__(256) void decode_dir_kernel(const float4 *__restrict__ anchors, const float *__restrict__ reg,
-                                                         float *__restrict__ out, int64_t A, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const float4 a = anchors[i % A];
+// One anchor's decode: 12 regression values -> 16 corner coordinates + 2D box (D/utils.py:104-135), written as 5 float4.
+__device__ __forceinline__ void decode_dir_one(const float4 a, const float *__restrict__ reg12, float *__restrict__ out20) {
     const float w = a.z - a.x, h = a.w - a.y;                                  // D/utils.py:104-107
     const float cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
-    const float4 *r4 = reinterpret_cast<const float4 *>(reg + i * 12);
+    const float4 *r4 = reinterpret_cast<const float4 *>(reg12);
     const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
     const float r[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
     float o[20];
@@ -41,9 +38,35 @@ __global__ __launch_bounds__(256) void decode_dir_kernel(const float4 *__restric
     o[17] = r[9] * h + cy;
     o[18] = r[10] * w + cx;
     o[19] = r[11] * h + cy;
-    float4 *o4 = reinterpret_cast<float4 *>(out + i * 20);
+    float4 *o4 = reinterpret_cast<float4 *>(out20);
 #pragma unroll
     for (int k = 0; k < 5; ++k) o4[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+__global__ __launch_bounds__(256) void decode_dir_kernel(const float4 *__restrict__ anchors, const float *__restrict__ reg,
+                                                         float *__restrict__ out, int64_t A, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    decode_dir_one(anchors[i % A], reg + i * 12, out + i * 20);
+}
+
+// Decode of the score filter's survivors only: candidate k = flat anchor index sel[k] of [B*A].  The eval
+// branches decode all B*A anchors first (D/model.py:347: 249 MB written at batch 8) and then keep <= 10 000 of them; the
+// arithmetic per anchor is the same function, so the kept boxes are bit-identical.  Also emits what the NMS and the
+// output gather need in candidate order: the candidate's score and its image index (D/model.py:314-316).
+__global__ __launch_bounds__(256) void decode_dir_select_kernel(const float4 *__restrict__ anchors, const float *__restrict__ reg,
+                                                                int64_t A, const float *__restrict__ scores, int64_t score_stride,
+                                                                const int32_t *__restrict__ sel, const int32_t *__restrict__ count,
+                                                                int max_cand, float *__restrict__ boxes, float *__restrict__ cscore,
+                                                                int32_t *__restrict__ image) {
+    int n = count[0];
+    if (n > max_cand) n = max_cand;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = sel[k];
+    decode_dir_one(anchors[i % A], reg + i * 12, boxes + (int64_t)k * 20);
+    cscore[k] = scores[i * score_stride];
+    if (image) image[k] = (int32_t)(i / A);
 }
 
 extern "C" int rn_decode_dir(const float *anchors, const float *reg, float *boxes, int B, int64_t A, void *stream) {
@@ -74,6 +97,17 @@ __global__ __launch_bounds__(256) void decode_2d_kernel(const float4 *__restrict
         o.z = fminf(o.z, width); o.w = fminf(o.w, height);
     }
     out[i] = o;
+}
+
+extern "C" int rn_decode_dir_select(const float *anchors, const float *reg, int64_t A, const float *scores, int64_t score_stride,
+                                    const int32_t *sel_idx, const int32_t *count, int max_candidates, float *boxes,
+                                    float *cand_scores, int32_t *cand_image, void *stream) {
+    if (A <= 0 || max_candidates <= 0 || score_stride <= 0) return RN_EINVAL;
+    hipLaunchKernelGGL(decode_dir_select_kernel, dim3(rn_blocks(max_candidates, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(anchors), reg, A, scores, score_stride, sel_idx, count, max_candidates,
+                       boxes, cand_scores, cand_image);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }
 
 extern "C" int rn_decode_2d(const float *anchors, const float *deltas, float *boxes, int B, int64_t A, int clip,

@@ -28,6 +28,7 @@ SIGNATURES = {
     "rn_focal_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_assign": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rn_decode_dir": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp]),
+    "rn_decode_dir_select": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rn_decode_2d": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp]),
     "rn_clip_boxes": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp]),
     "rn_post_workspace_bytes": (c_i64, [c_i64, c_i64]),

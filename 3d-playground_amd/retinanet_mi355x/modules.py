@@ -304,12 +304,11 @@ class ResNet(nn.Module):
                 reg, cls, _ = eng.forward(self._tensor_dict(), img_batch, save=False)
             anc = eng.anchors(H_in, W_in, reg.device)
             if self.directional:
-                boxes = ops.decode_dir(anc, reg)
-                if MULTI_FRAME:                                            # D/model.py:311-344
-                    return ops.postprocess_multi(cls, boxes)
+                if MULTI_FRAME:                                            # D/model.py:311-344, decoding the survivors only
+                    return ops.detect_multi(cls, reg, anc)
                 if LOCALIZE:                                               # D/model.py:362-363
-                    return boxes, cls
-                return ops.postprocess_single(cls, boxes)                  # D/model.py:365-397
+                    return ops.decode_dir(anc, reg), cls
+                return ops.detect_single(cls, reg, anc)                    # D/model.py:365-397
             boxes = ops.decode_2d(anc, reg, clip_hw=(H_in, W_in))          # R/model.py:270-271
             if LOCALIZE:
                 return boxes, cls

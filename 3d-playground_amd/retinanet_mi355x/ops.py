@@ -294,6 +294,86 @@ def postprocess_multi(cls, boxes20):
     return scores[idx], classes[idx], boxes20.reshape(n, 20)[idx], torch.div(idx, A, rounding_mode="floor")
 
 
+def _arange_i32(n, device, _cache={}):
+    key = (n, str(device))
+    if key not in _cache:
+        _cache[key] = torch.arange(n, dtype=torch.int32, device=device)
+    return _cache[key]
+
+
+def detect_multi(cls, reg, anchor_boxes):
+    """MULTI_FRAME eval branch (D/model.py:311-344) from the head outputs, decoding ONLY the survivors of the score
+    filter: row max over classes -> adaptive threshold (<= 10 000 candidates) -> decode those (rn_decode_dir_select; the
+    reference decodes all B*A anchors first, :347) -> batched NMS keyed by image on the compact boxes.  Same survivors,
+    bit-identical boxes.  -> (scores[K], classes[K] i64, boxes[K,20], im_index[K] i64)."""
+    lib = _hip.load()
+    _hip.need_gpu(cls, reg, anchor_boxes)
+    cls, reg = _hip.f32c(cls), _hip.f32c(reg)
+    anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
+    B, A, C = cls.shape
+    n = B * A
+    dev = cls.device
+    scores = torch.empty(n, dtype=torch.float32, device=dev)
+    classes = torch.empty(n, dtype=torch.int64, device=dev)
+    buf = _PostBuffers(n, 1, KEEP, dev)
+    cboxes = torch.empty((KEEP, 20), dtype=torch.float32, device=dev)
+    cscore = torch.empty(KEEP, dtype=torch.float32, device=dev)
+    cimage = torch.empty(KEEP, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.rn_rowmax(cls.data_ptr(), n, C, scores.data_ptr(), classes.data_ptr(), _hip.stream()), "rn_rowmax")
+        _select(lib, scores.data_ptr(), n, 1, 1e-7, -1.0, buf, 0)
+        _hip.check(lib.rn_decode_dir_select(anc.data_ptr(), reg.data_ptr(), A, scores.data_ptr(), 1, buf.sel[0].data_ptr(),
+                                            buf.count[0, 0:1].data_ptr(), KEEP, cboxes.data_ptr(), cscore.data_ptr(),
+                                            cimage.data_ptr(), _hip.stream()), "rn_decode_dir_select")
+        _hip.check(lib.rn_nms(cboxes.data_ptr(), 20, 16, cscore.data_ptr(), 1, _arange_i32(KEEP, dev).data_ptr(),
+                              cimage.data_ptr(), buf.count[0, 0:1].data_ptr(), KEEP, 0.5, buf.ws.data_ptr(),
+                              buf.keep[0].data_ptr(), buf.count[0, 1:2].data_ptr(), _hip.stream()), "rn_nms")
+    counts = buf.count.cpu().numpy()
+    kept = buf.keep[0, :counts[0, 1]].long()                              # candidate positions, decreasing score
+    return cscore[kept], classes[buf.sel[0].long()[kept]], cboxes[kept], cimage[kept].long()
+
+
+def detect_single(cls, reg, anchor_boxes):
+    """Single-frame eval branch (D/model.py:346-397) from the head outputs, decoding only each class's survivors.
+    cls [1,A,C], reg [1,A,12] -> [scores[K], class_idx[K] i64, boxes[K,20]]."""
+    lib = _hip.load()
+    _hip.need_gpu(cls, reg, anchor_boxes)
+    if cls.shape[0] != 1:
+        raise RuntimeError("single-frame post-process assumes batch 1 (D/model.py:366 squeezes the batch away); "
+                           "use MULTI_FRAME=True for batches")
+    cls, reg = _hip.f32c(cls), _hip.f32c(reg)
+    anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
+    A, C = cls.shape[1], cls.shape[2]
+    dev = cls.device
+    buf = _PostBuffers(A, C, KEEP, dev)
+    cboxes = torch.empty((C, KEEP, 20), dtype=torch.float32, device=dev)
+    cscore = torch.empty((C, KEEP), dtype=torch.float32, device=dev)
+    ar = _arange_i32(KEEP, dev)
+    with torch.cuda.device(dev):
+        for c in range(C):
+            sp = cls.data_ptr() + 4 * c
+            _select(lib, sp, A, C, 1e-25, -1.0, buf, c)
+            _hip.check(lib.rn_decode_dir_select(anc.data_ptr(), reg.data_ptr(), A, sp, C, buf.sel[c].data_ptr(),
+                                                buf.count[c, 0:1].data_ptr(), KEEP, cboxes[c].data_ptr(), cscore[c].data_ptr(),
+                                                None, _hip.stream()), "rn_decode_dir_select")
+            _hip.check(lib.rn_nms(cboxes[c].data_ptr(), 20, 16, cscore[c].data_ptr(), 1, ar.data_ptr(), None,
+                                  buf.count[c, 0:1].data_ptr(), KEEP, 0.5, buf.ws.data_ptr(), buf.keep[c].data_ptr(),
+                                  buf.count[c, 1:2].data_ptr(), _hip.stream()), "rn_nms")
+    counts = buf.count.cpu().numpy()
+    out_s, out_c, out_b = [], [], []
+    for c in range(C):
+        if counts[c, 0] == 0:
+            continue                                                       # D/model.py:376-378
+        kept = buf.keep[c, :counts[c, 1]].long()
+        out_s.append(cscore[c][kept])
+        out_c.append(torch.full((kept.numel(),), c, dtype=torch.int64, device=dev))
+        out_b.append(cboxes[c][kept])
+    if not out_s:
+        e = torch.zeros(0, device=dev)
+        return [e, torch.zeros(0, dtype=torch.int64, device=dev), e.clone()]
+    return [torch.cat(out_s), torch.cat(out_c), torch.cat(out_b)]
+
+
 def postprocess_2d(cls, boxes4):
     """2D eval branch (R/model.py:283-311): per class score > 0.05, NMS(0.5)."""
     lib = _hip.load()
@@ -359,10 +439,18 @@ def _mats(m, device):
     return torch.as_tensor(np.ascontiguousarray(m, dtype=np.float64)).to(device)
 
 
+def _state6(state):
+    """[d, >= 6] -> contiguous fp32 [d,6]: the reference's transforms index columns 0..5 of the state and ignore further
+    ones (homography.py:305-320; the tracker's states carry the speed as a 7th, MC3D_crop_tracker.py:1278)."""
+    if state.dim() != 2 or state.shape[1] < 6:
+        raise RuntimeError("state tensors are [d, 6] (x, y, l, w, h, direction[, ...]); got %s" % (tuple(state.shape),))
+    return _hip.f32c(state[:, :6])
+
+
 def hg_state_to_space(state):
     lib = _hip.load()
     _hip.need_gpu(state)
-    s = _hip.f32c(state)
+    s = _state6(state)
     out = torch.empty((s.shape[0], 8, 3), dtype=torch.float32, device=s.device)
     if s.shape[0]:
         with torch.cuda.device(s.device):
@@ -385,7 +473,7 @@ def hg_to_im(points, P, P2=None, mat_index=None, from_state=True):
     """state [d,6] (from_state) or space [d,8,3] fp32 -> image [d,8,2] fp64.  P: device fp64 [n,3,4]."""
     lib = _hip.load()
     _hip.need_gpu(points, P, P2, mat_index)
-    p = _hip.f32c(points)
+    p = _state6(points) if from_state else _hip.f32c(points)
     d = p.shape[0]
     out = torch.empty((d, 8, 2), dtype=torch.float64, device=p.device)
     if d:

@@ -78,6 +78,14 @@ int rn_assign(const float *anchors, const float *ann, int B, int64_t A, int N, i
  * clip != 0, ClipBoxes.forward fused (R/utils.py:134-144): deltas [B,A,4] -> boxes [B,A,4].
  * rn_clip_boxes is the standalone in-place ClipBoxes. */
 int rn_decode_dir(const float *anchors, const float *reg, float *boxes, int B, int64_t A, void *stream);
+/* Decode of the score filter's survivors only (the eval branches decode all B*A anchors at D/model.py:347 and then keep
+ * <= 10 000, :322-328 / :368-374): candidate k (k < min(*count, max_candidates)) is flat anchor sel_idx[k] of [B*A];
+ * writes boxes [max_candidates,20] (same per-anchor arithmetic as rn_decode_dir: bit-identical rows), cand_scores[k] =
+ * scores[sel_idx[k] * score_stride] and, when cand_image != NULL, the image index sel_idx[k] / A (D/model.py:314-316).
+ * count stays on the device (no host sync). */
+int rn_decode_dir_select(const float *anchors, const float *reg, int64_t A, const float *scores, int64_t score_stride,
+                         const int32_t *sel_idx, const int32_t *count, int max_candidates, float *boxes,
+                         float *cand_scores, int32_t *cand_image, void *stream);
 int rn_decode_2d(const float *anchors, const float *deltas, float *boxes, int B, int64_t A,
                  int clip, float width, float height, void *stream);
 int rn_clip_boxes(float *boxes, int64_t n, float width, float height, void *stream);

@@ -183,6 +183,28 @@ def test_postprocess_multi(ops, dev, golden):
     assert sha(b.cpu().numpy()) == str(z["dir_multi_boxes_sha"])
 
 
+def test_detect_from_head_outputs_decodes_survivors_only(ops, dev, golden):
+    """ops.detect_single / detect_multi (what the model's eval branches run: score filter first, decode of the <= 10 000
+    survivors, NMS on the compact boxes) against the same reference goldens as the decode-everything form."""
+    z = golden("boxes")
+    anc = torch.from_numpy(oanchors.anchors_for_image(*gc.POST_HW)).to(dev)
+    cls, reg = gc.post_single_inputs()
+    s, c, b = ops.detect_single(cls.to(dev), reg.to(dev), anc)
+    assert np.array_equal(s.cpu().numpy(), z["dir_single_scores"])
+    assert np.array_equal(c.cpu().numpy(), z["dir_single_classes"])
+    assert sha(b.cpu().numpy()) == str(z["dir_single_boxes_sha"])
+    cls, reg = gc.post_multi_inputs()
+    s, c, b, im = ops.detect_multi(cls.to(dev), reg.to(dev), anc)
+    assert np.array_equal(s.cpu().numpy(), z["dir_multi_scores"])
+    assert np.array_equal(c.cpu().numpy(), z["dir_multi_classes"])
+    assert np.array_equal(im.cpu().numpy(), z["dir_multi_im"])
+    assert sha(b.cpu().numpy()) == str(z["dir_multi_boxes_sha"])
+    assert im.dtype == torch.int64 and c.dtype == torch.int64
+    # nothing survives the threshold grid (reference quirk): empty outputs of the right shapes
+    s, c, b, im = ops.detect_multi(torch.full((2, anc.shape[1], 1), 0.9, device=dev), reg[:2].to(dev), anc)
+    assert s.numel() == 0 and b.shape == (0, 20) and im.numel() == 0
+
+
 def test_postprocess_2d(ops, dev, golden):
     z = golden("boxes")
     cls, reg = gc.post_2d_inputs()
