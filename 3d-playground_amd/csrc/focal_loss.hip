@@ -25,21 +25,29 @@
 //
 // Roofline: HBM.  Forward algorithmic bytes = B*A*C*4 (cls) + A*16 (anchors; read once per XCD, L2-resident for the other
 // images) + B*N*cols*4 = 105.9 MB at B=8, A=389 205, C=8; measured HBM reads 104 MB.  Backward adds
-// the dcls and dreg writes (99.6 + 149.5 MB).  What bounds it in practice (profiles/r01_loss_analysis.txt): a bare
-// 100 MB streaming read in the same launch shape takes 17 us; the launch, the dependent-latency prologue (labels ->
-// LDS -> first unit) and the completion/epilogue chain add ~15 us that no amount of VALU trimming removes.
+// the dcls and dreg writes (99.6 + 149.5 MB).  What bounds it in practice (profiles/r01_loss_analysis.txt,
+// r02_loss_analysis.txt): a bare 100 MB streaming read in the same launch shape takes 17 us; of the forward's 31 us the
+// loads-only skeleton of this kernel is 21.8, the focal arithmetic adds 1.6, the assignment 3.0, publishing the partials
+// 0.6 and the two-level completion chain 4.3 (five dependent device-scope round trips of ~0.8 us).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
-#define NTHR 256          // threads per workgroup
+#ifndef FOCAL_NTHR
+#define FOCAL_NTHR 256
+#endif
+#define NTHR FOCAL_NTHR   // threads per workgroup
 #define APT 4             // anchors per thread of rn_assign
 #define TILE (NTHR * APT) // rn_assign: 1024 anchors per workgroup
 #define NWAVES (NTHR / 64)
 #define UAPT 2            // fused loss: anchors per lane per unit
 #define UNIT (64 * UAPT)  // fused loss: a wave's work item = 128 consecutive anchors of one image
 #define QCAP 256          // fused loss: capacity of a wave's queue of positive anchors (>= 2 * UNIT)
-#define RN_FOCAL_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs: no spills)
+#ifndef RN_FOCAL_WAVES_PER_SIMD
+#define RN_FOCAL_WAVES_PER_SIMD 4
+#endif
+#define RN_FOCAL_WAVES_NOTE 4  // (HIP: second launch-bound = waves per SIMD) the register allocator must leave room for (128 VGPRs: no spills)
 #define RN_FOCAL_RESIDENT 768   // workgroups of the persistent grid (3 per CU).  Measured at B=8, A=389 205: 512..768 is
                                 // the optimum; more workgroups lengthen the same-address completion-counter queue
                                 // (~8 ns each) faster than they add memory-level parallelism
@@ -47,9 +55,13 @@
 // Workgroups per image of the persistent loss kernel: all B*G workgroups are resident in one round; G is a multiple
 // of 8 so that workgroup g of every image lands on XCD g%8 (ids are dealt round-robin) and the images share the
 // anchors of "their" units in that XCD's L2.
+static inline int focal_resident() {                             // RN_FOCAL_RESIDENT in the environment: tuning sweeps only
+    static const int v = [] { const char *e = getenv("RN_FOCAL_RESIDENT"); const int x = e ? atoi(e) : 0; return x >= 8 ? x : RN_FOCAL_RESIDENT; }();
+    return v;
+}
 static inline int focal_groups(int B, int64_t A) {
     const int64_t units = (A + UNIT - 1) / UNIT;
-    int64_t G = (RN_FOCAL_RESIDENT / B) & ~7;
+    int64_t G = (focal_resident() / B) & ~7;
     if (G < 8) G = 8;
     const int64_t need = (units + NWAVES - 1) / NWAVES;          // more workgroups than units/4 would idle
     if (G > need) G = need >= 8 ? ((need + 7) & ~7LL) : need;
@@ -81,12 +93,16 @@ struct ImageStats {       // one per image, written by finalize, read by backwar
 
 static_assert(sizeof(ImageStats) == 32, "layout");
 
-// Workspace layout: [64 B] completion counter (must be ZERO on entry to rn_focal_loss_fwd; left zero on exit)
-//                   | [B] ImageStats | [B][4] double per-image loss terms | [B][G] float4 partial sums
+// Workspace layout: [64 B] batch completion counter | [B] per-image completion counters (padded to 64 B) -- these first
+//                   rn_focal_workspace_zero_bytes(B) bytes must be ZERO on entry to rn_focal_loss_fwd; left zero on exit --
+//                   | [B] ImageStats | [B][8] double per-image loss terms | [B][G] float4 partial sums
 #define RN_WS_HEAD 64
+#define RN_TERMS 8        // doubles per image: cls, reg, vp loss terms, has_labels, npos, (3 unused)
+static inline int64_t focal_counter_bytes(int B) { return ((int64_t)B * 4 + 63) / 64 * 64; }
+extern "C" int64_t rn_focal_workspace_zero_bytes(int B) { return B > 0 ? RN_WS_HEAD + focal_counter_bytes(B) : 0; }
 extern "C" int64_t rn_focal_workspace_bytes(int B, int64_t A) {
     if (B <= 0 || A <= 0) return 0;
-    return RN_WS_HEAD + (int64_t)B * sizeof(ImageStats) + (int64_t)B * 4 * sizeof(double) +
+    return RN_WS_HEAD + focal_counter_bytes(B) + (int64_t)B * sizeof(ImageStats) + (int64_t)B * RN_TERMS * sizeof(double) +
            (int64_t)B * focal_groups(B, A) * 4 * sizeof(float);
 }
 
@@ -338,99 +354,140 @@ __device__ __forceinline__ float focal_elem(float x, bool pos, float wl) {
     return (x < 1e-4f || x > 1.0f - 1e-4f) ? 0.f : g;                         // clamp passes no gradient outside
 }
 
-// Epilogue of the forward, run by the LAST workgroup to finish (completion counter): wave w adds the partials of images
-// w, w+4, ... in fp64 in a fixed lane / group order (bit-reproducible), checks whether the image has any label row,
-// derives the per-image loss terms and gradient scales; thread 0 then forms the batch means
-// (D/losses.py:152, 350, 304, 359-362).  `s_part` is 4*4*64 doubles of LDS that the caller no longer needs.
-template <bool DIR>
-__device__ __forceinline__ void focal_finalize_last(const float4 *__restrict__ partials, int G, int B,
-                                                    const float *__restrict__ ann, int N, ImageStats *__restrict__ stats,
-                                                    double *__restrict__ terms, float *__restrict__ losses,
-                                                    double *s_part) {
-    constexpr int COLS = DIR ? 27 : 5;
-    constexpr int CLS_COL = DIR ? 20 : 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < B; j += NWAVES) {
-        double v[4] = {0, 0, 0, 0};
-        for (int t0 = 0; t0 < G; t0 += 64 * 4) {                             // 4 independent loads in flight per lane
-            float4 p[4];
+// Epilogue of the forward, two levels so that nothing waits in one long same-address queue and the per-image work runs
+// in parallel (profiles/r01_loss_analysis.txt: 768 arrivals at one counter ~6 us, then a serial epilogue ~7 us):
+//   level 1  the LAST workgroup of image j to finish (per-image counter: G arrivals) adds that image's G partials -- all
+//            256 threads, fp64, a fixed strided + butterfly order (bit-reproducible) --, checks whether the image has any
+//            label row, and publishes the per-image loss terms;
+//   level 2  the last of those B workgroups (batch counter: B arrivals) forms the batch means and writes the per-image
+//            gradient scales the backward kernel reads (D/losses.py:152, 350, 304, 359-362).
+__device__ __forceinline__ double shfl_xor_f64(double v, int off) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, off, 64);
+    hi = __shfl_xor(hi, off, 64);
+    return __hiloint2double(hi, lo);
+}
+// Sum of v[0..NV) over the 256 threads of the workgroup in a fixed order; valid in thread 0.  red: 4*NV doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum_f64(double (&v)[NV], double *red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                                      // agent-scope loads: see the publishing side
-                const int t = t0 + k * 64 + lane;
-                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(partials) +
-                                              2 * ((int64_t)j * G + (t < G ? t : G - 1));
-                const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p[k] = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
-                                   __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
-            }
+    for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (t0 + k * 64 + lane < G) { v[0] += p[k].x; v[1] += p[k].y; v[2] += p[k].z; v[3] += p[k].w; }
-            }
-        }
+        for (int off = 32; off > 0; off >>= 1) v[i] += shfl_xor_f64(v[i], off);
+    if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_part[(wave * 4 + i) * 64 + lane] = v[i];
-        bool any = false;
-        for (int r = lane; r < N; r += 64) any |= ann[((int64_t)j * N + r) * COLS + CLS_COL] != -1.0f;
-        const bool has = __ballot(any) != 0ull;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 4) {                                      // same-wave LDS traffic: program order suffices
-            double t = 0.0;
-            for (int k = 0; k < 64; ++k) t += s_part[(wave * 4 + lane) * 64 + k];
-            s_part[(wave * 4 + lane) * 64] = t;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = s_part[(wave * 4 + i) * 64];
-            const double npos = v[3];
-            ImageStats st;
-            st.npos = (float)npos;
-            st.has_labels = has ? 1.f : 0.f;
-            st.pad[0] = st.pad[1] = st.pad[2] = 0.f;
-            const double nvals = DIR ? 20.0 : 4.0;
-            double lc, lr = 0.0, lv = 0.0;
-            if (!has) {
-                lc = v[0];                                                    // raw sum, not normalised (D/losses.py:58-87)
-                st.cls_scale = 1.0f; st.reg_scale = 0.f; st.vp_scale = 0.f;
-            } else {
-                const double dn = npos > 1.0 ? npos : 1.0;                    // clamp(min=1), D/losses.py:152
-                lc = v[0] / dn;
-                st.cls_scale = (float)(1.0 / dn);
-                if (npos > 0.0) {
-                    lr = v[1] / (npos * nvals);                               // mean over [P,20] / [P,4]
-                    lv = v[2] / (3.0 * npos);                                 // mean over P of (sum_k)/3
-                    st.reg_scale = (float)(1.0 / (npos * nvals));
-                    st.vp_scale = (float)(1.0 / (3.0 * npos));
-                } else {
-                    st.reg_scale = 0.f; st.vp_scale = 0.f;
-                }
-            }
-            terms[j * 4 + 0] = lc; terms[j * 4 + 1] = lr; terms[j * 4 + 2] = lv; terms[j * 4 + 3] = has ? 1.0 : 0.0;
-            stats[j] = st;
-        }
+        for (int i = 0; i < NV; ++i) red[w * NV + i] = v[i];
     }
-    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
-        double sum[3] = {0, 0, 0};
-        int vp_images = 0;
-        for (int j = 0; j < B; ++j) {                                          // plain loads: independent, issued together
-            const double *t = terms + j * 4;
-            sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2];
-            vp_images += t[3] != 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = 0.0;
+            for (int k = 0; k < NWAVES; ++k) t += red[k * NV + i];            // fixed order
+            v[i] = t;
         }
-        losses[0] = (float)(sum[0] / B);
-        losses[1] = (float)(sum[1] / B);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void publish_f64(double *p, double v) {     // agent scope, no L2 writeback (see the partials)
+    (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fetch_f64(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <bool DIR>
+__device__ __forceinline__ void focal_finalize_image(const float4 *__restrict__ partials, int G, int j,
+                                                     const float *__restrict__ ann, int N, double *__restrict__ terms,
+                                                     double *s_red) {
+    constexpr int COLS = DIR ? 27 : 5;
+    constexpr int CLS_COL = DIR ? 20 : 4;
+    double v[4] = {0, 0, 0, 0};
+    for (int t0 = 0; t0 < G; t0 += NTHR * 2) {                                // 2 independent partials in flight per thread
+        float4 p[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = t0 + k * NTHR + threadIdx.x;
+            const unsigned long long *q = reinterpret_cast<const unsigned long long *>(partials) +
+                                          2 * ((int64_t)j * G + (t < G ? t : G - 1));
+            const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p[k] = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                               __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (t0 + k * NTHR + threadIdx.x < G) { v[0] += p[k].x; v[1] += p[k].y; v[2] += p[k].z; v[3] += p[k].w; }
+    }
+    bool any = false;
+    for (int r = threadIdx.x; r < N; r += NTHR) any |= ann[((int64_t)j * N + r) * COLS + CLS_COL] != -1.0f;
+    const bool has = __syncthreads_or(any) != 0;
+    block_sum_f64<4>(v, s_red);
+    if (threadIdx.x == 0) {
+        const double npos = v[3];
+        const double nvals = DIR ? 20.0 : 4.0;
+        double lc, lr = 0.0, lv = 0.0;
+        if (!has) {
+            lc = v[0];                                                        // raw sum, not normalised (D/losses.py:58-87)
+        } else {
+            const double dn = npos > 1.0 ? npos : 1.0;                        // clamp(min=1), D/losses.py:152
+            lc = v[0] / dn;
+            if (npos > 0.0) {
+                lr = v[1] / (npos * nvals);                                   // mean over [P,20] / [P,4]
+                lv = v[2] / (3.0 * npos);                                     // mean over P of (sum_k)/3
+            }
+        }
+        double *t = terms + (int64_t)j * RN_TERMS;
+        publish_f64(t + 0, lc); publish_f64(t + 1, lr); publish_f64(t + 2, lv);
+        publish_f64(t + 3, has ? 1.0 : 0.0); publish_f64(t + 4, npos);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <bool DIR>
+__device__ __forceinline__ void focal_finalize_batch(int B, const double *__restrict__ terms, ImageStats *__restrict__ stats,
+                                                     float *__restrict__ losses, double *s_red, double *s_bc) {
+    double v[4] = {0, 0, 0, 0};                                               // cls, reg, vp sums, images with labels
+    for (int j = threadIdx.x; j < B; j += NTHR) {
+        const double *t = terms + (int64_t)j * RN_TERMS;
+        v[0] += fetch_f64(t + 0); v[1] += fetch_f64(t + 1); v[2] += fetch_f64(t + 2);
+        v[3] += fetch_f64(t + 3) != 0.0 ? 1.0 : 0.0;
+    }
+    block_sum_f64<4>(v, s_red);
+    if (threadIdx.x == 0) {
+        losses[0] = (float)(v[0] / B);
+        losses[1] = (float)(v[1] / B);
         // vp: mean over images that have labels; none -> 0/0 = NaN (the reference raises, D/losses.py:362)
-        losses[2] = DIR ? (float)(sum[2] / (double)vp_images) : 0.f;
-        for (int j = 0; j < B; ++j) {                                          // fold the batch means into the scales
-            ImageStats *st = stats + j;
-            st->cls_scale = st->cls_scale / (float)B;
-            st->reg_scale = st->reg_scale / (float)B;
-            st->vp_scale = vp_images > 0 ? st->vp_scale / (float)vp_images : 0.f;
+        losses[2] = DIR ? (float)(v[2] / v[3]) : 0.f;
+        s_bc[0] = v[3];
+    }
+    __syncthreads();
+    const int vp_images = (int)s_bc[0];
+    const double nvals = DIR ? 20.0 : 4.0;
+    for (int j = threadIdx.x; j < B; j += NTHR) {                              // per-image scales with the batch means folded in
+        const double *t = terms + (int64_t)j * RN_TERMS;
+        const bool has = fetch_f64(t + 3) != 0.0;
+        const double npos = fetch_f64(t + 4);
+        ImageStats st;
+        st.npos = (float)npos;
+        st.has_labels = has ? 1.f : 0.f;
+        st.pad[0] = st.pad[1] = st.pad[2] = 0.f;
+        st.cls_scale = 1.0f; st.reg_scale = 0.f; st.vp_scale = 0.f;
+        if (has) {
+            const double dn = npos > 1.0 ? npos : 1.0;
+            st.cls_scale = (float)(1.0 / dn);
+            if (npos > 0.0) {
+                st.reg_scale = (float)(1.0 / (npos * nvals));
+                st.vp_scale = (float)(1.0 / (3.0 * npos));
+            }
         }
+        st.cls_scale = st.cls_scale / (float)B;
+        st.reg_scale = st.reg_scale / (float)B;
+        st.vp_scale = vp_images > 0 ? st.vp_scale / (float)vp_images : 0.f;
+        stats[j] = st;
     }
 }
 
@@ -449,7 +506,7 @@ __device__ __forceinline__ void focal_finalize_last(const float4 *__restrict__ p
 // A template parameter, not a runtime test: loads inside conditional blocks make the compiler's s_waitcnt
 // accounting pessimistic.
 template <bool DIR, bool BWD, int CQ>
-__global__ __launch_bounds__(NTHR, RN_FOCAL_WAVES) void focal_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
+__global__ __launch_bounds__(NTHR, RN_FOCAL_WAVES_PER_SIMD) void focal_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
                                                      const float4 *__restrict__ anchors, const float *__restrict__ ann,
                                                      int64_t A, int C, int N, float *__restrict__ partials,
                                                      ImageStats *__restrict__ stats, float *__restrict__ dcls,
@@ -465,7 +522,7 @@ __global__ __launch_bounds__(NTHR, RN_FOCAL_WAVES) void focal_kernel(const float
     __shared__ int s_q[2][NWAVES][QCAP];                     // per wave: queue of positives -- [0] anchor index, [1] label row
     __shared__ float s_red[NWAVES * 4];
     __shared__ int s_last;
-    static_assert(sizeof(int) * 2 * NWAVES * QCAP >= sizeof(double) * NWAVES * 4 * 64, "epilogue scratch reuses the queues");
+    static_assert(sizeof(int) * 2 * NWAVES * QCAP >= sizeof(double) * (NWAVES * 4 + 1), "epilogue scratch reuses the queues");
 
     const int j = blockIdx.x / G, g = blockIdx.x - j * G;
     const int lane = threadIdx.x & 63;
@@ -756,13 +813,22 @@ __global__ __launch_bounds__(NTHR, RN_FOCAL_WAVES) void focal_kernel(const float
             (void)__hip_atomic_exchange(p64, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_exchange(p64 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+            s_last = atomicAdd(counter + RN_WS_HEAD / 4 + j, 1u) == (unsigned)G - 1;   // this image's counter: G arrivals
         }
         __syncthreads();
-        if (s_last) {                                                          // every partial is in: finish the losses here
-            focal_finalize_last<DIR>(reinterpret_cast<const float4 *>(partials), G, (int)(gridDim.x / G), ann, N, stats,
-                                     terms, losses, reinterpret_cast<double *>(&s_q[0][0][0]));
-            if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+        if (s_last) {                                                          // every partial of image j is in
+            double *s_red = reinterpret_cast<double *>(&s_q[0][0][0]);
+            const int B = (int)(gridDim.x / G);
+            focal_finalize_image<DIR>(reinterpret_cast<const float4 *>(partials), G, j, ann, N, terms, s_red);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(counter + RN_WS_HEAD / 4 + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+                s_last = atomicAdd(counter, 1u) == (unsigned)B - 1;            // batch counter: B arrivals
+            }
+            __syncthreads();
+            if (s_last) {                                                      // every image's terms are in
+                focal_finalize_batch<DIR>(B, terms, stats, losses, s_red, s_red + NWAVES * 4);
+                if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -785,9 +851,10 @@ static inline FocalWs focal_ws(void *workspace, int B) {
     char *w = reinterpret_cast<char *>(workspace);
     FocalWs r;
     r.counter = reinterpret_cast<unsigned *>(w);
-    r.stats = reinterpret_cast<ImageStats *>(w + RN_WS_HEAD);
-    r.terms = reinterpret_cast<double *>(w + RN_WS_HEAD + (size_t)B * sizeof(ImageStats));
-    r.partials = reinterpret_cast<float *>(w + RN_WS_HEAD + (size_t)B * sizeof(ImageStats) + (size_t)B * 4 * sizeof(double));
+    const size_t head = RN_WS_HEAD + (size_t)focal_counter_bytes(B);
+    r.stats = reinterpret_cast<ImageStats *>(w + head);
+    r.terms = reinterpret_cast<double *>(w + head + (size_t)B * sizeof(ImageStats));
+    r.partials = reinterpret_cast<float *>(w + head + (size_t)B * sizeof(ImageStats) + (size_t)B * RN_TERMS * sizeof(double));
     return r;
 }
 

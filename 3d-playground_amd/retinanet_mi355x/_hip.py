@@ -24,6 +24,7 @@ SIGNATURES = {
     "rn_anchors_fwd": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "rn_pairwise_iou": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "rn_focal_workspace_bytes": (c_i64, [c_i32, c_i64]),
+    "rn_focal_workspace_zero_bytes": (c_i64, [c_i32]),
     "rn_focal_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rn_focal_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_assign": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),

@@ -65,10 +65,11 @@ def assign(anchor_boxes, ann, directional=True):
 
 # ------------------------------------------------------------------------------------------------ loss
 def focal_workspace(B, A, device):
-    """Workspace of rn_focal_loss_fwd / _bwd.  The first 64 bytes are the forward's completion counter and must be zero
-    on entry (the kernel leaves them zero); the rest needs no initialisation."""
-    ws = torch.empty(_hip.load().rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=device)
-    ws[:64].zero_()
+    """Workspace of rn_focal_loss_fwd / _bwd.  Its head holds the forward's completion counters and must be zero on entry
+    (the kernel leaves it zero); the rest needs no initialisation."""
+    lib = _hip.load()
+    ws = torch.empty(lib.rn_focal_workspace_bytes(B, A), dtype=torch.uint8, device=device)
+    ws[:lib.rn_focal_workspace_zero_bytes(B)].zero_()
     return ws
 
 

@@ -51,15 +51,17 @@ int rn_pairwise_iou(const float *a, const float *b, float *iou, int64_t A, int N
  *
  *   cls [B,A,C] post-sigmoid, reg [B,A,n_reg], anchors [A,4], ann [B,N,label_cols] (padding rows: class -1)
  *   workspace: rn_focal_workspace_bytes(B, A) bytes, written by fwd, read by bwd (per-image statistics).  Its first
- *           64 bytes hold the forward's completion counter and must be ZERO when rn_focal_loss_fwd is called; the
- *           kernel leaves them zero, so a workspace can be reused call after call without clearing it again
- *           (re-zero it after an aborted launch).  One workspace serves one stream at a time.
+ *           rn_focal_workspace_zero_bytes(B) bytes hold the forward's completion counters (one per image + one for the
+ *           batch) and must be ZERO when rn_focal_loss_fwd is called; the kernel leaves them zero, so a workspace can be
+ *           reused call after call without clearing it again (re-zero it after an aborted launch).  One workspace
+ *           serves one stream at a time.
  *   losses: 3 floats  (cls, reg, vp; vp = 0 for the 2D variant).  An all-empty batch yields vp = NaN
  *           (the reference raises there, D/losses.py:362; the Python binding raises before launching).
  *   bwd: grad_losses = 3 device floats (dL/dcls_loss, dL/dreg_loss, dL/dvp_loss); writes dense
  *        dcls [B,A,C] and dreg [B,A,n_reg] (zeros where no gradient flows).
  */
 int64_t rn_focal_workspace_bytes(int B, int64_t A);
+int64_t rn_focal_workspace_zero_bytes(int B);
 int rn_focal_loss_fwd(const float *cls, const float *reg, const float *anchors, const float *ann,
                       int B, int64_t A, int C, int N, int directional,
                       void *workspace, float *losses, void *stream);
