@@ -1,0 +1,574 @@
+// bf16 implicit-GEMM convolution and weight gradient on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+// accumulation; dense peak ~2.5 PFLOP/s) -- the reduced-precision form of conv_igemm.hip / conv_wgrad.hip for BASELINE
+// configs[2] ("bf16 MFMA").  Same convolutions of the reference (every nn.Conv2d of D/model.py with its fused frozen
+// batch-norm / bias / residual / ReLU / sigmoid / FPN upsample-add epilogue, D/model.py:59-205, D/utils.py:12-80), same
+// rn_conv_desc geometry (so the same call computes data gradients), different storage: activations and packed weights
+// are bf16 (NHWC / [Cout][kh][kw][Cin]), accumulation and the whole epilogue are fp32, the result is rounded once on
+// the way out (bf16, or fp32 where the consumer is the loss).  Parameters stay fp32 master copies: the packed bf16
+// weights are derived per step (rn_pack_weights, then rn_f32_to_bf16).
+//
+// Tile / staging: identical to the fp32 kernel BYTE for byte -- a staged row is 64 bytes of K (32 bf16 instead of 16
+// floats), rows go global -> LDS by direct-to-LDS buffer loads, out-of-range offsets are the zero padding, the 16-byte
+// chunks of a row are XOR-permuted on the load's source address and on the fragment read.  A ds_read_b128 at
+// [row = lane&31][chunk 2*st + (lane>>5)] is exactly the A / B operand of one 32x32x16 MFMA (8 consecutive k per lane,
+// k 0-7 in lanes 0-31, 8-15 in lanes 32-63), so per 64-byte K-step a wave issues 8 b128 reads against 8 MFMAs of 32
+// cycles -- where the fp32 kernel runs 32 MFMAs of 64 cycles on the same bytes.  That ratio is the point: per byte
+// staged the matrix cores are busy 1/8 as long, so this kernel lives on L2 / LDS / HBM bandwidth, not on MFMA issue
+// (128x128 tile: 64 FLOP per staged byte).
+//
+// Weight gradient: dW[co][k] = sum over pixels of dY[pixel][co] * X[pixel + tap][ci] has the REDUCTION index (pixels) as
+// the row of both NHWC operands, while a 32x32x16 operand wants 8 consecutive reduction elements per lane.  The tiles
+// are staged as they lie ([pixel][channel], direct-to-LDS like conv_wgrad.hip) and read through ds_read_b64_tr_b16,
+// gfx950's transposing LDS read: per 16 lanes a 4-pixel x 16-channel block comes back channel-major, two of them make
+// one operand.  fp32 atomics into the same packed fp32 [Cout][Kpad] gradient buffer the fp32 path uses.
+//
+// Roofline: MFMA by FLOPs (2.5 PF dense), in practice the staging bandwidth (see above) and, for the 1x1 layers, HBM.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BF_BK 32                 // K elements per step = 64 bytes per staged row
+
+__device__ __forceinline__ int bf_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+__device__ __forceinline__ int bf_swz(int row) { return (row >> 2) & 3; }     // 64-byte rows (conv_igemm_tile.h: lds_swz<16>)
+
+__device__ __forceinline__ void bf_load4(const __bf16 *p, float (&v)[4]) {
+    const bf16x4 q = *reinterpret_cast<const bf16x4 *>(p);
+    v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+}
+
+// ---------------------------------------------------------------------------------------------- casts
+__global__ void f32_to_bf16_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + i);
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;     // plain casts: RNE, a NaN stays a NaN
+        *reinterpret_cast<bf16x4 *>(dst + i) = o;
+    } else {
+        for (int64_t k = i; k < n; ++k) dst[k] = (__bf16)src[k];
+    }
+}
+__global__ void bf16_to_f32_kernel(const __bf16 *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float v[4];
+        bf_load4(src + i, v);
+        *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int64_t k = i; k < n; ++k) dst[k] = (float)src[k];
+    }
+}
+extern "C" int rn_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream) {
+    if (n <= 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return RN_EINVAL;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(rn_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<__bf16 *>(dst), n);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+extern "C" int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stream) {
+    if (n <= 0 || ((uintptr_t)src & 7) || ((uintptr_t)dst & 15)) return RN_EINVAL;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(rn_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16 *>(src), dst, n);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- implicit GEMM
+// One 128 x 128 output tile; 4 waves as 2 x 2, each a 64 x 64 sub-tile = 2 x 2 accumulators of the 32x32x16 MFMA.
+// YF32: the output is written as fp32 (head outputs feeding the loss) instead of bf16; addend and mask are bf16.
+template <bool YF32>
+__global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
+                                                                 const __bf16 *__restrict__ w, void *__restrict__ yv,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask) {
+    constexpr int BM = 128, BN = 128, WN = 2;
+    constexpr int RF = 16;                                   // floats (4-byte words) per staged row: 64 bytes
+    constexpr int RPI = 16;                                  // rows one wave instruction fills (1 KiB / 64 B)
+    constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;      // DMA instructions per wave per K-step and operand
+    constexpr int STEP = (BM + BN) * RF;                     // 4-byte words per buffer: A rows, then B rows
+    constexpr int LDT = BN + 4;                              // epilogue: padded fp32 output tile row
+    constexpr int RP = BM / 2;                               // tile rows per epilogue pass (two passes)
+    constexpr int LDSF = 2 * STEP > RP * LDT ? 2 * STEP : RP * LDT;
+    __shared__ float lds[LDSF];
+
+    const int tile = bf_xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ntn = (d.Cout + BN - 1) / BN;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int64_t M = (int64_t)d.N * HoWo;
+    const int K = d.kh * d.kw * d.Cin;
+    const int Kpad = (K + 31) / 32 * 32;                     // packed weight rows: zero-padded to a multiple of 32 elements
+    const int nks = Kpad / BF_BK;
+    const int dmask = (1 << d.div_shift) - 1;
+
+    // buffer descriptors (scalar); out-of-range offsets read as zero = padding / rows past M / weight rows past Cout
+    const int n_first = (int)(m0 / HoWo);
+    const int64_t x_elems = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
+    const v4i32 rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride,
+                                 (unsigned)(x_elems * 2 > 0x7FFFFFFF ? 0x7FFFFFFF : x_elems * 2));
+    const v4i32 rs_b = make_rsrc(w, (unsigned)((int64_t)d.Cout * Kpad * 2));
+
+    // per-lane staging geometry: instruction j of this wave fills rows (wave*I + j)*16 .. +15 of the operand; the lane
+    // fills 16-byte position pos of row rsub of them, i.e. fetches logical chunk pos ^ swz(row) = 8 elements of K
+    const int pos = lane & 3, rsub = lane >> 2;
+    int a_h[IA], a_w[IA], a_img[IA], a_c[IA];
+    unsigned a_voff[IA];
+    const int rel0 = m0 - n_first * HoWo;
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+        const int row = (wave * IA + j) * RPI + rsub;
+        a_c[j] = 8 * (pos ^ bf_swz(row));
+        if ((int64_t)m0 + row < M) {
+            const unsigned rel = (unsigned)(rel0 + row);
+            const unsigned n = rel / (unsigned)HoWo;
+            const unsigned rem = rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)d.Wo, ow = rem - oh * (unsigned)d.Wo;
+            a_img[j] = (int)((int64_t)n * d.x_batch_stride * 2);
+            a_h[j] = (int)oh * d.a + d.p;
+            a_w[j] = (int)ow * d.a + d.p_w;
+        } else {
+            a_img[j] = 0;
+            a_h[j] = -(1 << 28);                             // fails every bounds test
+            a_w[j] = 0;
+        }
+        a_voff[j] = 0x80000000u;
+    }
+    unsigned b_voff[IB];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int row = (wave * IB + j) * RPI + rsub;
+        const int n = n0 + row;
+        b_voff[j] = n < d.Cout ? (unsigned)((n * Kpad + 8 * (pos ^ bf_swz(row))) * 2) : 0x80000000u;
+    }
+
+    // fast path: Cin a multiple of the K-step -> a step lies inside one filter tap; offsets change only with the tap
+    const bool fast = (d.Cin % BF_BK) == 0;
+    int f_r = 0, f_s = 0, f_c = 0;
+    const unsigned lds0 = lds_addr(lds);
+    auto dma_step = [&](int ks, int buf) {
+        const unsigned A = lds0 + (unsigned)((buf * STEP + (wave_u * IA) * RPI * RF) * 4);
+        const unsigned B = lds0 + (unsigned)((buf * STEP + BM * RF + (wave_u * IB) * RPI * RF) * 4);
+#pragma unroll
+        for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (RPI * RF * 4), b_voff[j], (unsigned)(ks * BF_BK * 2));
+        if (fast) {
+            if (f_c == 0) {                                  // new tap (wave-uniform)
+                const bool tap_ok = f_r < d.kh;
+                const int hoff = f_r * d.b, woff = f_s * d.b;
+#pragma unroll
+                for (int j = 0; j < IA; ++j) {
+                    const int nh = a_h[j] + hoff, nw = a_w[j] + woff;
+                    const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+                    const bool ok = tap_ok & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
+                    a_voff[j] = ok ? (unsigned)(a_img[j] + ((ih * d.Wi + iw) * d.Cin + a_c[j]) * 2) : 0x80000000u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (RPI * RF * 4), a_voff[j], (unsigned)(f_c * 2));
+            f_c += BF_BK;
+            if (f_c >= d.Cin) { f_c = 0; if (++f_s == d.kw) { f_s = 0; ++f_r; } }
+        } else {
+#pragma unroll
+            for (int j = 0; j < IA; ++j) {                   // Cin % 8 == 0: a 16-byte chunk stays inside one tap
+                const int k = ks * BF_BK + a_c[j];
+                const int tap = k / d.Cin;
+                const int c0 = k - tap * d.Cin;
+                const int r = tap / d.kw, s_ = tap - r * d.kw;
+                const int nh = a_h[j] + r * d.b, nw = a_w[j] + s_ * d.b;
+                const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+                const bool ok = (r < d.kh) & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
+                dma16(rs_a, A + j * (RPI * RF * 4), ok ? (unsigned)(a_img[j] + ((ih * d.Wi + iw) * d.Cin + c0) * 2) : 0x80000000u, 0u);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses (4-byte words within a buffer): row = lane & 31 of each 32-row MFMA tile, logical chunk
+    // 2*st + (lane >> 5) of sub-step st, at its swizzled position
+    int fa[2][2], fb[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+            fa[t][st] = ra * RF + 4 * ((2 * st + (lane >> 5)) ^ bf_swz(ra));
+            fb[t][st] = BM * RF + rb * RF + 4 * ((2 * st + (lane >> 5)) ^ bf_swz(rb));
+        }
+    auto multiply = [&](int buf) {
+        const float *S = lds + buf * STEP;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(S + fa[0][st]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(S + fa[1][st]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(S + fb[0][st]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(S + fb[1][st]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+
+    // K loop: two LDS buffers, the loads of step ks+1 are issued before the MFMAs of step ks, one barrier per step
+    if (nks > 0) dma_step(0, 0);
+    rn_wait_dma();
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) dma_step(ks + 1, buf ^ 1);
+        multiply(buf);
+        rn_wait_dma();
+        __syncthreads();
+    }
+
+    // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add; act; [mask after]; one rounding on the store.
+    // The accumulator tile goes through LDS (two passes of 64 rows) so that global memory sees whole row segments:
+    // a lane owns 4 consecutive channels (8 bytes of bf16 or 16 bytes of fp32) of one output pixel.
+    float *T = lds;
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 4-channel chunks per tile row, rows per pass of stores
+    const int c4 = tid % CPR;
+    const int col = n0 + 4 * c4;
+    const bool col_ok = col < d.Cout;                        // Cout % 4 == 0 (checked by the launcher)
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (col_ok && scale != nullptr) sc[j] = scale[col + j];
+        if (col_ok && shift != nullptr) sh[j] = shift[col + j];
+    }
+    __bf16 *yb = reinterpret_cast<__bf16 *>(yv);
+    float *yf = reinterpret_cast<float *>(yv);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][e];
+        }
+        __syncthreads();
+        if (!col_ok) continue;
+        for (int r = tid / CPR; r < RP; r += RPP) {
+            const int64_t m = (int64_t)m0 + pass * RP + r;
+            if (m >= M) break;
+            const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+            const int n = (int)(m / HoWo);
+            const int rem = (int)(m - (int64_t)n * HoWo);
+            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+            const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
+            const int64_t pix = (int64_t)ph * d.Wy + pw;
+            const int64_t off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
+            float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+            if (d.mask_mode != 0) bf_load4(mask + off, mk);
+            if (d.add_mode == 1) bf_load4(add + (int64_t)n * d.add_batch_stride + pix * d.Cout + col, ad);
+            else if (d.add_mode == 2)                          // nearest x2 upsample, cropped (D/model.py:88-108)
+                bf_load4(add + (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col, ad);
+            float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j];
+                if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f;
+                u += ad[j];
+                if (d.act == 1) u = fmaxf(u, 0.f);
+                else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
+                if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f;
+                v[j] = u;
+            }
+            if (YF32) {
+                *reinterpret_cast<float4 *>(yf + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x4 o;
+                o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                *reinterpret_cast<bf16x4 *>(yb + off) = o;
+            }
+        }
+    }
+}
+
+static inline int check_desc_bf16(const rn_conv_desc *d) {
+    if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
+    if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3)) return RN_EINVAL;   // 16-byte chunks of 8 channels; 4-channel stores
+    if ((int64_t)d->Hi * d->Wi * d->Cin * 2 > 0x7fffffffLL) return RN_EINVAL;
+    const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 127 / HoWo + 2;
+    if (d->x_batch_stride < 0 || ((span - 1) * d->x_batch_stride + (int64_t)d->Hi * d->Wi * d->Cin) * 2 > 0x7fffffffLL) return RN_EINVAL;
+    const int64_t Kpad = ((int64_t)d->kh * d->kw * d->Cin + 31) / 32 * 32;
+    if (d->Cout * Kpad * 2 > 0x7fffffffLL || (int64_t)d->N * HoWo > 0x7fffffffLL) return RN_EINVAL;
+    if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
+    if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2 || d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;
+    if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0) return RN_EINVAL;
+    if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
+    if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
+    if (d->in_relu || d->add2_mode != 0 || d->w_batch_stride != 0) return RN_EINVAL;   // not in the bf16 form (yet)
+    return RN_OK;
+}
+
+extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const void *w_packed, void *y, int y_is_f32,
+                                  const float *scale, const float *shift, const void *add, const void *mask, void *stream) {
+    const int rc = check_desc_bf16(d);
+    if (rc) return rc;
+    if ((d->add_mode != 0) != (add != nullptr) || (d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 7) || ((uintptr_t)add & 7) || ((uintptr_t)mask & 7)) return RN_EINVAL;
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (tiles > 0x7fffffff) return RN_EINVAL;
+    const dim3 grid((unsigned)tiles), block(256);
+    const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(w_packed);
+    const __bf16 *ab = reinterpret_cast<const __bf16 *>(add), *mb = reinterpret_cast<const __bf16 *>(mask);
+    if (y_is_f32) hipLaunchKernelGGL(conv_igemm_bf16_kernel<true>, grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    else hipLaunchKernelGGL(conv_igemm_bf16_kernel<false>, grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dw[co][kk] += sum over pixels of dy[pixel][co] * x[pixel shifted by tap(kk)][ci(kk)], kk = packed-row index
+// (tap-major, channel-minor).  Tile 128 (co) x 128 (kk), 32 pixels per K-step, K split over the grid, fp32 atomics.
+struct WgradBf16Args {
+    const __bf16 *dy, *x;
+    float *dw;
+    float *colsum;               // [Cout] += sum over pixels of dy, or NULL
+    int ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad;
+    int Kflat, Kpad;             // kh*kw*Cin and its round-up to 32
+    int tiles_n, tiles, splits;
+    int64_t pixels, per_split;   // K extent and K per slice (multiple of 32)
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define WG_WK 32                 // pixels per K-step
+#define WG_ROWB 256              // bytes per staged row: 128 bf16
+
+// LDS image of a staged [32 pixels][128 columns] bf16 tile: 256-byte rows whose 16 chunks of 16 bytes are XOR-permuted
+// by wg_fx(row), the image that serves gfx950's transposing read without bank conflicts (cdna_hip_programming.md T10 (b);
+// operand addressing verified by tools/probes/tr_probe.hip).  The direct-to-LDS load fills rows linearly, so the
+// permutation is applied on the load's SOURCE: the lane filling position cp of row r fetches logical chunk cp ^ wg_fx(r).
+__device__ __forceinline__ int wg_fx(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// One 32x32x16 operand from such an image: lane l <- 8 consecutive rows (pixels) 16*kh + 8*(l>>5) + 0..7 of column
+// col0 + (l & 31), by two ds_read_b64_tr_b16 (each: a 4-row x 16-column block per 16 lanes, returned column-major).
+__device__ __forceinline__ bf16x8 wg_operand(const char *img, unsigned a_rd0, unsigned a_rd1, int kh) {
+    typedef __attribute__((address_space(3))) s16x4 *lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(__attribute__((address_space(3))) char *)(img + a_rd0 + kh * 16 * WG_ROWB));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(__attribute__((address_space(3))) char *)(img + a_rd1 + kh * 16 * WG_ROWB));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16Args p) {
+    constexpr int BM = 128, BN = 128, WK = WG_WK;
+    constexpr int TB = 256 / WK;                             // K-steps per pixel-table batch: one entry per thread
+    constexpr int IA = WK / 4 / 4, IB = WK / 4 / 4;          // DMA instructions per wave per K-step: 4 rows each, 4 waves
+    __shared__ __attribute__((aligned(16))) char lds[2][WK * (BM + BN) * 2];   // per buffer: dY [32][128], then X [32][128]
+    __shared__ int4 pixtab[2][TB * WK];                      // (x byte offset of input pixel (ih0, iw0), ih0, iw0, -)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int slice = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int64_t kbeg = (int64_t)slice * p.per_split;
+    const int64_t kend = (kbeg + p.per_split < p.pixels) ? kbeg + p.per_split : p.pixels;
+    const int nks = (int)((kend - kbeg + WK - 1) / WK);
+    if (nks <= 0) return;
+    const int HoWo = p.Ho * p.Wo;
+
+    // buffer descriptors: dY = this K slice only (pixels past kend are out of range by themselves); X from the first
+    // image the slice touches (the host keeps a slice's span of images below 2 GiB)
+    const int n_first = (int)(kbeg / HoWo);
+    const int rel0 = (int)(kbeg - (int64_t)n_first * HoWo);
+    const int64_t img = (int64_t)p.Hi * p.Wi * p.Cin;
+    int64_t xbytes = ((int64_t)p.N - n_first) * img * 2;
+    if (xbytes > 0x7FFFFFFF) xbytes = 0x7FFFFFFF;
+    const v4i32 rs_a = make_rsrc(p.dy + kbeg * p.ldy, (unsigned)((kend - kbeg) * p.ldy * 2));
+    const v4i32 rs_b = make_rsrc(p.x + (int64_t)n_first * img, (unsigned)xbytes);
+
+    // staging geometry: instruction j of wave w fills pixel rows (w*I + j)*4 + lane/16; the lane fills chunk position cp
+    const int cp = lane & 15, rq = lane >> 4;
+    unsigned a_voff[IA];
+    int b_fr[IB], b_fs[IB], b_tapoff[IB];
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+        const int row = (wave * IA + j) * 4 + rq;
+        const int col = m0 + 8 * (cp ^ wg_fx(row));
+        a_voff[j] = col < p.ldy ? (unsigned)((row * p.ldy + col) * 2) : 0x80000000u;
+    }
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int row = (wave * IB + j) * 4 + rq;
+        const int jcol = n0 + 8 * (cp ^ wg_fx(row));         // the chunk fixes (tap, first input channel)
+        const int tap = jcol / p.Cin;
+        const int ci0 = jcol - tap * p.Cin;
+        const int fr = tap / p.kw;
+        b_fs[j] = tap - fr * p.kw;
+        b_fr[j] = jcol < p.Kflat ? fr : (1 << 24);           // a column past the matrix fails every row test
+        b_tapoff[j] = ((fr * p.Wi + b_fs[j]) * p.Cin + ci0) * 2;
+    }
+    const int b_px0 = wave * IB * 4 + rq;                    // this lane's pixel for instruction 0 (+4 per instruction)
+
+    auto fill_batch = [&](int j) {
+        const int rel = rel0 + j * (TB * WK) + tid;
+        int4 e = make_int4(0, -(1 << 28), 0, 0);             // past the slice: fails the row test
+        if (kbeg + (int64_t)j * (TB * WK) + tid < kend) {
+            const unsigned n = (unsigned)rel / (unsigned)HoWo;
+            const unsigned rem = (unsigned)rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)p.Wo, ow = rem - oh * (unsigned)p.Wo;
+            const int ih0 = (int)oh * p.stride - p.pad, iw0 = (int)ow * p.stride - p.pad;
+            e = make_int4((((int)n * p.Hi + ih0) * p.Wi + iw0) * p.Cin * 2, ih0, iw0, 0);
+        }
+        pixtab[j & 1][tid] = e;
+    };
+    unsigned b_voff[IB];
+    auto make_offsets = [&](int ks) {
+        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK + b_px0];
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+            const int4 e = tab[j * 4];
+            const bool ok = ((unsigned)(e.y + b_fr[j]) < (unsigned)p.Hi) & ((unsigned)(e.z + b_fs[j]) < (unsigned)p.Wi);
+            b_voff[j] = ok ? (unsigned)(e.x + b_tapoff[j]) : 0xFFFFFFFFu;
+        }
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds0 = lds_addr(&lds[0][0]);
+    constexpr unsigned BUFB = WK * (BM + BN) * 2;
+    auto dma_step = [&](int ks, int buf) {
+        const unsigned A = lds0 + (unsigned)(buf * BUFB + wave_u * IA * 4 * WG_ROWB);
+        const unsigned B = lds0 + (unsigned)(buf * BUFB + WK * WG_ROWB + wave_u * IB * 4 * WG_ROWB);
+        const unsigned so = (unsigned)ks * (unsigned)(WK * 2) * (unsigned)p.ldy;     // scalar: the K-step advance of dY
+#pragma unroll
+        for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (4 * WG_ROWB), a_voff[j], so);   // a_voff[j] holds instruction j's rows
+#pragma unroll
+        for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (4 * WG_ROWB), b_voff[j], 0u);
+    };
+
+    // fragment read addresses (bytes within a tile image): block row r0 + q, chunk c0 + (pp >> 1), half pp & 1
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    unsigned fa[2][2], fb[2][2];                             // [32-column sub-tile][read 0/1]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int row = 8 * (g >> 1) + 4 * rd + q;
+            const int ca = (wm * 64 + t * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
+            const int cb = (wn * 64 + t * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
+            fa[t][rd] = (unsigned)(WG_ROWB * row + 16 * (ca ^ wg_fx(row)) + 8 * (pp & 1));
+            fb[t][rd] = (unsigned)(WK * WG_ROWB + WG_ROWB * row + 16 * (cb ^ wg_fx(row)) + 8 * (pp & 1));
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e_ = 0; e_ < 16; ++e_) acc[i][j][e_] = 0.f;
+    float cs[2] = {0.f, 0.f};
+    const bool do_cs = p.colsum != nullptr && (tile % p.tiles_n) == 0 && wn == 0;
+
+    fill_batch(0);
+    __syncthreads();
+    make_offsets(0);
+    dma_step(0, 0);
+    rn_wait_dma();
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nks) {
+            // the table batch of step ks+1 was published by an earlier barrier: batch b is filled during step
+            // b*TB - 4 (below) or before the loop (batch 0)
+            make_offsets(ks + 1);
+            dma_step(ks + 1, buf ^ 1);
+        }
+        const char *S = &lds[buf][0];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const bf16x8 a0 = wg_operand(S, fa[0][0], fa[0][1], kh), a1 = wg_operand(S, fa[1][0], fa[1][1], kh);
+            const bf16x8 b0 = wg_operand(S, fb[0][0], fb[0][1], kh), b1 = wg_operand(S, fb[1][0], fb[1][1], kh);
+            if (do_cs) {
+#pragma unroll
+                for (int e_ = 0; e_ < 8; ++e_) { cs[0] += (float)a0[e_]; cs[1] += (float)a1[e_]; }
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // next table batch: needed from step (b+1)*TB - 1 on (make_offsets(ks + 1)); its slot held batch b-1, last read
+        // for step b*TB - 1, i.e. during iteration b*TB - 2
+        if ((ks % TB) == TB - 4 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
+        rn_wait_dma();
+        __syncthreads();
+    }
+    if (do_cs) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            cs[t] += __shfl_xor(cs[t], 32);                   // the two 8-pixel groups of the same channel
+            const int c = m0 + wm * 64 + t * 32 + (lane & 31);
+            if (lane < 32 && c < p.Cout) atomicAdd(p.colsum + c, cs[t]);
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < p.Cout && col < p.Kflat) atomicAdd(p.dw + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+            }
+        }
+}
+
+extern "C" int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi,
+                                  int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream) {
+    if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 8 || (Cin & 7) || (ldy & 7) || ldy < Cout)
+        return RN_EINVAL;
+    if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return RN_EINVAL;
+    WgradBf16Args a;
+    a.dy = reinterpret_cast<const __bf16 *>(dy); a.x = reinterpret_cast<const __bf16 *>(x); a.dw = dw; a.colsum = colsum; a.ldy = ldy;
+    a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.Kflat = kh * kw * Cin;
+    a.Kpad = (a.Kflat + 31) / 32 * 32;
+    a.pixels = (int64_t)N * Ho * Wo;
+    const int tiles_m = (Cout + 127) / 128;
+    a.tiles_n = (a.Kflat + 127) / 128;
+    a.tiles = tiles_m * a.tiles_n;
+    int64_t splits = (2048 + a.tiles - 1) / a.tiles;         // ~2048 workgroups (conv_wgrad.hip), slices >= 512 pixels
+    const int64_t max_splits = (a.pixels + 16 * WG_WK - 1) / (16 * WG_WK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const int64_t HoWo = (int64_t)Ho * Wo, img_bytes = (int64_t)Hi * Wi * Cin * 2;
+    for (;;) {
+        a.per_split = ((a.pixels + splits - 1) / splits + WG_WK - 1) / WG_WK * WG_WK;
+        const int64_t span_imgs = (a.per_split + HoWo - 2) / HoWo + 1;
+        if ((a.per_split + WG_WK) * ldy * 2 <= 0x7FFFFFFF && span_imgs * img_bytes <= 0x7FFFFFFF) break;
+        if (a.per_split <= WG_WK || splits >= 65535) return RN_EINVAL;
+        splits = splits * 2 > 65535 ? 65535 : splits * 2;
+    }
+    splits = (a.pixels + a.per_split - 1) / a.per_split;
+    a.splits = (int)splits;
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(a.tiles * splits)), dim3(256), 0, (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -121,6 +121,10 @@ SIGNATURES.update({
     "rn_wino_dy": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "rn_wino_dw": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "rn_conv_wgrad_batched": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp]),
+    "rn_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_bf16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_conv_igemm_bf16": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rn_conv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 11 + [c_vp]),
     "rn_opt_workspace_bytes": (c_i64, [c_i32]),
     "rn_opt_clip_adam": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
 })

@@ -414,3 +414,73 @@ def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, d
 def add_(dst, src):
     _hip.check(_hip.load().rn_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), _hip.stream()), "rn_add_inplace")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------- bf16 engine (BASELINE configs[2])
+def to_bf16(t):
+    """fp32 device tensor -> bf16 (round to nearest even, rn_f32_to_bf16)."""
+    t = _hip.f32c(t)
+    _hip.need_gpu(t)
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    if t.numel():
+        _hip.check(_hip.load().rn_f32_to_bf16(t.data_ptr(), out.data_ptr(), t.numel(), _hip.stream()), "rn_f32_to_bf16")
+    return out
+
+
+def to_f32(t):
+    _hip.need_gpu(t)
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    if t.numel():
+        _hip.check(_hip.load().rn_bf16_to_f32(t.data_ptr(), out.data_ptr(), t.numel(), _hip.stream()), "rn_bf16_to_f32")
+    return out
+
+
+def pack_weights_bf16(weight, mode=0, scale=None, c_pad=None, taps=None):
+    """fp32 OIHW master weights -> packed bf16 rows (pack_weights' layout; rows are multiples of 32 elements)."""
+    cin, cout = weight.shape[1], weight.shape[0]
+    if c_pad is None:
+        c_pad = ((cin if mode == 0 else cout) + 7) // 8 * 8                  # 16-byte chunks hold 8 channels
+    return to_bf16(pack_weights(weight, mode, scale=scale, c_pad=c_pad, taps=taps))
+
+
+def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
+                    mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, flops=0.0, out_map=None):
+    """rn_conv_igemm_bf16: x [N,Hi,Wi,Cin] bf16, w_packed bf16, y bf16 or fp32 (its dtype decides); geom as conv_igemm."""
+    lib = _hip.load()
+    assert x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and y.dtype in (torch.bfloat16, torch.float32)
+    d = _make_desc(x, geom, act, add_mode, add_hw, (mask_mode if mask is not None else 0), False, out_map, y_batch_stride,
+                   add_batch_stride, None)
+    rc = prof.timed("conv_igemm_bf16", flops, lambda: lib.rn_conv_igemm_bf16(
+        ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), int(y.dtype == torch.float32), _hip.ptr(scale),
+        _hip.ptr(shift), _hip.ptr(add), _hip.ptr(mask), _hip.stream()))
+    _hip.check(rc, "rn_conv_igemm_bf16")
+    return y
+
+
+def fprop_bf16(x, w_packed, cout, k, stride, pad, out_dtype=torch.bfloat16, **kw):
+    N, Hi, Wi, _ = x.shape
+    Ho, Wo = out_size(Hi, k, stride, pad), out_size(Wi, k, stride, pad)
+    y = torch.empty((N, Ho, Wo, cout), dtype=out_dtype, device=x.device)
+    return conv_igemm_bf16(x, w_packed, y, (Ho, Wo, cout, k, k, stride, 1, -pad, 0), **kw)
+
+
+def dgrad_bf16(dy, w_packed_dgrad, in_hw, cin, k, pad, **kw):
+    """Stride-1 data gradient in bf16 (dy [N,Ho,Wo,Cout(_pad)] bf16 -> dx [N,Hi,Wi,Cin] bf16)."""
+    N = dy.shape[0]
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, cin), dtype=torch.bfloat16, device=dy.device)
+    return conv_igemm_bf16(dy, w_packed_dgrad, dx, (Hi, Wi, cin, k, k, 1, -1, pad, 0), **kw)
+
+
+def wgrad_bf16(dy, x, dw, cout, k, stride, pad, flops=0.0, colsum=None):
+    """dw[Cout][Kpad] (fp32) += wgrad(dy, x) with bf16 operands; colsum[Cout] += column sums of dy."""
+    lib = _hip.load()
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    N, Ho, Wo, ldy = dy.shape
+    _, Hi, Wi, Cin = x.shape
+    rc = prof.timed("conv_wgrad_bf16", flops, lambda: lib.rn_conv_wgrad_bf16(
+        dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), N, Hi, Wi, Cin, Ho, Wo, cout, k, k, stride, pad,
+        _hip.stream()))
+    _hip.check(rc, "rn_conv_wgrad_bf16")
+    return dw

@@ -308,6 +308,24 @@ int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, f
                           int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
 
+/* ---------------------------------------------------------------- bf16 convolution engine -----------------
+ * The reduced-precision form of rn_conv_igemm / rn_conv_wgrad for BASELINE configs[2] (bf16 MFMA,
+ * v_mfma_f32_32x32x16_bf16): activations, addend, mask and packed weights are bf16 (IEEE bfloat16, 2 bytes; NHWC /
+ * [Cout][kh][kw][Cin] rows padded to a multiple of 32 ELEMENTS -- rn_pack_weights' fp32 output cast by rn_f32_to_bf16),
+ * accumulation and the epilogue (scale, shift, mask, addend, activation: as rn_conv_igemm) are fp32, the result is rounded
+ * once: to bf16, or stored as fp32 when y_is_f32 != 0 (head outputs that feed the loss).  Same rn_conv_desc, with strides
+ * counted in elements; Cin % 8 == 0, Cout % 4 == 0; in_relu, add2 and w_batch_stride are not available (RN_EINVAL).
+ * x, w_packed 16-byte aligned; y, add, mask 8-byte aligned.  Replaces the same nn.Conv2d call sites as rn_conv_igemm
+ * (D/model.py:59-205, D/utils.py:12-80) when the caller opts into bf16 storage; the reference itself is fp32. */
+int rn_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);   /* round-to-nearest-even, NaN stays NaN */
+int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stream);
+int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const void *w_packed, void *y, int y_is_f32,
+                       const float *scale, const float *shift, const void *add, const void *mask, void *stream);
+/* dw[co][r][s][ci] (fp32, packed [Cout][Kpad] like rn_conv_wgrad, atomically accumulated) from bf16 dy [N,Ho,Wo,ldy>=Cout]
+ * and bf16 x [N,Hi,Wi,Cin]; colsum (may be NULL) += column sums of dy.  Cin % 8 == 0, ldy % 8 == 0. */
+int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi, int Cin,
+                       int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream);
+
 /* Winograd F(4x4,3x3) stages for 3x3 / stride 1 / padding 1 convolutions (the head towers, D/model.py:120-205), fp32:
  *   rn_wino_input   x [N,H,W,C] -> V [36][Tpad][C]: B^T d B of every 6x6 patch; the problem's tiles (N * ceil(H/4) *
  *                   ceil(W/4), image-major) are written from row tile_offset on, so several problems (pyramid levels)
