@@ -390,8 +390,9 @@ def upsample_add_bwd(src, dst):
     """dst[n,h,w,:] += sum of the (in-bounds) 2x2 children in src."""
     lib = _hip.load()
     N, Hs, Ws, C = src.shape
-    _hip.check(lib.rn_upsample_add_bwd(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C,
-                                       _hip.stream()), "rn_upsample_add_bwd")
+    fn = lib.rn_upsample_add_bwd_bf16 if src.dtype == torch.bfloat16 else lib.rn_upsample_add_bwd
+    assert src.dtype == dst.dtype
+    _hip.check(fn(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C, _hip.stream()), "rn_upsample_add_bwd")
     return dst
 
 
@@ -400,14 +401,14 @@ def relu_mask_(g, z):
     return g
 
 
-def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, device):
+def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, device, bf16=False):
     """Gradient slice of a head output (B images, rows_per_image pixels of C channels each, images
     src_batch_stride floats apart; raw device pointers) -> dense [B*rows_per_image, ld], zero-padded channels,
     multiplied by s(1-s) when the sigmoid output pointer is given."""
     lib = _hip.load()
-    out = torch.empty((B * rows_per_image, ld), dtype=torch.float32, device=device)
-    _hip.check(lib.rn_sigmoid_bwd_pad(dy_ptr, s_ptr, out.data_ptr(), B, rows_per_image, C, ld, src_batch_stride,
-                                      _hip.stream()), "rn_sigmoid_bwd_pad")
+    out = torch.empty((B * rows_per_image, ld), dtype=torch.bfloat16 if bf16 else torch.float32, device=device)
+    fn = lib.rn_sigmoid_bwd_pad_bf16 if bf16 else lib.rn_sigmoid_bwd_pad
+    _hip.check(fn(dy_ptr, s_ptr, out.data_ptr(), B, rows_per_image, C, ld, src_batch_stride, _hip.stream()), "rn_sigmoid_bwd_pad")
     return out
 
 
@@ -484,3 +485,58 @@ def wgrad_bf16(dy, x, dw, cout, k, stride, pad, flops=0.0, colsum=None):
         _hip.stream()))
     _hip.check(rc, "rn_conv_wgrad_bf16")
     return dw
+
+
+def dgrad_any_bf16(dy, w_packed_dgrad, in_hw, cin, k, stride, pad, **kw):
+    """Data gradient, generic form (every tap tried at every input pixel; for stride 2 three of four fail the divisibility
+    test): used for the 1x1 stride-2 shortcuts, whose single tap makes the waste irrelevant."""
+    N = dy.shape[0]
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, cin), dtype=torch.bfloat16, device=dy.device)
+    return conv_igemm_bf16(dy, w_packed_dgrad, dx, (Hi, Wi, cin, k, k, 1, -1, pad, stride.bit_length() - 1), **kw)
+
+
+def dgrad_s2_classes_bf16(dy, class_weights, in_hw, cin, k, pad, flops=0.0, **kw):
+    """dgrad_s2_classes with bf16 operands: one launch per output-parity class, stored at the class's strided positions."""
+    N, Ho, Wo, _ = dy.shape
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, cin), dtype=torch.bfloat16, device=dy.device)
+    classes = s2_classes(k, pad)
+    if len(classes) < 4:
+        dx.zero_()
+    total_taps = sum(c[2][1] * c[2][3] for c in classes)
+    for (ph, pw, (r0, nr, s0, ns), (dh0, dw0)), wc in zip(classes, class_weights):
+        gh, gw = (Hi - ph + 1) // 2, (Wi - pw + 1) // 2
+        if gh <= 0 or gw <= 0:
+            continue
+        conv_igemm_bf16(dy, wc, dx, (gh, gw, cin, nr, ns, 1, -1, (dh0, dw0), 0), out_map=(2, ph, pw, Hi, Wi),
+                        flops=flops * nr * ns / total_taps, **kw)
+    return dx
+
+
+def maxpool_fwd_bf16(x, want_argmax=False):
+    """fp32 stem output -> bf16 pooled activations (+ uint8 argmax)."""
+    lib = _hip.load()
+    N, H, W, C = x.shape
+    Ho, Wo = out_size(H, 3, 2, 1), out_size(W, 3, 2, 1)
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    arg = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if want_argmax else None
+    _hip.check(lib.rn_maxpool_fwd_bf16out(x.data_ptr(), y.data_ptr(), _hip.ptr(arg), N, H, W, C, Ho, Wo, _hip.stream()),
+               "rn_maxpool_fwd_bf16out")
+    return (y, arg) if want_argmax else y
+
+
+def maxpool_bwd_bf16(x, dy, argmax, relu_mask=True):
+    """bf16 gradient of the pooled activations -> fp32 gradient of the (fp32) stem output."""
+    lib = _hip.load()
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _hip.check(lib.rn_maxpool_bwd_bf16in(x.data_ptr(), dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(), N, H, W, C,
+                                         dy.shape[1], dy.shape[2], int(relu_mask), _hip.stream()), "rn_maxpool_bwd_bf16in")
+    return dx
+
+
+def relu_bf16(x):
+    out = torch.empty_like(x)
+    _hip.check(_hip.load().rn_relu_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _hip.stream()), "rn_relu_bf16")
+    return out

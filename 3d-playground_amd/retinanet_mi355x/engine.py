@@ -27,17 +27,19 @@ from . import _hip, arch, conv as cv, ops
 class Layer:
     """One convolution with its fused batch-norm / bias, the per-step packed weights and gradient accumulators."""
 
-    def __init__(self, spec, kw_pad=None, cin_pad=None):
+    def __init__(self, spec, kw_pad=None, cin_pad=None, bf16=False):
         self.spec = spec
+        self.bf16 = bf16                               # bf16 activations / packed weights, fp32 accumulation (conv_bf16.hip)
         self.kw_pad = spec.k if kw_pad is None else kw_pad
         self.cin_pad = spec.cin if cin_pad is None else cin_pad
-        self.cout_pad = (spec.cout + 31) // 32 * 32 if spec.cout % 4 else spec.cout
+        # channel count of a padded head-output gradient = K of its data gradient: 16-byte chunks must not straddle taps
+        self.cout_pad = (spec.cout + 31) // 32 * 32 if spec.cout % (8 if bf16 else 4) else spec.cout
         # Winograd F(4x4,3x3) is available for 3x3 / stride 1 / padding 1 layers with whole 16-byte channel chunks; the
         # engine turns it on for the head towers in training (conv_wino.hip: 2.1-2.3x on those layers, ~1e-5 accuracy)
         self.wino_ok = spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
         # worth it from 128 channels on one side and 64 on the other (below, the 36 GEMMs have too short a K loop or too
         # few columns); set per step by the engine
-        self.wino_layer = self.wino_ok and min(spec.cin, spec.cout) >= 64 and max(spec.cin, spec.cout) >= 128
+        self.wino_layer = self.wino_ok and min(spec.cin, spec.cout) >= 64 and max(spec.cin, spec.cout) >= 128 and not bf16
         self.wino_active = False
         self.keep_v = True
         self._cache = None
@@ -47,6 +49,7 @@ class Layer:
         self.wf = self.wd = self.scale = self.shift = self.rstd = self.mean = None
         self.dw = self.cs = None
         self.uf = self.ud = None
+        self.wf16 = self.wd16 = None               # bf16 copies of the packed weights (bf16 mode)
         self.saved_v = None                        # Winograd input transform of the forward, kept for the weight gradient
 
     # ---- per-step preparation
@@ -67,6 +70,8 @@ class Layer:
         self.wd = None
         self.dw = self.cs = None
         self.uf = self.ud = None
+        self.wd16 = None
+        self.wf16 = cache.get(("wf16", s.name), w, lambda: cv.to_bf16(self.wf)) if self.bf16 else None
 
     def adopt(self, P, cache, wf, bn, wd, wino=None):
         """Training step: take this step's packed weights / folded batch norm from the engine's batched preparation
@@ -84,6 +89,8 @@ class Layer:
         self.wd = wd                                  # None: packed on demand (layers that normally take the Winograd path)
         self.dw = self.cs = None
         self.uf, self.ud = wino if wino is not None else (None, None)
+        self.wd16 = None
+        self.wf16 = cv.to_bf16(self.wf) if self.bf16 else None
 
     def wino_weights(self, mode):
         """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
@@ -95,6 +102,13 @@ class Layer:
         if self.ud is None:
             self.ud = cv.wino_weights(self.weight, 1, scale=self.scale)
         return self.ud
+
+    def dgrad_weights16(self):
+        """bf16 copies of dgrad_weights()."""
+        if self.wd16 is None:
+            wd = self.dgrad_weights()
+            self.wd16 = [cv.to_bf16(t) for t in wd] if isinstance(wd, list) else cv.to_bf16(wd)
+        return self.wd16
 
     def dgrad_weights(self):
         """Packed dgrad weights (BN scale folded in); for a stride-2 k>1 layer: one tap subset per parity class."""
@@ -112,6 +126,13 @@ class Layer:
         s = self.spec
         N, Hi, Wi, _ = x.shape
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
+        if self.bf16:
+            assert not in_relu, "bf16: the caller applies the input ReLU (cv.relu_bf16)"
+            if out is None:
+                out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.bfloat16, device=x.device)
+            return cv.conv_igemm_bf16(x, self.wf16, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
+                                      scale=self.scale, shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
+                                      y_batch_stride=y_batch_stride, flops=self.flops(N, Ho, Wo))
         if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
                 and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
             r = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, keep_v=self.keep_v)
@@ -128,6 +149,9 @@ class Layer:
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only)."""
         s = self.spec
+        if self.bf16:                                  # one launch per level (no grouped bf16 launch yet)
+            return [self.fwd(x, act=act, out=None if outs is None else outs[i], y_batch_stride=y_batch_stride)
+                    for i, x in enumerate(xs)]
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
             r = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift, act=act, flops=fl,
@@ -150,6 +174,9 @@ class Layer:
         """Stride-1 data gradient of several problems in one launch; adds / masks: per-problem tensors or None."""
         s = self.spec
         assert s.stride == 1
+        if self.bf16:
+            return [self.bwd_data(g, in_hws[i], add=None if adds is None else adds[i], mask=None if masks is None else masks[i])
+                    for i, g in enumerate(gs)]
         if (wino or self.wino_active) and self.wino_ok and all(g.shape[3] == s.cout for g in gs):
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
             return cv.wino_conv_group(gs, self.wino_weights(1), adds=adds, masks=masks, mask_mode=2, flops=fl)
@@ -177,6 +204,11 @@ class Layer:
         if self.dw is None:
             self.dw = torch.zeros_like(self.wf)
             self.cs = torch.zeros(s.cout, dtype=torch.float32, device=g.device)
+        if self.bf16:
+            assert not in_relu
+            cv.wgrad_bf16(g, x, self.dw, s.cout, s.k, s.stride, s.pad, flops=self.flops(g.shape[0], g.shape[1], g.shape[2]),
+                          colsum=self.cs)
+            return
         if self.wino_active and not in_relu and g.shape[3] == s.cout and g.is_contiguous() and x.is_contiguous():
             cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v)
             self.saved_v = None
@@ -200,6 +232,13 @@ class Layer:
 
     def bwd_data(self, g, in_hw, add=None, mask=None, mask_mode=2, add2=None):
         s = self.spec
+        if self.bf16:
+            assert add2 is None
+            kw = dict(add=add, add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
+                      flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
+            if s.stride == 2 and s.k > 1:
+                return cv.dgrad_s2_classes_bf16(g, self.dgrad_weights16(), in_hw, s.cin, s.k, s.pad, **kw)
+            return cv.dgrad_any_bf16(g, self.dgrad_weights16(), in_hw, s.cin, s.k, s.stride, s.pad, **kw)
         if self.wino_active and add2 is None and g.shape[3] == s.cout and g.is_contiguous():
             return cv.wino_conv_group([g], self.wino_weights(1), adds=None if add is None else [add],
                                       masks=None if mask is None else [mask], mask_mode=mask_mode)[0]
@@ -266,7 +305,15 @@ class _Cache:
 
 
 class Engine:
-    def __init__(self, arch_name, num_classes, n_reg):
+    def __init__(self, arch_name, num_classes, n_reg, dtype="fp32"):
+        """dtype "fp32": the reference's arithmetic (default).  "bf16" (BASELINE configs[2]): bf16 activations and packed
+        weights, fp32 accumulation / epilogues / parameters / gradients / loss; the 3-channel stem stays fp32 and the
+        Winograd path is not used.  Bottleneck architectures only (resnet50 / 101 / 152)."""
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("dtype must be 'fp32' or 'bf16'")
+        self.bf16 = dtype == "bf16"
+        if self.bf16 and arch.LAYERS[arch_name][0] != "bottleneck":
+            raise NotImplementedError("the bf16 schedule is built for the bottleneck networks (resnet50/101/152)")
         self.arch = arch_name
         self.num_classes = num_classes
         self.n_reg = n_reg
@@ -293,14 +340,14 @@ class Engine:
             if role == "stem":
                 self.layers[spec.name] = Layer(spec, kw_pad=8, cin_pad=4)
                 continue
-            self.layers[spec.name] = Layer(spec)
+            self.layers[spec.name] = Layer(spec, bf16=self.bf16)
             if cur is None or cur[0] != pre:
                 cur = (pre, {})
                 self.blocks.append(cur)
             cur[1][role] = self.layers[spec.name]
         for spec in arch.fpn_convs(arch_name) + arch.head_convs("regressionModel", n_reg) + \
                 arch.head_convs("classificationModel", num_classes):
-            self.layers[spec.name] = Layer(spec)
+            self.layers[spec.name] = Layer(spec, bf16=self.bf16)
         self.param_names = [k for k, shp in arch.state_dict_shapes(arch_name, num_classes, n_reg).items()
                             if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
 
@@ -481,7 +528,7 @@ class Engine:
         else:
             self._prepare(P)
         for L in Ls.values():                              # Winograd where it pays; in inference only on request
-            L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer)
+            L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer and not self.bf16)
             L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow
         if x4 is None:
             _hip.need_gpu(img)
@@ -491,11 +538,12 @@ class Engine:
         B, H, W, _ = x4.shape
         S = {} if save else None
         stem = Ls["conv1"].fwd(x4, act=cv.ACT_RELU)
+        pool = cv.maxpool_fwd_bf16 if self.bf16 else cv.maxpool_fwd       # bf16 mode: the fp32 stem ends here
         if save:
-            x, pool_arg = cv.maxpool_fwd(stem, want_argmax=True)
+            x, pool_arg = pool(stem, want_argmax=True)
             S["x4"], S["stem"], S["pool_arg"] = x4, stem, pool_arg
         else:
-            x = cv.maxpool_fwd(stem)
+            x = pool(stem)
         if save:
             S["blocks"] = []
         feats = {}
@@ -521,10 +569,12 @@ class Engine:
         p3sum = Ls["fpn.P3_1"].fwd(c3, add=p4sum, add_mode=2, add_hw=(p4sum.shape[1], p4sum.shape[2]))
         p3 = Ls["fpn.P3_2"].fwd(p3sum)
         p6 = Ls["fpn.P6"].fwd(c5)
-        p7 = Ls["fpn.P7_2"].fwd(p6, in_relu=True)
+        p6r = cv.relu_bf16(p6) if self.bf16 else None                      # fp32: the ReLU rides on the fragments (in_relu)
+        p7 = Ls["fpn.P7_2"].fwd(p6r) if self.bf16 else Ls["fpn.P7_2"].fwd(p6, in_relu=True)
         pyramid = [p3, p4, p5, p6, p7]
         if save:
             S["fpn"] = (c3, c4, c5, p5lat, p4sum, p3sum, p6)
+            S["p6r"] = p6r
             S["pyramid"] = pyramid
         # ---- heads: towers share weights across levels; outputs land in their slice of [B, A, n]
         counts = [f.shape[1] * f.shape[2] * arch.NUM_ANCHORS for f in pyramid]
@@ -539,7 +589,7 @@ class Engine:
             ts = pyramid
             acts = []                                                     # acts[i][level]
             for i in range(1, 5):                                         # one launch per tower conv, all 5 levels
-                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino)
+                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16)
                 acts.append(ts)
             views, off = [], 0
             for cnt in counts:
@@ -599,17 +649,18 @@ class Engine:
             for (Hh, Ww), cnt in zip(hws, counts):                        # head-output gradient slices -> dense, padded
                 byte_off = 4 * off * width
                 g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
-                                       B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device)
+                                       B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device,
+                                       bf16=self.bf16)
                 gs.append(g.view(B, Hh, Ww, Lout.cout_pad))
                 off += cnt
             Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
             gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
             for i in (3, 2, 1):
-                tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino)
-                gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino)
-            tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino)
+                tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
+                gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
+            tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino and not self.bf16)
             first = dpyr[0] is None
-            dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino)
+            dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino and not self.bf16)
             S["towers"][prefix] = None
             done(Lout)
             for L in reversed(tower):
@@ -619,7 +670,10 @@ class Engine:
         dp3, dp4, dp5, dp6, dp7 = dpyr
         hw = lambda t: (t.shape[1], t.shape[2])
         L = Ls["fpn.P7_2"]
-        L.bwd_params(dp7, p6, in_relu=True)
+        if self.bf16:
+            L.bwd_params(dp7, S["p6r"])
+        else:
+            L.bwd_params(dp7, p6, in_relu=True)
         dp6 = L.bwd_data(dp7, hw(p6), add=dp6, mask=p6, mask_mode=1)     # d relu(p6) masked, heads' part added raw
         done(L)
         L = Ls["fpn.P6"]
@@ -680,7 +734,7 @@ class Engine:
             dcompact = None
             if "down" in roles:
                 roles["down"].bwd_params(g, xin)
-                if roles["down"].spec.stride == 2 and roles["conv1"].spec.stride == 1:
+                if roles["down"].spec.stride == 2 and roles["conv1"].spec.stride == 1 and not self.bf16:
                     dcompact = roles["down"].bwd_data_compact(g)       # bottleneck: conv1 is 1x1 s1, takes add2
                     dres = extra
                 else:
@@ -694,7 +748,7 @@ class Engine:
             done(roles["conv1"])
             del layer_name
         # ---- stem
-        gstem = cv.maxpool_bwd(S["stem"], g, S["pool_arg"], relu_mask=True)
+        gstem = (cv.maxpool_bwd_bf16 if self.bf16 else cv.maxpool_bwd)(S["stem"], g, S["pool_arg"], relu_mask=True)
         Ls["conv1"].bwd_params(gstem, S["x4"])
         done(Ls["conv1"])
         assert flat is None or next_bucket == len(buckets), "backward finished layers in an order finish_order() does not describe"

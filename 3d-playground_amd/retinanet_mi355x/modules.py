@@ -228,6 +228,7 @@ class ResNet(nn.Module):
                      (Bottleneck, (3, 8, 36, 3)): "resnet152"}.get((block, tuple(layers)))
         if arch_name is None:
             raise ValueError("Block type %s / layers %s not understood" % (block, layers))
+        self.__dict__["_arch_name"] = arch_name
         self.__dict__["_engine"] = engine.Engine(arch_name, num_classes, n_reg)
 
     def _make_layer(self, block, planes, blocks, stride=1):                # D/model.py:262-276
@@ -258,6 +259,17 @@ class ResNet(nn.Module):
         else:
             self._engine.bucket_hook = None
             self._engine.set_flat_grads(None)
+
+    def set_compute_dtype(self, dtype):
+        """"fp32" (default: the reference's arithmetic) or "bf16" (BASELINE configs[2]): bf16 activations and packed weights
+        on the bf16 matrix cores, fp32 accumulation, parameters, gradients and loss.  Not the reference's numerics: expect
+        ~1e-2 relative differences in losses and gradients (tests/test_gpu_model_bf16.py)."""
+        old = self._engine
+        eng = engine.Engine(self._arch_name, old.num_classes, old.n_reg, dtype=dtype)
+        eng.set_flat_grads(old.flat_bucket_bytes)
+        eng.bucket_hook = old.bucket_hook
+        self.__dict__["_engine"] = eng
+        return self
 
     def use_flat_gradients(self, on=True):
         """Write parameter gradients into one persistent device buffer (stable ``p.grad`` pointers from step to step,

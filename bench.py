@@ -32,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TF = 2500.0        # dense bf16 MFMA (same guide); only for the kernels of --dtype bf16
 PEAK_HBM_GBS = 8000.0             # HBM3E spec; 6.29 TB/s measured copy
 
 
@@ -44,6 +45,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the reference's arithmetic = the headline (BASELINE configs[1]); bf16 = configs[2]'s storage "
+                         "format (bf16 activations / MFMA, fp32 accumulation and master weights), reported with dtype bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ddp-timeline", action="store_true",
@@ -177,6 +181,8 @@ def main():
     net = getattr(modules, args.arch)(num_classes=8)
     net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))          # same weights on every rank
     net = net.to(dev)
+    if args.dtype == "bf16":
+        net.set_compute_dtype("bf16")
     net.train()
     net.freeze_bn()
     if world > 1:
@@ -235,10 +241,12 @@ def main():
         line = {"metric": "training images/sec at 1920x1080, ResNet-50 3D-RetinaNet", "value": round(value, 3),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
                 "config": {"workload": "%s directional 3D-RetinaNet, %dx%d synthetic frames, batch %d per GPU, 10 GT "
-                                       "boxes/image, fp32, fwd+loss+bwd+clip+Adam (BASELINE configs[1])"
-                                       % (args.arch, W, H, B),
+                                       "boxes/image, %s, fwd+loss+bwd+clip+Adam (BASELINE configs[%d])"
+                                       % (args.arch, W, H, B, "fp32" if args.dtype == "fp32" else
+                                          "bf16 activations / MFMA with fp32 accumulation and master weights",
+                                          1 if args.dtype == "fp32" else 2),
                            "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)}}
         if timer is not None:
             summ = timer.summary()
@@ -251,8 +259,9 @@ def main():
                                      "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
                     continue
                 tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12 if a["ms_total"] > 0 else 0.0
-                kernels[kind] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                                 "frac": round(tf / PEAK_F32_MFMA_TF, 4), "launches_per_step": a["launches"] // args.steps,
+                peak = PEAK_BF16_MFMA_TF if kind.endswith("_bf16") else PEAK_F32_MFMA_TF
+                kernels[kind] = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                 "frac": round(tf / peak, 4), "launches_per_step": a["launches"] // args.steps,
                                  "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             r = dict(kernels[dom])

@@ -326,6 +326,18 @@ int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const void *w_packe
 int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi, int Cin,
                        int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream);
 
+/* Non-convolution steps of the schedule with bf16 activations (elementwise_bf16.hip): the same operations as
+ * rn_maxpool_fwd / rn_maxpool_bwd / rn_upsample_add_bwd / rn_sigmoid_bwd_pad with bf16 storage on the activation side.
+ * The stem stays fp32, so pooling is the boundary: forward reads the fp32 stem output and writes bf16 (+ uint8 argmax),
+ * backward reads the bf16 gradient and writes the fp32 gradient of the stem output (masked by the stem's ReLU). */
+int rn_maxpool_fwd_bf16out(const float *x, void *y, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo, void *stream);
+int rn_maxpool_bwd_bf16in(const float *x, const void *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C, int Ho,
+                          int Wo, int relu_mask, void *stream);
+int rn_upsample_add_bwd_bf16(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *stream);
+int rn_sigmoid_bwd_pad_bf16(const float *dy, const float *s, void *out, int B, int64_t rows_per_image, int C, int ld,
+                            int64_t src_batch_stride, void *stream);
+int rn_relu_bf16(const void *src, void *dst, int64_t n, void *stream);      /* n % 4 == 0 */
+
 /* Winograd F(4x4,3x3) stages for 3x3 / stride 1 / padding 1 convolutions (the head towers, D/model.py:120-205), fp32:
  *   rn_wino_input   x [N,H,W,C] -> V [36][Tpad][C]: B^T d B of every 6x6 patch; the problem's tiles (N * ceil(H/4) *
  *                   ceil(W/4), image-major) are written from row tile_offset on, so several problems (pyramid levels)

@@ -1,0 +1,87 @@
+"""The bf16 schedule of the engine (Engine(dtype="bf16"), BASELINE configs[2]) on the whole detector: same network, same
+goldens as the fp32 tests -- but NOT the same bar: bf16 activations carry 8 significant bits, so after 50 layers the losses
+agree with the reference's fp32 values to about a percent and the gradients in direction rather than digit by digit.
+Bounds below are ~3x what was measured on the MI355X (profiles/r02_bf16_model_errors.txt).  The reference itself has no
+bf16 mode; what is pinned here is that the bf16 schedule computes the SAME function (wiring, epilogues, strides, masks)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL = 1e-2                 # relative, each of the three losses (measured 1.2e-3 on ResNet-50)
+COS_MIN = 0.97                  # cosine between a bf16-path gradient tensor and the reference's fp32 one (>= 90 % of tensors)
+
+
+def _build(arch, dev):
+    from retinanet_mi355x import modules
+    fn, sd, img, ann = gc.model_case(arch, True)
+    net = getattr(modules, arch)(num_classes=4)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    net.set_compute_dtype("bf16")
+    return net, img.to(dev), ann.to(dev), fn
+
+
+@pytest.mark.parametrize("arch", ["resnet50", "resnet101"])
+def test_bf16_train_losses_and_gradient_directions(dev, golden, arch):
+    net, img, ann, fn = _build(arch, dev)
+    z = golden(fn)
+    net.train()
+    net.freeze_bn()
+    losses = net([img, ann])
+    got = np.array([float(l.detach()) for l in losses])
+    want = z["%s_dir_losses" % arch]
+    assert np.all(np.abs(got - want) <= LOSS_TOL * np.abs(want)), (got, want)
+    sum(l.sum() for l in losses).backward()
+    cos, norms = [], []
+    for name, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        full = "%s_dir_g_%s" % (arch, name)
+        if full in z.files and np.abs(z[full]).max() > 0:
+            g, w = p.grad.detach().cpu().numpy().ravel().astype(np.float64), z[full].ravel().astype(np.float64)
+            cos.append(float(g @ w / (np.linalg.norm(g) * np.linalg.norm(w) + 1e-300)))
+        ref = z["%s_dir_gsum_%s" % (arch, name)][2]
+        norms.append(float(p.grad.double().norm()) / (ref + 1e-300))
+    cos, norms = np.array(cos), np.array(norms)
+    print("bf16 %s: losses %s vs %s; gradient cosine min %.4f median %.4f; norm ratio %.3f .. %.3f"
+          % (arch, got, want, cos.min(), np.median(cos), norms.min(), norms.max()))
+    assert (cos >= COS_MIN).mean() >= 0.9 and cos.min() > 0.8, (cos.min(), np.median(cos))
+    assert np.median(np.abs(norms - 1.0)) <= 0.05
+
+
+def test_bf16_eval_localize(dev, golden):
+    net, img, ann, fn = _build("resnet50", dev)
+    z = golden(fn)
+    net.eval()
+    boxes, cls = net(img, LOCALIZE=True)
+    assert boxes.dtype == torch.float32 and cls.dtype == torch.float32
+    c, b = cls.cpu().numpy(), boxes.cpu().numpy()
+    assert np.abs(c - z["resnet50_dir_cls"]).max() <= 3e-2 * np.abs(z["resnet50_dir_cls"]).max()
+    assert np.abs(b - z["resnet50_dir_boxes"]).max() <= 3e-2 * np.abs(z["resnet50_dir_boxes"]).max()
+
+
+def test_bf16_step_trains(dev):
+    """Three optimizer steps in bf16 mode (fp32 master weights, fused clip + Adam): the loss goes down."""
+    from retinanet_mi355x import optim
+    net, img, ann, _ = _build("resnet50", dev)
+    net.train()
+    net.freeze_bn()
+    net.use_flat_gradients()
+    opt = optim.ClipAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, max_norm=0.1)
+    vals = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = sum(l.mean() for l in net([img, ann]))
+        loss.backward()
+        opt.step()
+        vals.append(float(loss.detach()))
+    assert vals[-1] < vals[0], vals
+
+
+def test_bf16_refuses_basic_block_networks(dev):
+    from retinanet_mi355x import modules
+    net = modules.resnet18(num_classes=4).to(dev)
+    with pytest.raises(NotImplementedError):
+        net.set_compute_dtype("bf16")
