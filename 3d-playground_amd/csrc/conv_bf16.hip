@@ -239,21 +239,32 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_d
     }
 
     // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add; act; [mask after]; one rounding on the store.
-    // The accumulator tile goes through LDS (two passes of 64 rows) so that global memory sees whole row segments:
-    // a lane owns 4 consecutive channels (8 bytes of bf16 or 16 bytes of fp32) of one output pixel.
+    // The accumulator tile goes through LDS (two passes of 64 rows) so that global memory sees whole row segments in
+    // 16-byte accesses: a lane owns CH consecutive channels of one output pixel -- 8 for a bf16 result (its addend and mask
+    // are 16-byte loads too; 8-byte accesses run at 0.54-0.70 of the 16-byte rate), 4 for an fp32 result.
     float *T = lds;
-    constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 4-channel chunks per tile row, rows per pass of stores
-    const int c4 = tid % CPR;
-    const int col = n0 + 4 * c4;
-    const bool col_ok = col < d.Cout;                        // Cout % 4 == 0 (checked by the launcher)
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CH = YF32 ? 4 : 8;
+    constexpr int CPR = BN / CH, RPP = 256 / CPR;            // chunks per tile row, rows per pass of stores
+    const int cc = tid % CPR;
+    const int col = n0 + CH * cc;
+    const bool col_ok = col < d.Cout;                        // Cout % CH == 0 (checked by the launcher)
+    float sc[CH], sh[CH];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (col_ok && scale != nullptr) sc[j] = scale[col + j];
-        if (col_ok && shift != nullptr) sh[j] = shift[col + j];
+    for (int j = 0; j < CH; ++j) {
+        sc[j] = (col_ok && scale != nullptr) ? scale[col + j] : 1.f;
+        sh[j] = (col_ok && shift != nullptr) ? shift[col + j] : 0.f;
     }
     __bf16 *yb = reinterpret_cast<__bf16 *>(yv);
     float *yf = reinterpret_cast<float *>(yv);
+    auto load_ch = [&](const __bf16 *p, float (&v)[CH]) {
+        if constexpr (CH == 8) {
+            const bf16x8 q = *reinterpret_cast<const bf16x8 *>(p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+        } else {
+            bf_load4(p, v);
+        }
+    };
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();
@@ -271,22 +282,28 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_d
         for (int r = tid / CPR; r < RP; r += RPP) {
             const int64_t m = (int64_t)m0 + pass * RP + r;
             if (m >= M) break;
-            const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+            float v[CH];
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + CH * cc + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
             const int n = (int)(m / HoWo);
             const int rem = (int)(m - (int64_t)n * HoWo);
             const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
             const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
             const int64_t pix = (int64_t)ph * d.Wy + pw;
             const int64_t off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
-            float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
-            if (d.mask_mode != 0) bf_load4(mask + off, mk);
-            if (d.add_mode == 1) bf_load4(add + (int64_t)n * d.add_batch_stride + pix * d.Cout + col, ad);
-            else if (d.add_mode == 2)                          // nearest x2 upsample, cropped (D/model.py:88-108)
-                bf_load4(add + (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col, ad);
-            float v[4] = {t.x * sc[0] + sh[0], t.y * sc[1] + sh[1], t.z * sc[2] + sh[2], t.w * sc[3] + sh[3]};
+            float mk[CH], ad[CH];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = v[j];
+            for (int j = 0; j < CH; ++j) { mk[j] = 1.f; ad[j] = 0.f; }
+            if (d.mask_mode != 0) load_ch(mask + off, mk);
+            if (d.add_mode == 1) load_ch(add + (int64_t)n * d.add_batch_stride + pix * d.Cout + col, ad);
+            else if (d.add_mode == 2)                          // nearest x2 upsample, cropped (D/model.py:88-108)
+                load_ch(add + (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col, ad);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float u = v[j] * sc[j] + sh[j];
                 if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f;
                 u += ad[j];
                 if (d.act == 1) u = fmaxf(u, 0.f);
@@ -294,12 +311,13 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_d
                 if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f;
                 v[j] = u;
             }
-            if (YF32) {
+            if constexpr (YF32) {
                 *reinterpret_cast<float4 *>(yf + off) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                bf16x4 o;
-                o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-                *reinterpret_cast<bf16x4 *>(yb + off) = o;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x8 *>(yb + off) = o;
             }
         }
     }
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_d
 
 static inline int check_desc_bf16(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
-    if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3)) return RN_EINVAL;   // 16-byte chunks of 8 channels; 4-channel stores
+    if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3)) return RN_EINVAL;   // 16-byte chunks of 8 channels; 16-byte stores
     if ((int64_t)d->Hi * d->Wi * d->Cin * 2 > 0x7fffffffLL) return RN_EINVAL;
     const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 127 / HoWo + 2;
     if (d->x_batch_stride < 0 || ((span - 1) * d->x_batch_stride + (int64_t)d->Hi * d->Wi * d->Cin) * 2 > 0x7fffffffLL) return RN_EINVAL;
@@ -327,7 +345,10 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     const int rc = check_desc_bf16(d);
     if (rc) return rc;
     if ((d->add_mode != 0) != (add != nullptr) || (d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 7) || ((uintptr_t)add & 7) || ((uintptr_t)mask & 7)) return RN_EINVAL;
+    if (!y_is_f32 && (d->Cout & 7)) return RN_EINVAL;                    // bf16 result: 8 channels = 16 bytes per lane
+    const uintptr_t am = y_is_f32 ? 7 : 15;                               // addend / mask: 8 bytes beside an fp32 result, else 16
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add & am) || ((uintptr_t)mask & am)) return RN_EINVAL;
+    if (!y_is_f32 && ((d->y_batch_stride & 7) || (d->add_batch_stride & 7))) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
     if (tiles > 0x7fffffff) return RN_EINVAL;

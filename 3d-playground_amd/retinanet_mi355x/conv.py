@@ -452,7 +452,10 @@ def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_
     assert x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and y.dtype in (torch.bfloat16, torch.float32)
     d = _make_desc(x, geom, act, add_mode, add_hw, (mask_mode if mask is not None else 0), False, out_map, y_batch_stride,
                    add_batch_stride, None)
-    rc = prof.timed("conv_igemm_bf16", flops, lambda: lib.rn_conv_igemm_bf16(
+    kind = "conv_igemm_bf16"
+    if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
+        kind += " %dx%dx%d %d->%d k%d a%d b%d ds%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh, d.a, d.b, d.div_shift)
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16(
         ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), int(y.dtype == torch.float32), _hip.ptr(scale),
         _hip.ptr(shift), _hip.ptr(add), _hip.ptr(mask), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm_bf16")
@@ -480,7 +483,10 @@ def wgrad_bf16(dy, x, dw, cout, k, stride, pad, flops=0.0, colsum=None):
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
-    rc = prof.timed("conv_wgrad_bf16", flops, lambda: lib.rn_conv_wgrad_bf16(
+    kind = "conv_wgrad_bf16"
+    if prof.BY_SHAPE:
+        kind += " %dx%dx%d %d->%d k%d s%d" % (N, Ho, Wo, Cin, cout, k, stride)
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_wgrad_bf16(
         dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), N, Hi, Wi, Cin, Ho, Wo, cout, k, k, stride, pad,
         _hip.stream()))
     _hip.check(rc, "rn_conv_wgrad_bf16")

@@ -5,6 +5,7 @@ import collections
 import torch
 
 ACTIVE = None          # a KernelTimer while bench.py is measuring, else None
+BY_SHAPE = False       # tools/profile_layers.py: key the bf16 conv launches by layer shape instead of by kernel family
 
 
 class KernelTimer:

@@ -314,8 +314,8 @@ int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, f
  * [Cout][kh][kw][Cin] rows padded to a multiple of 32 ELEMENTS -- rn_pack_weights' fp32 output cast by rn_f32_to_bf16),
  * accumulation and the epilogue (scale, shift, mask, addend, activation: as rn_conv_igemm) are fp32, the result is rounded
  * once: to bf16, or stored as fp32 when y_is_f32 != 0 (head outputs that feed the loss).  Same rn_conv_desc, with strides
- * counted in elements; Cin % 8 == 0, Cout % 4 == 0; in_relu, add2 and w_batch_stride are not available (RN_EINVAL).
- * x, w_packed 16-byte aligned; y, add, mask 8-byte aligned.  Replaces the same nn.Conv2d call sites as rn_conv_igemm
+ * counted in elements; Cin % 8 == 0, Cout % 8 == 0 for a bf16 result (% 4 for an fp32 one); in_relu, add2 and w_batch_stride
+ * are not available (RN_EINVAL).  x, w_packed, y 16-byte aligned; add, mask 16-byte aligned (8 beside an fp32 result).  Replaces the same nn.Conv2d call sites as rn_conv_igemm
  * (D/model.py:59-205, D/utils.py:12-80) when the caller opts into bf16 storage; the reference itself is fp32. */
 int rn_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);   /* round-to-nearest-even, NaN stays NaN */
 int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stream);
