@@ -85,10 +85,10 @@ extern "C" int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stre
 // One 128 x 128 output tile; 4 waves as 2 x 2, each a 64 x 64 sub-tile = 2 x 2 accumulators of the 32x32x16 MFMA.
 // YF32: the output is written as fp32 (head outputs feeding the loss) instead of bf16; addend and mask are bf16.
 template <bool YF32>
-__global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
-                                                                 const __bf16 *__restrict__ w, void *__restrict__ yv,
-                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                 const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask) {
+__device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, const __bf16 *__restrict__ x,
+                                                     const __bf16 *__restrict__ w, void *__restrict__ yv,
+                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                     const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask, const int tile) {
     constexpr int BM = 128, BN = 128, WN = 2;
     constexpr int RF = 16;                                   // floats (4-byte words) per staged row: 64 bytes
     constexpr int RPI = 16;                                  // rows one wave instruction fills (1 KiB / 64 B)
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_d
     constexpr int LDSF = 2 * STEP > RP * LDT ? 2 * STEP : RP * LDT;
     __shared__ float lds[LDSF];
 
-    const int tile = bf_xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -323,6 +322,35 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_d
     }
 }
 
+template <bool YF32>
+__global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
+                                                                 const __bf16 *__restrict__ w, void *__restrict__ yv,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask) {
+    conv_igemm_bf16_tile<YF32>(d, x, w, yv, scale, shift, add, mask, bf_xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch (rn_conv_igemm_grouped's form): up to RN_MAX_GROUP problems sharing weights and epilogue scalars -- the five
+// pyramid levels of a head layer -- as ONE grid; the workgroup looks up its problem by tile id (wave-uniform).
+template <bool YF32>
+__global__ __launch_bounds__(256, 4) void conv_igemm_bf16_grouped_kernel(const rn_conv_group g, const __bf16 *__restrict__ w,
+                                                                         const float *__restrict__ scale,
+                                                                         const float *__restrict__ shift) {
+    const int tile = bf_xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    rn_conv_desc d = g.d[0];
+    const float *x = g.x[0], *add = g.add[0], *mask = g.mask[0];
+    float *y = g.y[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
+    conv_igemm_bf16_tile<YF32>(d, reinterpret_cast<const __bf16 *>(x), w, y, scale, shift, reinterpret_cast<const __bf16 *>(add),
+                               reinterpret_cast<const __bf16 *>(mask), tile - first);
+}
+
 static inline int check_desc_bf16(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3)) return RN_EINVAL;   // 16-byte chunks of 8 channels; 16-byte stores
@@ -340,15 +368,46 @@ static inline int check_desc_bf16(const rn_conv_desc *d) {
     return RN_OK;
 }
 
+static inline int check_ptrs_bf16(const rn_conv_desc *d, const void *x, const void *y, const void *add, const void *mask, int y_is_f32) {
+    if ((d->add_mode != 0) != (add != nullptr) || (d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
+    if (!y_is_f32 && (d->Cout & 7)) return RN_EINVAL;                    // bf16 result: 8 channels = 16 bytes per lane
+    const uintptr_t am = y_is_f32 ? 7 : 15;                               // addend / mask: 8 bytes beside an fp32 result, else 16
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add & am) || ((uintptr_t)mask & am)) return RN_EINVAL;
+    if (!y_is_f32 && ((d->y_batch_stride & 7) || (d->add_batch_stride & 7))) return RN_EINVAL;
+    return RN_OK;
+}
+
+extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int y_is_f32, const float *scale,
+                                          const float *shift, void *stream) {
+    if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
+    const rn_conv_desc &d0 = g->d[0];
+    int prev = 0;
+    for (int i = 0; i < g->n; ++i) {
+        const rn_conv_desc &d = g->d[i];
+        int rc = check_desc_bf16(&d);
+        if (rc) return rc;
+        rc = check_ptrs_bf16(&d, g->x[i], g->y[i], g->add[i], g->mask[i], y_is_f32);
+        if (rc) return rc;
+        if (d.Cin != d0.Cin || d.Cout != d0.Cout || d.kh != d0.kh || d.kw != d0.kw || d.act != d0.act) return RN_EINVAL;
+        const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+        const int64_t tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
+        if (g->tile_end[i] - prev != tiles) return RN_EINVAL;
+        prev = g->tile_end[i];
+    }
+    const dim3 grid((unsigned)prev), block(256);
+    const __bf16 *wb = reinterpret_cast<const __bf16 *>(w_packed);
+    if (y_is_f32) hipLaunchKernelGGL(conv_igemm_bf16_grouped_kernel<true>, grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+    else hipLaunchKernelGGL(conv_igemm_bf16_grouped_kernel<false>, grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const void *w_packed, void *y, int y_is_f32,
                                   const float *scale, const float *shift, const void *add, const void *mask, void *stream) {
     const int rc = check_desc_bf16(d);
     if (rc) return rc;
-    if ((d->add_mode != 0) != (add != nullptr) || (d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
-    if (!y_is_f32 && (d->Cout & 7)) return RN_EINVAL;                    // bf16 result: 8 channels = 16 bytes per lane
-    const uintptr_t am = y_is_f32 ? 7 : 15;                               // addend / mask: 8 bytes beside an fp32 result, else 16
-    if (((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add & am) || ((uintptr_t)mask & am)) return RN_EINVAL;
-    if (!y_is_f32 && ((d->y_batch_stride & 7) || (d->add_batch_stride & 7))) return RN_EINVAL;
+    const int rp = check_ptrs_bf16(d, x, y, add, mask, y_is_f32);
+    if (rp || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
     if (tiles > 0x7fffffff) return RN_EINVAL;

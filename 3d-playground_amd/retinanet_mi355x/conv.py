@@ -546,3 +546,28 @@ def relu_bf16(x):
     out = torch.empty_like(x)
     _hip.check(_hip.load().rn_relu_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _hip.stream()), "rn_relu_bf16")
     return out
+
+
+def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):
+    """conv_igemm_grouped with bf16 operands: one launch for up to 5 problems sharing weights / epilogue scalars (the
+    pyramid levels of a head layer).  All results bf16, or all fp32 (the dtype of the first y decides)."""
+    lib = _hip.load()
+    g = _hip.ConvGroup()
+    g.n = len(problems)
+    total = 0
+    yf32 = problems[0]["y"].dtype == torch.float32
+    for i, pr in enumerate(problems):
+        x, geom = pr["x"], pr["geom"]
+        add, mask = pr.get("add"), pr.get("mask")
+        assert x.dtype == torch.bfloat16 and (pr["y"].dtype == torch.float32) == yf32
+        d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), (pr.get("mask_mode", 2) if mask is not None else 0),
+                       False, None, pr.get("y_batch_stride"), None, None)
+        g.d[i] = d
+        M = d.N * d.Ho * d.Wo
+        total += ((M + 127) // 128) * ((d.Cout + 127) // 128)
+        g.tile_end[i] = total
+        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
+    kind = "conv_igemm_bf16" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16_grouped(
+        ctypes.byref(g), w_packed.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
+    _hip.check(rc, "rn_conv_igemm_bf16_grouped")

@@ -149,9 +149,17 @@ class Layer:
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only)."""
         s = self.spec
-        if self.bf16:                                  # one launch per level (no grouped bf16 launch yet)
-            return [self.fwd(x, act=act, out=None if outs is None else outs[i], y_batch_stride=y_batch_stride)
-                    for i, x in enumerate(xs)]
+        if self.bf16:                                  # the levels of a head layer as one grouped bf16 launch
+            probs, ys, fl = [], [], 0.0
+            for i, x in enumerate(xs):
+                N, Hi, Wi, _ = x.shape
+                y = outs[i] if outs is not None else torch.empty((N, Hi, Wi, s.cout), dtype=torch.bfloat16, device=x.device)
+                ys.append(y)
+                fl += self.flops(N, Hi, Wi)
+                probs.append({"x": x, "y": y, "geom": (Hi, Wi, s.cout, s.k, self.kw_pad, 1, 1, -s.pad, 0),
+                              "y_batch_stride": y_batch_stride})
+            cv.conv_igemm_bf16_grouped(probs, self.wf16, scale=self.scale, shift=self.shift, act=act, flops=fl)
+            return ys
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
             r = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift, act=act, flops=fl,
@@ -175,8 +183,16 @@ class Layer:
         s = self.spec
         assert s.stride == 1
         if self.bf16:
-            return [self.bwd_data(g, in_hws[i], add=None if adds is None else adds[i], mask=None if masks is None else masks[i])
-                    for i, g in enumerate(gs)]
+            probs, outs, fl = [], [], 0.0
+            for i, g in enumerate(gs):
+                Hi, Wi = in_hws[i]
+                dx = torch.empty((g.shape[0], Hi, Wi, s.cin), dtype=torch.bfloat16, device=g.device)
+                outs.append(dx)
+                fl += self.flops(g.shape[0], g.shape[1], g.shape[2])
+                probs.append({"x": g, "y": dx, "geom": (Hi, Wi, s.cin, s.k, s.k, 1, -1, s.pad, 0),
+                              "add": None if adds is None else adds[i], "mask": None if masks is None else masks[i]})
+            cv.conv_igemm_bf16_grouped(probs, self.dgrad_weights16(), flops=fl)
+            return outs
         if (wino or self.wino_active) and self.wino_ok and all(g.shape[3] == s.cout for g in gs):
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
             return cv.wino_conv_group(gs, self.wino_weights(1), adds=adds, masks=masks, mask_mode=2, flops=fl)

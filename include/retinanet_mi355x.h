@@ -321,6 +321,9 @@ int rn_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);   /* r
 int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stream);
 int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const void *w_packed, void *y, int y_is_f32,
                        const float *scale, const float *shift, const void *add, const void *mask, void *stream);
+/* Grouped form (see rn_conv_igemm_grouped): the pointers of rn_conv_group are bf16 (x, add, mask) / bf16 or fp32 (y). */
+int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int y_is_f32, const float *scale,
+                               const float *shift, void *stream);
 /* dw[co][r][s][ci] (fp32, packed [Cout][Kpad] like rn_conv_wgrad, atomically accumulated) from bf16 dy [N,Ho,Wo,ldy>=Cout]
  * and bf16 x [N,Hi,Wi,Cin]; colsum (may be NULL) += column sums of dy.  Cin % 8 == 0, ldy % 8 == 0. */
 int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi, int Cin,
