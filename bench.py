@@ -111,6 +111,75 @@ def loss_kernel_roofline(dev, B, H, W, C=8, N=10, iters=20):
     return res
 
 
+def bf16_section(dev, args, B, H, W):
+    """Supplementary, NOT the headline: BASELINE configs[2]'s storage format on this GPU -- (a) the bf16 MFMA kernels on
+    the benchmark's dominant layer (3x3, 256->256 at 135x240, batch B) against the 2.5 PF dense bf16 MFMA peak AND the HBM
+    roof (algorithmic bytes: every operand once), (b) the same training step with bf16 activations (fp32 accumulation,
+    master weights, gradients, loss)."""
+    from retinanet_mi355x import conv as cv, modules, optim, synth
+    C, Hh, Ww = 256, 135, 240
+    x = cv.to_bf16(torch.randn(B, Hh, Ww, C, device=dev))
+    g = cv.to_bf16(torch.randn(B, Hh, Ww, C, device=dev))
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.02
+    wf = cv.pack_weights_bf16(w, 0)
+    y = torch.empty(B, Hh, Ww, C, dtype=torch.bfloat16, device=dev)
+    dw = torch.zeros(C, 9 * C, device=dev)
+    flops = 2.0 * B * Hh * Ww * C * C * 9
+
+    def timeit(fn, iters=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    out = {}
+    for name, fn, nbytes in (("conv_igemm_bf16", lambda: cv.conv_igemm_bf16(x, wf, y, (Hh, Ww, C, 3, 3, 1, 1, -1, 0)),
+                              2 * (x.numel() + y.numel() + wf.numel())),
+                             ("conv_wgrad_bf16", lambda: cv.wgrad_bf16(g, x, dw, C, 3, 1, 1), 2 * (g.numel() + x.numel()) + 4 * dw.numel())):
+        ms = timeit(fn)
+        tf, gbs = flops / ms / 1e9, nbytes / ms / 1e6
+        out[name] = {"layer": "3x3 256->256 @135x240, batch %d" % B, "bound": "mfma", "achieved": round(tf, 1),
+                     "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_MFMA_TF, 4), "ms": round(ms, 4),
+                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes}
+    del x, g, y, dw
+    net = getattr(modules, args.arch)(num_classes=8)
+    net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))
+    net = net.to(dev)
+    net.set_compute_dtype("bf16")
+    net.train()
+    net.freeze_bn()
+    net.use_flat_gradients()
+    opt = optim.ClipAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, max_norm=0.1)
+    img = torch.randn(B, 3, H, W, device=dev)
+    ann = synth.labels_dir(B, 10, H, W, 8, seed=1).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = sum(l.mean() for l in net([img, ann]))
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    n = 5
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    out["training_step"] = {"value": round(B * n / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / n, 2),
+                            "dtype": "bf16", "steps": n, "final_loss": round(float(loss.detach()), 5),
+                            "note": "same step as the headline with bf16 activations / MFMA (fp32 accumulation, master weights, "
+                                    "gradients, loss); not the reference's arithmetic, not the headline"}
+    return out
+
+
 def pmc_traffic(kind):
     """Average HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command
     (tools/collect_traffic.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).
@@ -298,6 +367,10 @@ def main():
                     "ms_per_pass": round(wms / 3, 2), "algorithmic_tflops": round(fwork / (wms * 1e-3) / 1e12, 2),
                     "note": "3x3 stride-1 layers with >= 128 channels by Winograd F(4x4,3x3): a quarter of the multiplications there"}
             line["kernels"] = kernels
+        if world == 1 and args.dtype == "fp32" and timer is not None:
+            del net, opt, params
+            torch.cuda.empty_cache()
+            line["bf16"] = bf16_section(dev, args, B, H, W)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
         print(json.dumps(line), flush=True)
