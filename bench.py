@@ -196,8 +196,12 @@ def pmc_traffic(kind):
 
 
 def cpu_baseline(arch, H, W):
-    """oracle/ (torch CPU kernels, reference algorithm) forward + loss + backward on ONE image of the workload."""
-    from oracle import model as omodel
+    """oracle/ (torch CPU kernels, reference algorithm) on this box's host cores, a bounded sample of the workload:
+    the whole model (forward + loss + backward on ONE image, all cores) = `value`, plus the path's components one by one at
+    the benchmark's own sizes, with all cores and with one thread: anchors, the fused loss forward and
+    forward + backward (B = 2), box decode (B = 2), the MULTI_FRAME post-process, the homography round trip."""
+    import numpy as np
+    from oracle import anchors as oanchors, boxes as oboxes, homography as ohg, losses as olosses, model as omodel
     from retinanet_mi355x import synth
     threads = torch.get_num_threads()
     sd = synth.state_dict(arch, 8, 12, seed=2)
@@ -209,8 +213,47 @@ def cpu_baseline(arch, H, W):
     losses = omodel.train_forward(img, ann, params, arch)
     sum(l.mean() for l in losses).backward()
     dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "1 image %dx%d, %s forward+loss+backward, torch CPU fp32 (%.1f s)" % (W, H, arch, dt)}
+    out = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": "1 image %dx%d, %s forward+loss+backward, torch CPU fp32 (%.1f s)" % (W, H, arch, dt)}
+    del params, losses
+    # ---- components (seconds per call; [all cores, 1 thread])
+    Bc = 2
+    anc = torch.from_numpy(oanchors.anchors_for_image(H, W))
+    A = anc.shape[1]
+    cls, reg = synth.head_outputs(1, A, 8, 12, seed=3)
+    cls, reg = cls.expand(Bc, A, 8).contiguous(), reg.expand(Bc, A, 12).contiguous()
+    ann2 = synth.labels_dir(Bc, 10, H, W, 8, seed=1)
+    Ps, Hs = synth.camera_matrices(18, seed=5)
+    state = synth.vehicle_states(3600, seed=6).numpy()
+    cam = np.arange(3600) % 18
+
+    def loss_fb():
+        c, r = cls.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+        sum(l.mean() for l in olosses.focal_loss_dir(c, r, anc, ann2)).backward()
+
+    def hg_round_trip():
+        im = ohg.space_to_im(ohg.state_to_space(state).astype(np.float64), Ps[cam])
+        ohg.im_to_state(im, Hs[cam], np.full(3600, 5.0, dtype=np.float32))
+    boxes = oboxes.decode_dir(anc, reg)
+    comps = (("anchors_1080p", lambda: oanchors.anchors_for_image(H, W)),
+             ("loss_fwd_B%d" % Bc, lambda: olosses.focal_loss_dir(cls, reg, anc, ann2)),
+             ("loss_fwd_bwd_B%d" % Bc, loss_fb),
+             ("decode_B%d" % Bc, lambda: oboxes.decode_dir(anc, reg)),
+             ("postprocess_multi_B%d" % Bc, lambda: oboxes.postprocess_multi(cls, boxes)),
+             ("homography_3600_boxes_round_trip", hg_round_trip))
+    res = {}
+    for name, fn in comps:
+        row = []
+        for nt in (threads, 1):
+            torch.set_num_threads(nt)
+            with torch.no_grad() if "bwd" not in name else torch.enable_grad():
+                t0 = time.time()
+                fn()
+                row.append(round(time.time() - t0, 4))
+        res[name] = row
+    torch.set_num_threads(threads)
+    out["components_seconds_allcores_1thread"] = res
+    return out
 
 
 def launch_ranks(args):

@@ -73,7 +73,11 @@ def main():
         flops = 2.0 * B * Ho * Wo * cout * cin * k * k
         bias = torch.randn(cout, device=dev)
         t_f = timeit(lambda: cv.fprop(x, wp, cout, k, stride, pad, shift=bias, act=cv.ACT_RELU), args.iters)
-        t_d = timeit(lambda: cv.dgrad(dy, wd, (H, W), cin, k, stride, pad), args.iters)
+        if stride == 2 and k > 1:                       # what the engine runs: one launch per output-parity class, no wasted taps
+            wcls = [cv.pack_weights(w, 1, c_pad=cpad, taps=c[2]) for c in cv.s2_classes(k, pad)]
+            t_d = timeit(lambda: cv.dgrad_s2_classes(dy, wcls, (H, W), cin, k, pad), args.iters)
+        else:
+            t_d = timeit(lambda: cv.dgrad(dy, wd, (H, W), cin, k, stride, pad), args.iters)
         t_w = timeit(lambda: cv.wgrad(dy, x, dw, cout, k, stride, pad), args.iters)
         tf = [flops / (t * 1e-3) / 1e12 for t in (t_f, t_d, t_w)]
         print("%-26s %5.1f %3.0f%% %5.1f %3.0f%% %5.1f %3.0f%%   ms %.3f %.3f %.3f" % (
