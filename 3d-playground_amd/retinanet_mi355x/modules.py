@@ -20,7 +20,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import _hip, arch, engine, ops
+from . import _hip, arch, engine, ops, torch_ops
 
 
 # ----------------------------------------------------------------------------------------------- containers
@@ -105,7 +105,9 @@ class Anchors(nn.Module):                         # D/anchors.py:6-40
         self.sizes = [2 ** (x + 2) for x in self.pyramid_levels]
 
     def forward(self, image):
-        return ops.anchors(image.shape[2], image.shape[3], image.device)
+        if not image.is_cuda:
+            raise RuntimeError("anchors are generated on the MI355X (no CPU fallback); got device %s" % image.device)
+        return torch.ops.retinanet_mi355x.anchors(image.shape[2], image.shape[3], image.device)
 
 
 class BBoxTransform(nn.Module):                   # D/utils.py:82-149 / R/utils.py:82-126
@@ -117,7 +119,9 @@ class BBoxTransform(nn.Module):                   # D/utils.py:82-149 / R/utils.
         self.directional = directional
 
     def forward(self, boxes, regression):
-        return ops.decode_dir(boxes, regression) if self.directional else ops.decode_2d(boxes, regression)
+        if self.directional:
+            return torch.ops.retinanet_mi355x.decode_dir(boxes, regression)
+        return torch.ops.retinanet_mi355x.decode_2d(boxes, regression, False, 0, 0)
 
 
 class ClipBoxes(nn.Module):                       # R/utils.py:129-144
@@ -125,7 +129,9 @@ class ClipBoxes(nn.Module):                       # R/utils.py:129-144
         super().__init__()
 
     def forward(self, boxes, img):
-        return ops.clip_boxes_(boxes, img.shape[2], img.shape[3])
+        ops.clip_boxes_check(boxes)
+        torch.ops.retinanet_mi355x.clip_boxes_(boxes, img.shape[2], img.shape[3])
+        return boxes
 
 
 class FocalLoss(nn.Module):                       # D/losses.py:24-362 / R/losses.py:24-177
@@ -134,11 +140,11 @@ class FocalLoss(nn.Module):                       # D/losses.py:24-362 / R/losse
         self.directional = directional
 
     def forward(self, classifications, regressions, anchors, annotations):
-        return ops.focal_loss(classifications, regressions, anchors, annotations, self.directional)
+        return torch_ops.focal_loss(classifications, regressions, anchors, annotations, self.directional)
 
 
 def calc_iou(a, b):                               # D/losses.py:5-22
-    return ops.pairwise_iou(a, b)
+    return torch.ops.retinanet_mi355x.pairwise_iou(a, b)
 
 
 # ----------------------------------------------------------------------------------------------- the network

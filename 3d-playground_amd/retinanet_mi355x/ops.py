@@ -73,47 +73,65 @@ def focal_workspace(B, A, device):
     return ws
 
 
+def focal_workspace_bytes(B, A):
+    return int(_hip.load().rn_focal_workspace_bytes(int(B), int(A)))
+
+
+def focal_loss_forward_raw(cls, reg, anchor_boxes, ann, directional):
+    """rn_focal_loss_fwd: -> (losses [3] fp32, workspace for the backward).  No autograd, no label check."""
+    lib = _hip.load()
+    _hip.need_gpu(cls, reg, anchor_boxes, ann)
+    cls_c, reg_c = _hip.f32c(cls), _hip.f32c(reg)
+    anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
+    ann_c = _hip.f32c(ann)
+    B, A, C = cls_c.shape
+    N = ann_c.shape[1]
+    n_reg, cols = (12, 27) if directional else (4, 5)
+    if reg_c.shape != (B, A, n_reg) or anc.shape[0] != A or ann_c.shape[2] != cols or ann_c.shape[0] != B:
+        raise RuntimeError("focal loss: shapes cls %s reg %s anchors %s ann %s do not fit the %s variant"
+                           % (tuple(cls.shape), tuple(reg.shape), tuple(anchor_boxes.shape), tuple(ann.shape),
+                              "directional" if directional else "2D"))
+    ws = focal_workspace(B, A, cls_c.device)
+    losses = torch.empty(3, dtype=torch.float32, device=cls_c.device)
+    with torch.cuda.device(cls_c.device):
+        _hip.check(lib.rn_focal_loss_fwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),
+                                         B, A, C, N, int(directional), ws.data_ptr(), losses.data_ptr(),
+                                         _hip.stream()), "rn_focal_loss_fwd")
+    return losses, ws
+
+
+def focal_loss_backward_raw(cls, reg, anchor_boxes, ann, directional, ws, grad_losses):
+    """rn_focal_loss_bwd: grad_losses [3] device floats -> (dcls, dreg)."""
+    lib = _hip.load()
+    cls_c, reg_c = _hip.f32c(cls), _hip.f32c(reg)
+    anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
+    ann_c = _hip.f32c(ann)
+    B, A, C = cls_c.shape
+    g = _hip.f32c(grad_losses.reshape(3))
+    dcls, dreg = torch.empty_like(cls_c), torch.empty_like(reg_c)
+    with torch.cuda.device(cls_c.device):
+        _hip.check(lib.rn_focal_loss_bwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),
+                                         B, A, C, ann_c.shape[1], int(directional), ws.data_ptr(),
+                                         g.data_ptr(), dcls.data_ptr(), dreg.data_ptr(), _hip.stream()), "rn_focal_loss_bwd")
+    return dcls, dreg
+
+
 class _FocalLossFn(torch.autograd.Function):
     """FocalLoss.forward (D/losses.py:27-362 / R/losses.py:27-177) with a hand-written backward."""
 
     @staticmethod
     def forward(ctx, cls, reg, anchor_boxes, ann, directional):
-        lib = _hip.load()
-        _hip.need_gpu(cls, reg, anchor_boxes, ann)
-        cls_c, reg_c = _hip.f32c(cls), _hip.f32c(reg)
-        anc = _hip.f32c(anchor_boxes.reshape(-1, 4))
-        ann_c = _hip.f32c(ann)
-        B, A, C = cls_c.shape
-        N = ann_c.shape[1]
-        n_reg, cols = (12, 27) if directional else (4, 5)
-        if reg_c.shape != (B, A, n_reg) or anc.shape[0] != A or ann_c.shape[2] != cols or ann_c.shape[0] != B:
-            raise RuntimeError("focal loss: shapes cls %s reg %s anchors %s ann %s do not fit the %s variant"
-                               % (tuple(cls.shape), tuple(reg.shape), tuple(anchor_boxes.shape), tuple(ann.shape),
-                                  "directional" if directional else "2D"))
-        ws = focal_workspace(B, A, cls_c.device)
-        losses = torch.empty(3, dtype=torch.float32, device=cls_c.device)
-        with torch.cuda.device(cls_c.device):
-            _hip.check(lib.rn_focal_loss_fwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),
-                                             B, A, C, N, int(directional), ws.data_ptr(), losses.data_ptr(),
-                                             _hip.stream()), "rn_focal_loss_fwd")
-        ctx.save_for_backward(cls_c, reg_c, anc, ann_c, ws)
+        losses, ws = focal_loss_forward_raw(cls, reg, anchor_boxes, ann, directional)
+        ctx.save_for_backward(cls, reg, anchor_boxes, ann, ws)
         ctx.directional = directional
         return losses[0:1], losses[1:2], losses[2:3]
 
     @staticmethod
     def backward(ctx, g_cls, g_reg, g_vp):
-        lib = _hip.load()
-        cls_c, reg_c, anc, ann_c, ws = ctx.saved_tensors
-        B, A, C = cls_c.shape
-        g = torch.cat([t.reshape(1).float() if t is not None else torch.zeros(1, device=cls_c.device)
+        cls, reg, anchor_boxes, ann, ws = ctx.saved_tensors
+        g = torch.cat([t.reshape(1).float() if t is not None else torch.zeros(1, device=cls.device)
                        for t in (g_cls, g_reg, g_vp)])
-        dcls = torch.empty_like(cls_c)
-        dreg = torch.empty_like(reg_c)
-        with torch.cuda.device(cls_c.device):
-            _hip.check(lib.rn_focal_loss_bwd(cls_c.data_ptr(), reg_c.data_ptr(), anc.data_ptr(), _hip.ptr(ann_c),
-                                             B, A, C, ann_c.shape[1], int(ctx.directional), ws.data_ptr(),
-                                             g.data_ptr(), dcls.data_ptr(), dreg.data_ptr(), _hip.stream()),
-                       "rn_focal_loss_bwd")
+        dcls, dreg = focal_loss_backward_raw(cls, reg, anchor_boxes, ann, ctx.directional, ws, g)
         return dcls, dreg, None, None, None
 
 
@@ -204,12 +222,16 @@ def decode_2d(anchor_boxes, deltas, clip_hw=None):
     return out
 
 
-def clip_boxes_(boxes, height, width):
-    """ClipBoxes.forward (R/utils.py:134-144): in place on a contiguous [..,4] fp32 tensor; returns it."""
-    lib = _hip.load()
+def clip_boxes_check(boxes):
     _hip.need_gpu(boxes)
     if boxes.dtype != torch.float32 or not boxes.is_contiguous() or boxes.shape[-1] != 4:
         raise RuntimeError("clip_boxes_ needs a contiguous fp32 [...,4] tensor")
+
+
+def clip_boxes_(boxes, height, width):
+    """ClipBoxes.forward (R/utils.py:134-144): in place on a contiguous [..,4] fp32 tensor; returns it."""
+    lib = _hip.load()
+    clip_boxes_check(boxes)
     if boxes.numel():
         with torch.cuda.device(boxes.device):
             _hip.check(lib.rn_clip_boxes(boxes.data_ptr(), boxes.numel() // 4, float(width), float(height),

@@ -274,3 +274,30 @@ def test_homography_round_trip_large(ops, dev):
     assert float((back - st).abs().max()) < 5e-3
     want = ohg.state_to_im(st.cpu().numpy(), Pn[idx.cpu().numpy()])
     assert np.allclose(im.cpu().numpy(), want, rtol=1e-9, atol=1e-8)
+
+
+def test_custom_operators_match_the_functional_layer(ops, dev, golden):
+    """torch.ops.retinanet_mi355x.* (retinanet_mi355x/torch_ops.py) run the same kernels: outputs identical to ops.*, the
+    registered autograd of focal_loss gives the same input gradients, and torch.library.opcheck accepts the registration."""
+    from retinanet_mi355x import torch_ops
+    H, W = gc.LOSS_HW
+    anc = torch.ops.retinanet_mi355x.anchors(H, W, dev)
+    assert torch.equal(anc, ops.anchors(H, W, dev))
+    cls, reg = gc.loss_heads(12, 21)
+    ann = gc.loss_labels_dir().to(dev)
+    c1, r1 = cls.to(dev).requires_grad_(True), reg.to(dev).requires_grad_(True)
+    c2, r2 = cls.to(dev).requires_grad_(True), reg.to(dev).requires_grad_(True)
+    a = torch_ops.focal_loss(c1, r1, anc, ann, True)
+    b = ops.focal_loss(c2, r2, anc, ann, True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    (a[0] + 2 * a[1] + 3 * a[2]).sum().backward()
+    (b[0] + 2 * b[1] + 3 * b[2]).sum().backward()
+    assert torch.equal(c1.grad, c2.grad) and torch.equal(r1.grad, r2.grad)
+    boxes = torch.ops.retinanet_mi355x.decode_dir(anc, reg.to(dev))
+    assert torch.equal(boxes, ops.decode_dir(anc, reg.to(dev)))
+    keep = torch.ops.retinanet_mi355x.nms(boxes[0, :500, 16:20].contiguous(), cls[0, :500, 0].to(dev).contiguous(), 0.5)
+    assert torch.equal(keep, ops.nms(boxes[0, :500, 16:20].contiguous(), cls[0, :500, 0].to(dev).contiguous(), 0.5))
+    torch.library.opcheck(torch.ops.retinanet_mi355x.decode_dir.default, (anc, reg.to(dev)),
+                          test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.retinanet_mi355x.focal_loss_fwd.default, (cls.to(dev), reg.to(dev), anc, ann, True),
+                          test_utils=("test_schema", "test_faketensor"))

@@ -97,3 +97,21 @@ def test_golden_recipe_regenerates_the_committed_fixtures(tmp_path):
             x, y = a[k].astype(np.float64), b[k].astype(np.float64)
             assert np.array_equal(np.isnan(x), np.isnan(y)), (fn, k)
             assert np.nanmax(np.abs(x - y)) <= 1e-6 * np.nanmax(np.abs(y)), (fn, k, np.nanmax(np.abs(x - y)))
+
+
+def test_custom_operators_are_registered_and_have_no_cpu_kernel():
+    """north_star: the HIP entry points are exposed as PyTorch custom ops (torch.ops.retinanet_mi355x.*) with schemas and
+    shape-only (fake) implementations; there is no CPU kernel behind them."""
+    from retinanet_mi355x import torch_ops
+    for name in torch_ops.OPERATORS:
+        op = getattr(torch.ops.retinanet_mi355x, name)
+        assert "retinanet_mi355x::" + name in str(op.default._schema)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.retinanet_mi355x.decode_dir(torch.zeros(1, 10, 4), torch.zeros(2, 10, 12))
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():                              # shape inference without a device
+        r = torch.ops.retinanet_mi355x.decode_dir(torch.empty(1, 10, 4, device="cuda"), torch.empty(2, 10, 12, device="cuda"))
+        assert tuple(r.shape) == (2, 10, 20)
+        l, ws = torch.ops.retinanet_mi355x.focal_loss_fwd(torch.empty(2, 100, 8, device="cuda"), torch.empty(2, 100, 12, device="cuda"),
+                                                          torch.empty(1, 100, 4, device="cuda"), torch.empty(2, 5, 27, device="cuda"), True)
+        assert tuple(l.shape) == (3,) and ws.dtype == torch.uint8
