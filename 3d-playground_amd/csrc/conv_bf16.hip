@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_wgrad_geom.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -441,7 +442,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // by wg_fx(row), the image that serves gfx950's transposing read without bank conflicts (cdna_hip_programming.md T10 (b);
 // operand addressing verified by tools/probes/tr_probe.hip).  The direct-to-LDS load fills rows linearly, so the
 // permutation is applied on the load's SOURCE: the lane filling position cp of row r fetches logical chunk cp ^ wg_fx(r).
-__device__ __forceinline__ int wg_fx(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int wg_fx(int row) { return WgradBf16Geom::fx(row); }
 
 // One 32x32x16 operand from such an image: lane l <- 8 consecutive rows (pixels) 16*kh + 8*(l>>5) + 0..7 of column
 // col0 + (l & 31), by two ds_read_b64_tr_b16 (each: a 4-row x 16-column block per 16 lanes, returned column-major).
@@ -487,13 +488,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
     int b_fr[IB], b_fs[IB], b_tapoff[IB];
 #pragma unroll
     for (int j = 0; j < IA; ++j) {
-        const int row = (wave * IA + j) * 4 + rq;
+        const int row = WgradBf16Geom::dma_row(wave, j) + rq;
         const int col = m0 + 8 * (cp ^ wg_fx(row));
         a_voff[j] = col < p.ldy ? (unsigned)((row * p.ldy + col) * 2) : 0x80000000u;
     }
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
-        const int row = (wave * IB + j) * 4 + rq;
+        const int row = WgradBf16Geom::dma_row(wave, j) + rq;
         const int jcol = n0 + 8 * (cp ^ wg_fx(row));         // the chunk fixes (tap, first input channel)
         const int tap = jcol / p.Cin;
         const int ci0 = jcol - tap * p.Cin;
@@ -502,7 +503,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
         b_fr[j] = jcol < p.Kflat ? fr : (1 << 24);           // a column past the matrix fails every row test
         b_tapoff[j] = ((fr * p.Wi + b_fs[j]) * p.Cin + ci0) * 2;
     }
-    const int b_px0 = wave * IB * 4 + rq;                    // this lane's pixel for instruction 0 (+4 per instruction)
 
     auto fill_batch = [&](int j) {
         const int rel = rel0 + j * (TB * WK) + tid;
@@ -518,10 +518,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
     };
     unsigned b_voff[IB];
     auto make_offsets = [&](int ks) {
-        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK + b_px0];
+        const int4 *tab = pixtab[(ks / TB) & 1];
 #pragma unroll
         for (int j = 0; j < IB; ++j) {
-            const int4 e = tab[j * 4];
+            const int4 e = tab[WgradBf16Geom::tab_index(ks, wave, lane, j)];
             const bool ok = ((unsigned)(e.y + b_fr[j]) < (unsigned)p.Hi) & ((unsigned)(e.z + b_fs[j]) < (unsigned)p.Wi);
             b_voff[j] = ok ? (unsigned)(e.x + b_tapoff[j]) : 0xFFFFFFFFu;
         }
@@ -539,18 +539,14 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
         for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (4 * WG_ROWB), b_voff[j], 0u);
     };
 
-    // fragment read addresses (bytes within a tile image): block row r0 + q, chunk c0 + (pp >> 1), half pp & 1
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    // fragment read addresses (bytes within a buffer): block row r0 + q, chunk c0 + (pp >> 1), half pp & 1 (conv_wgrad_geom.h)
     unsigned fa[2][2], fb[2][2];                             // [32-column sub-tile][read 0/1]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
-            const int row = 8 * (g >> 1) + 4 * rd + q;
-            const int ca = (wm * 64 + t * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
-            const int cb = (wn * 64 + t * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
-            fa[t][rd] = (unsigned)(WG_ROWB * row + 16 * (ca ^ wg_fx(row)) + 8 * (pp & 1));
-            fb[t][rd] = (unsigned)(WK * WG_ROWB + WG_ROWB * row + 16 * (cb ^ wg_fx(row)) + 8 * (pp & 1));
+            fa[t][rd] = (unsigned)WgradBf16Geom::tr_addr(wm, t, rd, 0, lane);
+            fb[t][rd] = (unsigned)(WgradBf16Geom::IMG + WgradBf16Geom::tr_addr(wn, t, rd, 0, lane));
         }
 
     f32x16 acc[2][2];

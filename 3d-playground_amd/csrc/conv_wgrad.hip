@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_wgrad_geom.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WK_MAX 32                // pixels per K-step: 32 or 16 (the kernel's WK parameter)
@@ -59,12 +60,12 @@ struct WgradArgs {
 // WK pixels per K-step, OCC workgroups per CU the register budget is cut for (LDS: 2 * WK * (BM + BN) * 4 + 8 KiB).
 template <int WM, int WN, bool RELU, int WK, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int TB = 256 / WK;                             // K-steps per pixel-table batch: one entry per thread
-    constexpr int CA = BM / 4, CB = BN / 4;                  // 16-byte chunks per tile row
-    constexpr int PA = 64 / CA, PB = 64 / CB;                // pixels one wave instruction (64 lanes x 16 B) covers
-    constexpr int IA = WK / PA / 4, IB = WK / PB / 4;        // DMA instructions per wave per K-step (4 waves share a tile)
-    static_assert(PA >= 1 && PB >= 1 && IA >= 1 && IB >= 1, "tile shape");
+    using G = WgradGeom<WM, WN, WK>;                         // index arithmetic shared with the host-side range check
+    constexpr int BM = G::BM, BN = G::BN;
+    constexpr int TB = G::TB;                                // K-steps per pixel-table batch: one entry per thread
+    constexpr int CA = G::CA, CB = G::CB;                    // 16-byte chunks per tile row
+    constexpr int PA = G::PA, PB = G::PB;                    // pixels one wave instruction (64 lanes x 16 B) covers
+    constexpr int IA = G::IA, IB = G::IB;                    // DMA instructions per wave per K-step (4 waves share a tile)
     __shared__ float lds[2][WK * (BM + BN)];                 // per buffer: A [32 px][BM], then B [32 px][BN]
     __shared__ int4 pixtab[2][TB * WK];                      // two batches of TB K-steps: (x byte offset, ih0, iw0, -)
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     // Lane -> (pixel within the instruction's group, 16-byte chunk).  Instruction j of wave w fills pixels
     // (w * I + j) * P + lane / C of the tile: 1 KiB of LDS starting at that pixel's row.
     const int ca = lane % CA, pa = lane / CA;
-    const int cb = lane % CB, pb = lane / CB;
+    const int cb = lane % CB;                                // (the B half's pixel is G::tab_index's business)
     const bool a_col_ok = (m0 + 4 * ca) < p.ldy;
     const unsigned a_voff = a_col_ok ? (unsigned)(((wave * IA * PA + pa) * p.ldy + m0 + 4 * ca) * 4) : 0x80000000u;
     const unsigned a_step = (unsigned)(PA * 4) * (unsigned)p.ldy;          // bytes between consecutive instructions (scalar)
@@ -124,7 +125,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     const int fr = tap / p.kw, fs = tap - fr * p.kw;
     const int fr_t = jcol < p.Kflat ? fr : (1 << 24);        // a column past the matrix fails every row test below
     const int tap_off = ((fr * p.Wi + fs) * p.Cin + ci0) * 4;
-    const int b_px0 = wave * IB * PB + pb;                   // this lane's pixel for instruction 0
 
     // Pixel table: one entry per pixel of the K range, (byte offset of input pixel (ih0, iw0) channel 0, ih0, iw0) with
     // ih0 = oh*stride - pad: the two integer divisions of the (n, oh, ow) decomposition are done once per pixel for all
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     unsigned b_voff[IB];                                     // offsets of the next step to issue
     int4 e[IB];                                              // table entries of the step after that
     auto table_read = [&](int ks) {
-        const int4 *tab = &pixtab[(ks / TB) & 1][(ks % TB) * WK + b_px0];
+        const int4 *tab = pixtab[(ks / TB) & 1];
 #pragma unroll
-        for (int j = 0; j < IB; ++j) e[j] = tab[j * PB];
+        for (int j = 0; j < IB; ++j) e[j] = tab[G::tab_index(ks, wave, lane, j)];
     };
     auto make_offsets = [&]() {
 #pragma unroll
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     // Issue the loads of K-step ks into buffer `buf` (b_voff holds that step's offsets).  The caller's barrier has made
     // sure nobody still reads the buffer.
     auto dma_step = [&](int ks, int buf) {
-        const unsigned A = lds0 + (unsigned)((buf * WK * (BM + BN) + wave_u * (IA * PA) * BM) * 4);   // this wave's first row
-        const unsigned B = lds0 + (unsigned)((buf * WK * (BM + BN) + WK * BM + wave_u * (IB * PB) * BN) * 4);
+        const unsigned A = lds0 + (unsigned)((buf * G::BUF + G::dma_a(wave_u, 0)) * 4);   // this wave's first row
+        const unsigned B = lds0 + (unsigned)((buf * G::BUF + G::dma_b(wave_u, 0)) * 4);
         const unsigned so = (unsigned)ks * (unsigned)(WK * 4) * (unsigned)p.ldy;   // scalar: the K-step advance
 #pragma unroll
         for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (PA * BM * 4), a_voff, so + j * a_step);
@@ -193,9 +193,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     rn_wait_dma();
     __syncthreads();
 
-    const int hi = lane >> 5;
-    const int fa0 = hi * BM + wm * 64 + 2 * (lane & 31);
-    const int fb0 = hi * BN + wn * 64 + (lane & 31);          // B: channels j and j + 32 (see the epilogue)
+    const int fa0 = G::frag_a(wm, lane, 0);
+    const int fb0 = G::frag_b(wn, lane, 0) - WK * BM;         // B: channels j and j + 32 (see the epilogue)
     // Only the waves that own distinct channels of N-tile 0 add up column sums: two copies of the loop, chosen once.
     const bool do_cs = p.colsum != nullptr && batch == p.colsum_batch && (tile % p.tiles_n) == 0 && wn == 0;
     auto k_loop = [&](auto cs_tag) {

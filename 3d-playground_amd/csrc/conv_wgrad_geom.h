@@ -1,0 +1,51 @@
+// Index arithmetic of the weight-gradient kernels' LDS structures, shared by the kernels (conv_wgrad.hip, conv_bf16.hip) and
+// by a HOST program (tests/test_wgrad_index_ranges.py compiles tests/wgrad_index_check.cpp with g++) that enumerates every
+// lane / wave / K-step / instruction of every tile instance and checks that each index stays inside the structure it
+// addresses.  Why: a logically inactive lane still forms an ADDRESS (DESIGN.md "Rules"): in round 1 a grouped-wgrad
+// experiment let the lanes of the 256x64 instance index a 32-row LDS table at rows 32-63 -- a GPU memory fault on the first
+// such shape.  Any change to these expressions is now checked on the host before it reaches a GPU.
+#pragma once
+
+#ifdef __HIPCC__
+#define RN_HD __host__ __device__ __forceinline__
+#else
+#define RN_HD inline
+#endif
+
+// fp32 kernel (conv_wgrad.hip): tile 64*WM x 64*WN, WK pixels per K-step, 256 threads = 4 waves.
+template <int WM, int WN, int WK>
+struct WgradGeom {
+    static constexpr int BM = 64 * WM, BN = 64 * WN;
+    static constexpr int TB = 256 / WK;                      // K-steps per pixel-table batch (one entry per thread)
+    static constexpr int CA = BM / 4, CB = BN / 4;           // 16-byte chunks per tile row
+    static constexpr int PA = 64 / CA, PB = 64 / CB;         // pixels one wave instruction (64 lanes x 16 B) covers
+    static constexpr int IA = WK / PA / 4, IB = WK / PB / 4; // DMA instructions per wave per K-step
+    static constexpr int TAB = TB * WK;                      // entries of one pixel-table half
+    static constexpr int BUF = WK * (BM + BN);               // floats of one LDS buffer: A [WK][BM], then B [WK][BN]
+    static_assert(PA >= 1 && PB >= 1 && IA >= 1 && IB >= 1 && TAB == 256, "tile shape");
+
+    // pixel-table entry read by lane `lane` of wave `wave` for DMA instruction j of K-step ks (within its half)
+    static RN_HD int tab_index(int ks, int wave, int lane, int j) { return (ks % TB) * WK + wave * IB * PB + lane / CB + j * PB; }
+    // first float of the 256-float (1 KiB) block that DMA instruction j of wave `wave` fills, within a buffer
+    static RN_HD int dma_a(int wave, int j) { return wave * (IA * PA) * BM + j * (PA * BM); }
+    static RN_HD int dma_b(int wave, int j) { return WK * BM + wave * (IB * PB) * BN + j * (PB * BN); }
+    // fragment reads of k-pair kp: A = 2 adjacent floats (ds_read_b64), B = floats +0 and +32 (ds_read2_b32), within a buffer
+    static RN_HD int frag_a(int wm, int lane, int kp) { return ((lane >> 5) + 2 * kp) * BM + wm * 64 + 2 * (lane & 31); }
+    static RN_HD int frag_b(int wn, int lane, int kp) { return WK * BM + ((lane >> 5) + 2 * kp) * BN + wn * 64 + (lane & 31); }
+};
+
+// bf16 kernel (conv_bf16.hip): tile 128 x 128, 32 pixels per K-step, images of [32 pixels][128 columns] bf16 = 256-byte rows.
+struct WgradBf16Geom {
+    static constexpr int WK = 32, ROWB = 256, TB = 256 / WK, IA = WK / 4 / 4, IB = WK / 4 / 4, TAB = TB * WK;
+    static constexpr int IMG = WK * ROWB;                    // bytes of one tile image; a buffer = dY image, then X image
+    static RN_HD int fx(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+    static RN_HD int tab_index(int ks, int wave, int lane, int j) { return (ks % TB) * WK + wave * IB * 4 + (lane >> 4) + 4 * j; }
+    static RN_HD int dma_row(int wave, int j) { return (wave * IA + j) * 4; }           // first of the 4 rows instruction j fills
+    // byte address (within an image) a lane supplies to ds_read_b64_tr_b16 for read rd of 32-column sub-tile t, pixel half kh
+    static RN_HD int tr_addr(int w2, int t, int rd, int kh, int lane) {
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        const int row = 16 * kh + 8 * (g >> 1) + 4 * rd + q;
+        const int ch = (w2 * 64 + t * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
+        return ROWB * row + 16 * (ch ^ fx(row)) + 8 * (pp & 1);
+    }
+};

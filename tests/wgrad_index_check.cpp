@@ -1,0 +1,104 @@
+// Host-side range check of the weight-gradient kernels' LDS indexing (see 3d-playground_amd/csrc/conv_wgrad_geom.h).
+// Enumerates every wave, lane, K-step and instruction of every tile instance the launchers use; exits non-zero and prints
+// the first violation.  Built and run by tests/test_wgrad_index_ranges.py (g++, no GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#include "conv_wgrad_geom.h"
+
+static int fails = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { if (fails++ < 10) { std::printf("FAIL " __VA_ARGS__); std::printf("\n"); } } } while (0)
+
+template <int WM, int WN, int WK>
+static void check_fp32(const char *name) {
+    using G = WgradGeom<WM, WN, WK>;
+    // pixel table: every (K-step, wave, lane, instruction) inside one 256-entry half, and per K-step the 4 waves x lanes x
+    // instructions read exactly the step's WK entries
+    for (int ks = 0; ks < 4 * G::TB; ++ks) {
+        std::set<int> seen;
+        for (int w = 0; w < 4; ++w)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < G::IB; ++j) {
+                    const int i = G::tab_index(ks, w, l, j);
+                    CHECK(i >= 0 && i < G::TAB, "%s: table index %d (ks %d wave %d lane %d j %d) outside [0,%d)", name, i, ks, w, l, j, G::TAB);
+                    CHECK(i / WK == ks % G::TB, "%s: table index %d belongs to another K-step than %d", name, i, ks);
+                    seen.insert(i);
+                }
+        CHECK((int)seen.size() == WK, "%s: K-step %d touches %d table entries, expected %d", name, ks, (int)seen.size(), WK);
+    }
+    // DMA destinations: the 1 KiB blocks of the 4 waves tile the A region [0, WK*BM) and the B region exactly once each
+    std::vector<int> cover(G::BUF, 0);
+    for (int w = 0; w < 4; ++w) {
+        for (int j = 0; j < G::IA; ++j) {
+            const int a = G::dma_a(w, j);
+            CHECK(a >= 0 && a + 256 <= WK * G::BM, "%s: A block of wave %d instr %d at %d leaves [0,%d)", name, w, j, a, WK * G::BM);
+            for (int k = 0; k < 256 && a + k < G::BUF && a >= 0; ++k) cover[a + k]++;
+        }
+        for (int j = 0; j < G::IB; ++j) {
+            const int b = G::dma_b(w, j);
+            CHECK(b >= WK * G::BM && b + 256 <= G::BUF, "%s: B block of wave %d instr %d at %d leaves [%d,%d)", name, w, j, b, WK * G::BM, G::BUF);
+            for (int k = 0; k < 256 && b + k < G::BUF && b >= 0; ++k) cover[b + k]++;
+        }
+    }
+    for (int i = 0; i < G::BUF; ++i) CHECK(cover[i] == 1, "%s: LDS float %d is filled %d times per K-step", name, i, cover[i]);
+    // fragment reads of every wave / lane / k-pair
+    for (int w = 0; w < 4; ++w)
+        for (int l = 0; l < 64; ++l)
+            for (int kp = 0; kp < WK / 2; ++kp) {
+                const int a = G::frag_a(w / WN, l, kp), b = G::frag_b(w % WN, l, kp);
+                CHECK(a >= 0 && a + 1 < WK * G::BM, "%s: A fragment read at %d (wave %d lane %d kp %d)", name, a, w, l, kp);
+                CHECK(b >= WK * G::BM && b + 32 < G::BUF, "%s: B fragment read at %d (wave %d lane %d kp %d)", name, b, w, l, kp);
+            }
+    std::printf("ok %s: table %d entries/half, buffer %d floats\n", name, G::TAB, G::BUF);
+}
+
+static void check_bf16() {
+    using G = WgradBf16Geom;
+    for (int ks = 0; ks < 4 * G::TB; ++ks) {
+        std::set<int> seen;
+        for (int w = 0; w < 4; ++w)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < G::IB; ++j) {
+                    const int i = G::tab_index(ks, w, l, j);
+                    CHECK(i >= 0 && i < G::TAB && i / G::WK == ks % G::TB, "bf16: table index %d (ks %d wave %d lane %d j %d)", i, ks, w, l, j);
+                    seen.insert(i);
+                }
+        CHECK((int)seen.size() == G::WK, "bf16: K-step %d touches %d table entries", ks, (int)seen.size());
+    }
+    std::vector<int> rows(G::WK, 0);
+    for (int w = 0; w < 4; ++w)
+        for (int j = 0; j < G::IA; ++j) {
+            const int r = G::dma_row(w, j);
+            CHECK(r >= 0 && r + 4 <= G::WK, "bf16: DMA rows %d..%d of wave %d instr %d", r, r + 3, w, j);
+            for (int k = 0; k < 4 && r + k < G::WK && r >= 0; ++k) rows[r + k]++;
+        }
+    for (int r = 0; r < G::WK; ++r) CHECK(rows[r] == 1, "bf16: image row %d filled %d times", r, rows[r]);
+    // transposing reads: 8-byte aligned, inside the image, and the operand they assemble is the one the MFMA wants
+    for (int w2 = 0; w2 < 2; ++w2)
+        for (int t = 0; t < 2; ++t)
+            for (int kh = 0; kh < 2; ++kh)
+                for (int rd = 0; rd < 2; ++rd)
+                    for (int l = 0; l < 64; ++l) {
+                        const int a = G::tr_addr(w2, t, rd, kh, l);
+                        CHECK(a >= 0 && a + 8 <= G::IMG && (a & 7) == 0, "bf16: transposing read at %d (sub-tile %d/%d kh %d rd %d lane %d)", a, w2, t, kh, rd, l);
+                        CHECK(G::tr_addr(w2, t, rd, kh, l) == G::tr_addr(w2, t, rd, 0, l) + kh * 16 * G::ROWB, "bf16: the pixel half is not a constant offset");
+                        // the lane supplies block row q, columns 4p..4p+3: logical position of its 8 bytes
+                        const int row = a / G::ROWB, chunk = ((a % G::ROWB) / 16) ^ G::fx(row), col = 8 * chunk + ((a & 8) ? 4 : 0);
+                        const int g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+                        CHECK(row == 16 * kh + 8 * (g >> 1) + 4 * rd + q && col == w2 * 64 + t * 32 + 16 * (g & 1) + 4 * pp,
+                              "bf16: lane %d supplies row %d col %d", l, row, col);
+                    }
+    std::printf("ok bf16: table %d entries/half, image %d bytes\n", G::TAB, G::IMG);
+}
+
+int main() {
+    check_fp32<1, 4, 16>("fp32 64x256");       // the three instances rn_conv_wgrad_batched launches (conv_wgrad.hip)
+    check_fp32<4, 1, 16>("fp32 256x64");
+    check_fp32<2, 2, 16>("fp32 128x128");
+    check_fp32<2, 2, 32>("fp32 128x128 / 32-pixel steps");
+    check_bf16();
+    if (fails) std::printf("%d violation(s)\n", fails);
+    return fails ? 1 : 0;
+}
