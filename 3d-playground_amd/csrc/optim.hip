@@ -51,10 +51,19 @@ __global__ __launch_bounds__(1024) void opt_norm_final_kernel(const double *__re
     }
 }
 
+// Device-resident step counter (hipGraph capture: a replayed launch must not carry the step number as a baked-in kernel
+// argument): one thread increments it, the update kernel derives the bias corrections from it in double, as the host does.
+__global__ void opt_step_inc_kernel(int *__restrict__ step) { step[0] += 1; }
+
 __global__ __launch_bounds__(256) void opt_adam_kernel(const OptTensor *__restrict__ T, const OptChunk *__restrict__ C,
                                                        const float *__restrict__ total_norm, float max_norm, float lr,
                                                        float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                       int write_clipped) {
+                                                       int write_clipped, const int *__restrict__ step_dev) {
+    if (step_dev != nullptr) {                                    // wave-uniform: same value for every thread
+        const int st = step_dev[0];
+        bc1 = (float)(1.0 - pow((double)beta1, (double)st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)st));
+    }
     const OptChunk c = C[blockIdx.x];
     const OptTensor t = T[c.tensor];
     const int64_t base = (int64_t)c.offset_chunks * OPT_CHUNK;
@@ -79,10 +88,32 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const OptTensor *__restri
 
 extern "C" int64_t rn_opt_workspace_bytes(int n_chunks) { return (int64_t)n_chunks * sizeof(double); }
 
+static int opt_clip_adam_impl(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
+                              float beta1, float beta2, float eps, int step, int *step_dev, int write_clipped, void *workspace,
+                              float *total_norm, void *stream);
+
 extern "C" int rn_opt_clip_adam(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
                                 float beta1, float beta2, float eps, int step, int write_clipped, void *workspace,
                                 float *total_norm, void *stream) {
-    if (n_chunks <= 0 || step <= 0) return RN_EINVAL;
+    if (step <= 0) return RN_EINVAL;
+    return opt_clip_adam_impl(tensor_table, chunk_table, n_chunks, max_norm, lr, beta1, beta2, eps, step, nullptr, write_clipped,
+                              workspace, total_norm, stream);
+}
+
+// Same step with the step number kept on the device: *step_dev is incremented first (start it at 0), then used.  No kernel
+// argument changes from step to step, so the launch sequence can be captured once and replayed (hipGraph).
+extern "C" int rn_opt_clip_adam_dev(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
+                                    float beta1, float beta2, float eps, int *step_dev, int write_clipped, void *workspace,
+                                    float *total_norm, void *stream) {
+    if (step_dev == nullptr) return RN_EINVAL;
+    return opt_clip_adam_impl(tensor_table, chunk_table, n_chunks, max_norm, lr, beta1, beta2, eps, 1, step_dev, write_clipped,
+                              workspace, total_norm, stream);
+}
+
+static int opt_clip_adam_impl(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
+                              float beta1, float beta2, float eps, int step, int *step_dev, int write_clipped, void *workspace,
+                              float *total_norm, void *stream) {
+    if (n_chunks <= 0) return RN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const OptTensor *T = reinterpret_cast<const OptTensor *>(tensor_table);
     const OptChunk *C = reinterpret_cast<const OptChunk *>(chunk_table);
@@ -91,9 +122,10 @@ extern "C" int rn_opt_clip_adam(const void *tensor_table, const void *chunk_tabl
         hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, s, T, C, partial);
         hipLaunchKernelGGL(opt_norm_final_kernel, dim3(1), dim3(1024), 0, s, (const double *)partial, n_chunks, total_norm);
     }
+    if (step_dev != nullptr) hipLaunchKernelGGL(opt_step_inc_kernel, dim3(1), dim3(1), 0, s, step_dev);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(opt_adam_kernel, dim3(n_chunks), dim3(256), 0, s, T, C, (const float *)total_norm, max_norm, lr, beta1,
-                       beta2, eps, (float)bc1, (float)sqrt(bc2), write_clipped);
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), write_clipped, (const int *)step_dev);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

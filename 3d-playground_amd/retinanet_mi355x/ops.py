@@ -150,6 +150,8 @@ def check_labels(ann, directional, eager=None):
         return
     if ann.shape[1] == 0:
         raise RuntimeError("stack expects a non-empty TensorList (no labels in the batch)")
+    if ann.is_cuda and torch.cuda.is_current_stream_capturing():
+        return                                          # graph capture: nothing may leave the device; the labels were checked eagerly in the warm-up
     if eager is None:
         eager = os.environ.get("RN_EAGER_LABEL_CHECK", "0") == "1"
     flush_label_checks(block=False)

@@ -51,6 +51,7 @@ class ClipAdam(torch.optim.Optimizer):
         lib = _hip.load()
         self.ws = torch.empty(lib.rn_opt_workspace_bytes(self.n_chunks), dtype=torch.uint8, device=dev)
         self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)    # the step number lives on the device (hipGraph replay)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -71,8 +72,12 @@ class ClipAdam(torch.optim.Optimizer):
             if not g.is_contiguous() or g.dtype != torch.float32:
                 g = p.grad = g.float().contiguous()
             ptrs += (p.data_ptr(), g.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel())
+        capturing = torch.cuda.is_current_stream_capturing()
         tab = self.tables[self.turn]
         if tab["ptrs"] != ptrs:
+            if capturing:
+                raise RuntimeError("ClipAdam.step inside a graph capture needs the pointer table of the warm-up steps: run "
+                                   "a few eager steps with persistent gradients (net.use_flat_gradients()) first")
             tab = self.tables[self.turn ^ 1]
             self.turn ^= 1
             if tab["event"] is not None:
@@ -80,14 +85,15 @@ class ClipAdam(torch.optim.Optimizer):
             tab["host"].copy_(torch.tensor(ptrs, dtype=torch.int64))
             tab["dev"].copy_(tab["host"], non_blocking=True)
             tab["ptrs"] = ptrs
-        self.step_count += 1
-        _hip.check(lib.rn_opt_clip_adam(tab["dev"].data_ptr(), self.chunk_table.data_ptr(), self.n_chunks,
-                                        float(self.max_norm if self.max_norm else 0.0), float(self.param_groups[0]["lr"]),
-                                        float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, 1,
-                                        self.ws.data_ptr(), self.total_norm.data_ptr(), _hip.stream()), "rn_opt_clip_adam")
-        if tab["event"] is None:
-            tab["event"] = torch.cuda.Event()
-        tab["event"].record()
+        self.step_count += 1                          # host mirror (information only; the kernels read step_dev)
+        _hip.check(lib.rn_opt_clip_adam_dev(tab["dev"].data_ptr(), self.chunk_table.data_ptr(), self.n_chunks,
+                                            float(self.max_norm if self.max_norm else 0.0), float(self.param_groups[0]["lr"]),
+                                            float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev.data_ptr(),
+                                            1, self.ws.data_ptr(), self.total_norm.data_ptr(), _hip.stream()), "rn_opt_clip_adam_dev")
+        if not capturing:
+            if tab["event"] is None:
+                tab["event"] = torch.cuda.Event()
+            tab["event"].record()
         # the kernel updated the parameters through raw pointers: bump their version counters so that caches
         # keyed on (data_ptr, _version) -- the engine's packed weights -- see the change
         setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)

@@ -459,6 +459,11 @@ int64_t rn_opt_workspace_bytes(int n_chunks);
 int rn_opt_clip_adam(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
                      float beta1, float beta2, float eps, int step, int write_clipped, void *workspace,
                      float *total_norm, void *stream);
+/* The same step with the step number on the device: *step_dev (int32, start at 0) is incremented, then used for the bias
+ * corrections.  No argument changes between steps: the launch sequence can be captured into a hipGraph and replayed. */
+int rn_opt_clip_adam_dev(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
+                         float beta1, float beta2, float eps, int *step_dev, int write_clipped, void *workspace,
+                         float *total_norm, void *stream);
 
 #ifdef __cplusplus
 }
