@@ -250,6 +250,7 @@ def cpu_baseline(arch, H, W):
         for nt in (threads, 1):
             torch.set_num_threads(nt)
             with torch.no_grad() if "bwd" not in name else torch.enable_grad():
+                fn()                                             # untimed: first-call effects (thread pool, lazy init)
                 t0 = time.time()
                 fn()
                 row.append(round(time.time() - t0, 4))
