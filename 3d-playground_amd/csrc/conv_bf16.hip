@@ -629,7 +629,12 @@ extern "C" int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float 
     const int tiles_m = (Cout + 127) / 128;
     a.tiles_n = (a.Kflat + 127) / 128;
     a.tiles = tiles_m * a.tiles_n;
-    int64_t splits = (2048 + a.tiles - 1) / a.tiles;         // ~2048 workgroups (conv_wgrad.hip), slices >= 512 pixels
+    static const int target_wgs = [] { const char *e = getenv("RN_WGRAD_BF16_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    // K slices for ~768 workgroups = ONE resident round at three per CU.  Every slice ends in tile-sized fp32 atomics
+    // (Cout x Kflat x slices of them per launch, ~1.3 TB/s chip-wide), and with the MFMAs eight times shorter than in the
+    // fp32 kernel that tail weighs more: measured per training step (all weight gradients) 512: 11.6 ms, 768: 11.1,
+    // 1024: 13.5, 1536: 13.2, 2048: 14.6, 3072: 15.2 (the fp32 kernel's optimum is 2048).  RN_WGRAD_BF16_WGS overrides.
+    int64_t splits = (target_wgs + a.tiles - 1) / a.tiles;
     const int64_t max_splits = (a.pixels + 16 * WG_WK - 1) / (16 * WG_WK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
