@@ -33,6 +33,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define BF_BK 32                 // K elements per step = 64 bytes per staged row
+#ifndef BF_NBUF
+#define BF_NBUF 2                // LDS ring depth of the implicit-GEMM kernel (K-steps staged or in flight per workgroup)
+#endif
+#ifndef BF_OCC
+#define BF_OCC 4                 // waves per SIMD the register budget is cut for = workgroups per CU that fit next to the LDS
+#endif
 
 __device__ __forceinline__ int bf_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -83,21 +89,28 @@ extern "C" int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stre
 }
 
 // ---------------------------------------------------------------------------------------------- implicit GEMM
-// One 128 x 128 output tile; 4 waves as 2 x 2, each a 64 x 64 sub-tile = 2 x 2 accumulators of the 32x32x16 MFMA.
+// One (64*WM) x (64*WN) output tile by WM x WN waves, each a 64 x 64 sub-tile = 2 x 2 accumulators of the 32x32x16 MFMA:
+//   <2,2>  128 x 128, 256 threads, four workgroups per CU  -- 64 FLOP per staged byte;
+//   <4,4>  256 x 256, 1024 threads, one workgroup per CU   -- 128 FLOP per staged byte: the per-wave work (8 MFMAs and
+//          8 ds_read_b128 per K-step) is the same, only HALF the bytes come through L2 -> LDS per FLOP, which is what
+//          bounds the small tile (~800 TFLOP/s = 12.5 TB/s of staging against 17-19 TB/s the LDS-DMA path delivers from L2).
+//          Used where the problem has enough 256-tiles to fill the chip (launcher).
 // YF32: the output is written as fp32 (head outputs feeding the loss) instead of bf16; addend and mask are bf16.
-template <bool YF32>
+template <bool YF32, int WM, int WN>
 __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, const __bf16 *__restrict__ x,
                                                      const __bf16 *__restrict__ w, void *__restrict__ yv,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask, const int tile) {
-    constexpr int BM = 128, BN = 128, WN = 2;
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
     constexpr int RF = 16;                                   // floats (4-byte words) per staged row: 64 bytes
     constexpr int RPI = 16;                                  // rows one wave instruction fills (1 KiB / 64 B)
-    constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;      // DMA instructions per wave per K-step and operand
+    constexpr int IA = BM / RPI / NW, IB = BN / RPI / NW;    // DMA instructions per wave per K-step and operand
     constexpr int STEP = (BM + BN) * RF;                     // 4-byte words per buffer: A rows, then B rows
     constexpr int LDT = BN + 4;                              // epilogue: padded fp32 output tile row
-    constexpr int RP = BM / 2;                               // tile rows per epilogue pass (two passes)
-    constexpr int LDSF = 2 * STEP > RP * LDT ? 2 * STEP : RP * LDT;
+    constexpr int RP = NW == 4 ? 64 : 32;                    // tile rows per epilogue pass (a multiple of an MFMA tile's 32)
+    constexpr int NBUF = NW == 4 ? BF_NBUF : 3;              // the one-workgroup-per-CU tile keeps a third K-step in flight (+7 % measured)
+    static_assert(IA >= 1 && IB >= 1 && BM % RP == 0, "tile shape");
+    constexpr int LDSF = NBUF * STEP > RP * LDT ? NBUF * STEP : RP * LDT;
     __shared__ float lds[LDSF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,17 +239,33 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
         }
     };
 
-    // K loop: two LDS buffers, the loads of step ks+1 are issued before the MFMAs of step ks, one barrier per step
-    if (nks > 0) dma_step(0, 0);
-    rn_wait_dma();
+    // K loop over a ring of NBUF LDS buffers: the loads of step ks + NBUF-1 are issued before the MFMAs of step ks, one
+    // barrier per step; the wait in front of the barrier is COUNTED -- everything but the steps issued after ks+1 must have
+    // landed -- so with NBUF > 2 loads stay in flight across barriers.  (A K-step is 8 MFMAs of 32 cycles per wave here
+    // against 32 of 64 in the fp32 kernel: one step of prefetch no longer covers an L2 round trip.)
+    constexpr int NLD = IA + IB;                             // loads one wave issues per K-step
+    auto wait_keep = [&](int steps_in_flight) {              // wave-uniform; vmcnt takes an immediate
+        if (steps_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else if (steps_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLD) : "memory");
+    };
+    static_assert(NBUF >= 2 && NBUF <= 5, "ring depth");
+    const int pre = nks < NBUF - 1 ? nks : NBUF - 1;
+    for (int s_ = 0; s_ < pre; ++s_) dma_step(s_, s_);
+    wait_keep(pre - 1);
     __syncthreads();
+    int rb = 0, wb = NBUF - 1;
     for (int ks = 0; ks < nks; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nks) dma_step(ks + 1, buf ^ 1);
-        multiply(buf);
-        rn_wait_dma();
+        if (ks + NBUF - 1 < nks) dma_step(ks + NBUF - 1, wb);
+        multiply(rb);
+        const int later = nks - 2 - ks;                      // steps issued after ks+1 that may stay in flight
+        wait_keep(later < NBUF - 2 ? later : NBUF - 2);
         __syncthreads();
+        rb = rb == NBUF - 1 ? 0 : rb + 1;
+        wb = wb == NBUF - 1 ? 0 : wb + 1;
     }
+    rn_wait_dma();
 
     // ---- epilogue: v = scale[c]*acc + shift[c]; [mask before add]; v += add; act; [mask after]; one rounding on the store.
     // The accumulator tile goes through LDS (two passes of 64 rows) so that global memory sees whole row segments in
@@ -244,7 +273,7 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
     // are 16-byte loads too; 8-byte accesses run at 0.54-0.70 of the 16-byte rate), 4 for an fp32 result.
     float *T = lds;
     constexpr int CH = YF32 ? 4 : 8;
-    constexpr int CPR = BN / CH, RPP = 256 / CPR;            // chunks per tile row, rows per pass of stores
+    constexpr int CPR = BN / CH, RPP = NT / CPR;             // chunks per tile row, rows per pass of stores
     const int cc = tid % CPR;
     const int col = n0 + CH * cc;
     const bool col_ok = col < d.Cout;                        // Cout % CH == 0 (checked by the launcher)
@@ -265,17 +294,19 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
             bf_load4(p, v);
         }
     };
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+    for (int pass = 0; pass < BM / RP; ++pass) {
         if (pass) __syncthreads();
-        if (wm == pass) {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < 2; ++tm) {
+            const int row0 = wm * 64 + tm * 32;              // this wave's 32-row MFMA tile: staged in the pass that holds it
+            if (row0 / RP == pass) {
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        T[(tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][e];
+                        T[(row0 % RP + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][e];
+            }
         }
         __syncthreads();
         if (!col_ok) continue;
@@ -323,18 +354,18 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
     }
 }
 
-template <bool YF32>
-__global__ __launch_bounds__(256, 4) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
+template <bool YF32, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BF_OCC) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
                                                                  const __bf16 *__restrict__ w, void *__restrict__ yv,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                                  const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask) {
-    conv_igemm_bf16_tile<YF32>(d, x, w, yv, scale, shift, add, mask, bf_xcd_remap(blockIdx.x, gridDim.x));
+    conv_igemm_bf16_tile<YF32, WM, WN>(d, x, w, yv, scale, shift, add, mask, bf_xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch (rn_conv_igemm_grouped's form): up to RN_MAX_GROUP problems sharing weights and epilogue scalars -- the five
 // pyramid levels of a head layer -- as ONE grid; the workgroup looks up its problem by tile id (wave-uniform).
-template <bool YF32>
-__global__ __launch_bounds__(256, 4) void conv_igemm_bf16_grouped_kernel(const rn_conv_group g, const __bf16 *__restrict__ w,
+template <bool YF32, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BF_OCC) void conv_igemm_bf16_grouped_kernel(const rn_conv_group g, const __bf16 *__restrict__ w,
                                                                          const float *__restrict__ scale,
                                                                          const float *__restrict__ shift) {
     const int tile = bf_xcd_remap(blockIdx.x, gridDim.x);
@@ -348,15 +379,15 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_bf16_grouped_kernel(const r
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_igemm_bf16_tile<YF32>(d, reinterpret_cast<const __bf16 *>(x), w, y, scale, shift, reinterpret_cast<const __bf16 *>(add),
-                               reinterpret_cast<const __bf16 *>(mask), tile - first);
+    conv_igemm_bf16_tile<YF32, WM, WN>(d, reinterpret_cast<const __bf16 *>(x), w, y, scale, shift,
+                                       reinterpret_cast<const __bf16 *>(add), reinterpret_cast<const __bf16 *>(mask), tile - first);
 }
 
 static inline int check_desc_bf16(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3)) return RN_EINVAL;   // 16-byte chunks of 8 channels; 16-byte stores
     if ((int64_t)d->Hi * d->Wi * d->Cin * 2 > 0x7fffffffLL) return RN_EINVAL;
-    const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 127 / HoWo + 2;
+    const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 255 / HoWo + 2;    // images a 256-row tile can touch
     if (d->x_batch_stride < 0 || ((span - 1) * d->x_batch_stride + (int64_t)d->Hi * d->Wi * d->Cin) * 2 > 0x7fffffffLL) return RN_EINVAL;
     const int64_t Kpad = ((int64_t)d->kh * d->kw * d->Cin + 31) / 32 * 32;
     if (d->Cout * Kpad * 2 > 0x7fffffffLL || (int64_t)d->N * HoWo > 0x7fffffffLL) return RN_EINVAL;
@@ -378,10 +409,39 @@ static inline int check_ptrs_bf16(const rn_conv_desc *d, const void *x, const vo
     return RN_OK;
 }
 
+// Tile choice: 256 x 256 (one 1024-thread workgroup per CU) when the result is bf16, Cout fills a 256-wide tile and the
+// problem (all problems of a group together) has at least ~one round of 256-tiles for the 256 CUs; else 128 x 128.
+// RN_BF16_BIG_TILE=1 forces it, =2 applies the size rule, unset / 0 = never (A/B measurements).
+// Measured (tools/bench_conv_bf16.py, RN_BF16_BIG_TILE=0 / 1): the big tile wins where the K loop is long -- 3x3 from
+// >= 256 channels: 626 -> 785 (fprop), 777 -> 921 (dgrad), 725 -> 903 TFLOP/s (68x120) -- and loses 15-30 % on the 1x1 layers
+// (short K: the epilogue of a lone 1024-thread workgroup has nothing to overlap with) and on problems with fewer tiles than CUs.
+// In the WHOLE training step, selected by that rule (RN_BF16_BIG_TILE=2), it LOSES: 171.1 against 180.0 images/s with the small
+// tile everywhere (the grouped head launches carry the small pyramid levels in 256-tiles, and a lone workgroup per CU drains
+// its epilogue alone) -- so the kernel stays in the library for A/B runs and the launcher does not pick it.
+static inline bool bf16_big_tile(int64_t rows_total_tiles256, int Cout, int K, int y_is_f32) {
+    static const int force = [] { const char *e = getenv("RN_BF16_BIG_TILE"); return e ? atoi(e) : -1; }();
+    if (y_is_f32 || (Cout & 255) != 0) return false;
+    if (force == 1) return true;
+    if (force == 2) return rows_total_tiles256 >= 224 && K >= 2048;
+    return false;                                                         // default OFF: see below
+}
+static inline bool bf16_tile_is_big(const rn_conv_group *g, int y_is_f32) {
+    int64_t t = 0;
+    for (int i = 0; i < g->n; ++i) t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 255) / 256);
+    return bf16_big_tile(t, g->d[0].Cout, g->d[0].kh * g->d[0].kw * g->d[0].Cin, y_is_f32);
+}
+// Rows (= columns) of the tile rn_conv_igemm_bf16_grouped will use for this group: the caller builds tile_end with it.
+extern "C" int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32) {
+    if (g->n < 1 || g->n > RN_MAX_GROUP) return 0;
+    return bf16_tile_is_big(g, y_is_f32) ? 256 : 128;
+}
+
 extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int y_is_f32, const float *scale,
                                           const float *shift, void *stream) {
     if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const rn_conv_desc &d0 = g->d[0];
+    const bool big = bf16_tile_is_big(g, y_is_f32);          // the caller's tile_end must follow rn_conv_igemm_bf16_tile_rows()
+    const int TR = big ? 256 : 128;
     int prev = 0;
     for (int i = 0; i < g->n; ++i) {
         const rn_conv_desc &d = g->d[i];
@@ -391,14 +451,19 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
         if (rc) return rc;
         if (d.Cin != d0.Cin || d.Cout != d0.Cout || d.kh != d0.kh || d.kw != d0.kw || d.act != d0.act) return RN_EINVAL;
         const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-        const int64_t tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
+        const int64_t tiles = ((M + TR - 1) / TR) * ((d.Cout + TR - 1) / TR);
         if (g->tile_end[i] - prev != tiles) return RN_EINVAL;
         prev = g->tile_end[i];
     }
-    const dim3 grid((unsigned)prev), block(256);
     const __bf16 *wb = reinterpret_cast<const __bf16 *>(w_packed);
-    if (y_is_f32) hipLaunchKernelGGL(conv_igemm_bf16_grouped_kernel<true>, grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
-    else hipLaunchKernelGGL(conv_igemm_bf16_grouped_kernel<false>, grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+    if (big) {
+        const dim3 grid((unsigned)prev), block(1024);
+        hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 4, 4>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+    } else {
+        const dim3 grid((unsigned)prev), block(256);
+        if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<true, 2, 2>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+        else hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 2, 2>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+    }
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -410,13 +475,16 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     const int rp = check_ptrs_bf16(d, x, y, add, mask, y_is_f32);
     if (rp || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-    const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    const bool big = bf16_big_tile(((M + 255) / 256) * ((d->Cout + 255) / 256), d->Cout, d->kh * d->kw * d->Cin, y_is_f32);
+    const int TR = big ? 256 : 128;
+    const int64_t tiles = ((M + TR - 1) / TR) * ((d->Cout + TR - 1) / TR);
     if (tiles > 0x7fffffff) return RN_EINVAL;
-    const dim3 grid((unsigned)tiles), block(256);
+    const dim3 grid((unsigned)tiles), block(big ? 1024 : 256);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(w_packed);
     const __bf16 *ab = reinterpret_cast<const __bf16 *>(add), *mb = reinterpret_cast<const __bf16 *>(mask);
-    if (y_is_f32) hipLaunchKernelGGL(conv_igemm_bf16_kernel<true>, grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
-    else hipLaunchKernelGGL(conv_igemm_bf16_kernel<false>, grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    if (big) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 4, 4>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    else if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_kernel<true, 2, 2>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    else hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -563,10 +563,13 @@ def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_
         d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), (pr.get("mask_mode", 2) if mask is not None else 0),
                        False, None, pr.get("y_batch_stride"), None, None)
         g.d[i] = d
-        M = d.N * d.Ho * d.Wo
-        total += ((M + 127) // 128) * ((d.Cout + 127) // 128)
-        g.tile_end[i] = total
         g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
+    tr = lib.rn_conv_igemm_bf16_tile_rows(ctypes.byref(g), int(yf32))       # 128 or 256: the launcher's tile for this group
+    for i in range(g.n):
+        d = g.d[i]
+        M = d.N * d.Ho * d.Wo
+        total += ((M + tr - 1) // tr) * ((d.Cout + tr - 1) // tr)
+        g.tile_end[i] = total
     kind = "conv_igemm_bf16" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16_grouped(
         ctypes.byref(g), w_packed.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))

@@ -40,10 +40,17 @@ def timeit(fn, iters=10):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="substring of a layer name")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 kernel beside each row (PMC runs)")
+    args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = 8
     print("%-38s %-6s %9s %8s %7s %9s %7s   %s" % ("layer", "op", "ms", "TFLOP/s", "of 2.5P", "GB/s", "of 8T", "fp32 kernel ms (TF)"))
     for name, cin, cout, k, st, pad, H, W in LAYERS:
+        if args.only and args.only not in name:
+            continue
         Ho, Wo = cv.out_size(H, k, st, pad), cv.out_size(W, k, st, pad)
         x32 = torch.randn(B, H, W, cin, device=dev)
         g32 = torch.randn(B, Ho, Wo, cout, device=dev)
@@ -68,7 +75,7 @@ def main():
              lambda: cv.wgrad(g32, x32, dw, cout, k, st, pad)),
         ]
         for op, fn, nbytes, fn32 in rows:
-            ms, ms32 = timeit(fn), timeit(fn32, 5)
+            ms, ms32 = timeit(fn), (float("nan") if args.no_fp32 else timeit(fn32, 5))
             tf, gbs = flops / ms / 1e9, nbytes / ms / 1e6
             print("%-38s %-6s %9.3f %8.1f %6.1f%% %9.0f %6.1f%%   %.3f (%.0f)"
                   % (name, op, ms, tf, 100 * tf / PEAK_BF16, gbs, 100 * gbs / PEAK_HBM, ms32, flops / ms32 / 1e9), flush=True)
