@@ -285,15 +285,6 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
     }
     __bf16 *yb = reinterpret_cast<__bf16 *>(yv);
     float *yf = reinterpret_cast<float *>(yv);
-    auto load_ch = [&](const __bf16 *p, float (&v)[CH]) {
-        if constexpr (CH == 8) {
-            const bf16x8 q = *reinterpret_cast<const bf16x8 *>(p);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
-        } else {
-            bf_load4(p, v);
-        }
-    };
 #pragma unroll 1
     for (int pass = 0; pass < BM / RP; ++pass) {
         if (pass) __syncthreads();
@@ -310,45 +301,60 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
         }
         __syncthreads();
         if (!col_ok) continue;
-        for (int r = tid / CPR; r < RP; r += RPP) {
-            const int64_t m = (int64_t)m0 + pass * RP + r;
-            if (m >= M) break;
-            float v[CH];
+        // The addend / mask operands of ALL rows this lane finishes in the pass are requested first (rows past M re-read
+        // row M-1), then the rows are finished: one memory round trip per pass instead of one per row -- on the 1x1 layers
+        // (a handful of K-steps per tile) the serialised round trips were most of the kernel (conv_igemm_tile.h, same fix).
+        constexpr int NR = RP / RPP;                         // rows per lane per pass
+        constexpr int G = NR % 2 == 0 ? 2 : 1;               // rows per group (more costs registers the K loop needs: spills)
+        typedef __bf16 opv __attribute__((ext_vector_type(CH)));
+#pragma unroll 1
+        for (int g0 = 0; g0 < NR; g0 += G) {
+            int64_t off_[G];
+            opv mk_[G], ad_[G];
 #pragma unroll
-            for (int q = 0; q < CH / 4; ++q) {
-                const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + CH * cc + 4 * q);
-                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            for (int i = 0; i < G; ++i) {
+                const int64_t mr = (int64_t)m0 + pass * RP + tid / CPR + (g0 + i) * RPP;
+                const int64_t m = mr < M ? mr : M - 1;
+                const int n = (int)(m / HoWo);
+                const int rem = (int)(m - (int64_t)n * HoWo);
+                const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
+                const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
+                const int64_t pix = (int64_t)ph * d.Wy + pw;
+                off_[i] = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
+                if (d.mask_mode != 0) mk_[i] = *reinterpret_cast<const opv *>(mask + off_[i]);
+                if (d.add_mode == 1) ad_[i] = *reinterpret_cast<const opv *>(add + (int64_t)n * d.add_batch_stride + pix * d.Cout + col);
+                else if (d.add_mode == 2)                      // nearest x2 upsample, cropped (D/model.py:88-108)
+                    ad_[i] = *reinterpret_cast<const opv *>(add + (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col);
             }
-            const int n = (int)(m / HoWo);
-            const int rem = (int)(m - (int64_t)n * HoWo);
-            const int oh = rem / d.Wo, ow = rem - oh * d.Wo;
-            const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
-            const int64_t pix = (int64_t)ph * d.Wy + pw;
-            const int64_t off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
-            float mk[CH], ad[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { mk[j] = 1.f; ad[j] = 0.f; }
-            if (d.mask_mode != 0) load_ch(mask + off, mk);
-            if (d.add_mode == 1) load_ch(add + (int64_t)n * d.add_batch_stride + pix * d.Cout + col, ad);
-            else if (d.add_mode == 2)                          // nearest x2 upsample, cropped (D/model.py:88-108)
-                load_ch(add + (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col, ad);
+            for (int i = 0; i < G; ++i) {
+                const int r = tid / CPR + (g0 + i) * RPP;
+                if ((int64_t)m0 + pass * RP + r < M) {
+                    float v[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                float u = v[j] * sc[j] + sh[j];
-                if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f;
-                u += ad[j];
-                if (d.act == 1) u = fmaxf(u, 0.f);
-                else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
-                if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f;
-                v[j] = u;
-            }
-            if constexpr (YF32) {
-                *reinterpret_cast<float4 *>(yf + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x8 o;
+                    for (int q = 0; q < CH / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + CH * cc + 4 * q);
+                        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
-                *reinterpret_cast<bf16x8 *>(yb + off) = o;
+                    for (int j = 0; j < CH; ++j) {
+                        float u = v[j] * sc[j] + sh[j];
+                        if (d.mask_mode == 1) u = (float)mk_[i][j] > 0.f ? u : 0.f;
+                        if (d.add_mode != 0) u += (float)ad_[i][j];
+                        if (d.act == 1) u = fmaxf(u, 0.f);
+                        else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
+                        if (d.mask_mode == 2) u = (float)mk_[i][j] > 0.f ? u : 0.f;
+                        v[j] = u;
+                    }
+                    if constexpr (YF32) {
+                        *reinterpret_cast<float4 *>(yf + off_[i]) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        bf16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+                        *reinterpret_cast<bf16x8 *>(yb + off_[i]) = o;
+                    }
+                }
             }
         }
     }
