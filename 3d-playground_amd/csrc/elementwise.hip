@@ -139,6 +139,10 @@ __global__ __launch_bounds__(256) void prep_batched_kernel(const rn_prep_job *__
         return;
     }
     if (i >= (int64_t)j.rows * j.Kpad) return;
+    if (j.kind == 3) {                                       // bf16 copy of an already packed fp32 buffer (conv_bf16.hip): src -> dst
+        reinterpret_cast<__bf16 *>(j.dst)[i] = (__bf16)j.src[i];
+        return;
+    }
     if (j.kind == 2) {                                       // Winograd weight transform U = G g G^T (conv_wino.hip), mode 0 / 1
         const int row = (int)(i / j.Kpad), k = (int)(i - (int64_t)row * j.Kpad);
         const int kdim = j.mode == 0 ? j.Cin : j.Cout;

@@ -73,7 +73,7 @@ class Layer:
         self.wd16 = None
         self.wf16 = cache.get(("wf16", s.name), w, lambda: cv.to_bf16(self.wf)) if self.bf16 else None
 
-    def adopt(self, P, cache, wf, bn, wd, wino=None):
+    def adopt(self, P, cache, wf, bn, wd, wino=None, wf16=None, wd16=None):
         """Training step: take this step's packed weights / folded batch norm from the engine's batched preparation
         (persistent buffers refreshed by two launches for the whole net) instead of one launch per tensor."""
         s = self.spec
@@ -89,8 +89,8 @@ class Layer:
         self.wd = wd                                  # None: packed on demand (layers that normally take the Winograd path)
         self.dw = self.cs = None
         self.uf, self.ud = wino if wino is not None else (None, None)
-        self.wd16 = None
-        self.wf16 = cv.to_bf16(self.wf) if self.bf16 else None
+        self.wd16 = wd16                              # bf16 twins from the batched preparation (launch 2), else on demand
+        self.wf16 = wf16 if wf16 is not None else (cv.to_bf16(self.wf) if self.bf16 else None)
 
     def wino_weights(self, mode):
         """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
@@ -449,12 +449,21 @@ class Engine:
             _hip.check(lib.rn_prep_batched(jobs.data_ptr(), chunks.data_ptr(), n, _hip.stream()), "rn_prep_batched")
         for name, L in self.layers.items():
             b = prep["bufs"][name]
-            L.adopt(P, self.cache, b["wf"], b.get("bn"), b.get("wd"), b.get("wino"))
+            L.adopt(P, self.cache, b["wf"], b.get("bn"), b.get("wd"), b.get("wino"), wf16=b.get("wf16"), wd16=b.get("wd16"))
 
     def _build_prep(self, P, key):
         dev = next(iter(P.values())).device
-        launches = [([], []), ([], [])]               # (jobs, chunks) of launch 0 (folds + forward packs) and 1 (dgrad packs)
-        bufs = {}
+        launches = [([], []), ([], []), ([], [])]     # (jobs, chunks) of launch 0 (folds + forward packs), 1 (dgrad packs) and
+        bufs = {}                                     # 2 (bf16 mode: the bf16 copies of all of them)
+
+        def cast_job(src):
+            """bf16 mode: a bf16 twin of a packed fp32 buffer, filled by launch 2."""
+            dst = torch.empty(src.shape, dtype=torch.bfloat16, device=dev)
+            j = _hip.PrepJob()
+            j.kind, j.rows, j.Kpad = 3, src.shape[0], src.shape[1]
+            j.src, j.dst = src.data_ptr(), dst.data_ptr()
+            add(2, j, src.numel())
+            return dst
 
         def add(which, job, nelem):
             jobs, chunks = launches[which]
@@ -478,6 +487,8 @@ class Engine:
             b = bufs[name] = {}
             b["wf"] = torch.empty((cout, (kh * L.kw_pad * L.cin_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
             add(0, pack_job(w, b["wf"], 0, L.kw_pad, L.cin_pad, None), b["wf"].numel())
+            if L.bf16:
+                b["wf16"] = cast_job(b["wf"])
             scale = None
             if s.bn:
                 bn = b["bn"] = torch.empty((3, cout), dtype=torch.float32, device=dev)
@@ -508,11 +519,17 @@ class Engine:
                     d = torch.empty((cin, (nr * ns * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
                     add(1, pack_job(w, d, 2, kw, L.cout_pad, scale, c[2]), d.numel())
                     b["wd"].append(d)
+                if L.bf16:
+                    b["wd16"] = [cast_job(d) for d in b["wd"]]
             else:
                 d = b["wd"] = torch.empty((cin, (kh * kw * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
                 add(1, pack_job(w, d, 1, kw, L.cout_pad, scale), d.numel())
+                if L.bf16:
+                    b["wd16"] = cast_job(d)
         out = []
         for jobs, chunks in launches:
+            if not jobs:
+                continue
             arr = (_hip.PrepJob * len(jobs))(*jobs)
             jt = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             ct = torch.tensor(chunks, dtype=torch.int32).to(dev)

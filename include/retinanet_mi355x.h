@@ -386,7 +386,8 @@ int rn_wino_dw(const float *dU, float *dw, int Cout, int Cin, void *stream);
 
 /* Batched per-step preparation: batch-norm folding (kind 0: bn_scale = gamma / sqrt(var + eps), bn_shift = beta - mean *
  * bn_scale, bn_rstd), weight packing (kind 1: the arguments of rn_pack_weights, rows / Kpad as it derives them) and
- * Winograd weight transforms (kind 2: the arguments of rn_wino_weights, dst [36][rows][Kpad]) for many layers in one launch.  jobs_dev: device array of rn_prep_job; chunks_dev: device array of nchunks (job index,
+ * Winograd weight transforms (kind 2: the arguments of rn_wino_weights, dst [36][rows][Kpad]) and bf16 copies of packed
+ * buffers (kind 3: rows * Kpad floats at src -> bf16 at dst; a launch AFTER the one that packs src) for many layers in one launch.  jobs_dev: device array of rn_prep_job; chunks_dev: device array of nchunks (job index,
  * 256-element block inside the job) pairs.  Jobs of one launch must not depend on each other: the data-gradient packs
  * (which read bn_scale) go in a second launch. */
 typedef struct rn_prep_job {
