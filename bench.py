@@ -373,7 +373,9 @@ def main():
     value = world * B * args.steps / dt
 
     if rank == 0:
-        line = {"metric": "training images/sec at 1920x1080, ResNet-50 3D-RetinaNet", "value": round(value, 3),
+        arch_label = {"resnet50": "ResNet-50", "resnet101": "ResNet-101", "resnet152": "ResNet-152", "resnet18": "ResNet-18",
+                      "resnet34": "ResNet-34"}.get(args.arch, args.arch)
+        line = {"metric": "training images/sec at %dx%d, %s 3D-RetinaNet" % (W, H, arch_label), "value": round(value, 3),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
