@@ -452,6 +452,7 @@ def main():
             for b in tl["buckets"]:
                 print("  bucket %(bucket)d  %(mbytes)6.1f MB  gradients final %(ready_gpu_ms)8.2f (GPU)  all-reduce issued "
                       "%(launch_host_ms)8.2f  done %(done_host_ms)8.2f (host)" % b, file=sys.stderr)
+        dist.barrier()                                            # rank 0 arrives last (it measured the extra kernels alone)
         dist.destroy_process_group()
 
 
