@@ -27,9 +27,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
             off = m * d.Cout + col; \
             if (d.add_mode == 1) aoff = off; \
         } else { \
-            const int n = (int)(m / HoWo); \
-            const int rem = (int)(m - (int64_t)n * HoWo); \
-            const int oh = rem / d.Wo, ow = rem - oh * d.Wo; \
+            /* m < N*Ho*Wo < 2^31 (check_desc): 32-bit unsigned divisions -- a 64-bit one is ~100 VALU instructions, per row */ \
+            const unsigned mu_ = (unsigned)m; \
+            const int n = (int)(mu_ / (unsigned)HoWo); \
+            const int rem = (int)(mu_ - (unsigned)n * (unsigned)HoWo); \
+            const int oh = (int)((unsigned)rem / (unsigned)d.Wo), ow = rem - oh * d.Wo; \
             const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w; \
             const int64_t pix = (int64_t)ph * d.Wy + pw; \
             off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col; \
