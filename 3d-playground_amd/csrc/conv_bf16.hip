@@ -96,12 +96,13 @@ extern "C" int rn_bf16_to_f32(const void *src, float *dst, int64_t n, void *stre
 //          bounds the small tile (~800 TFLOP/s = 12.5 TB/s of staging against 17-19 TB/s the LDS-DMA path delivers from L2).
 //          Used where the problem has enough 256-tiles to fill the chip (launcher).
 // YF32: the output is written as fp32 (head outputs feeding the loss) instead of bf16; addend and mask are bf16.
-template <bool YF32, int WM, int WN, bool DENSE>
+template <bool YF32, int WM, int WN, bool DENSE, int TM = 2>
 __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, const __bf16 *__restrict__ x,
                                                      const __bf16 *__restrict__ w, void *__restrict__ yv,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask, const int tile) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    constexpr int TN = 2;                                    // 32-wide MFMA tiles per wave along N; TM along M (2: 64 rows, 4: 128 rows)
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN, NT = 64 * NW;
     constexpr int RF = 16;                                   // floats (4-byte words) per staged row: 64 bytes
     constexpr int RPI = 16;                                  // rows one wave instruction fills (1 KiB / 64 B)
     constexpr int IA = BM / RPI / NW, IB = BN / RPI / NW;    // DMA instructions per wave per K-step and operand
@@ -205,37 +206,44 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment addresses (4-byte words within a buffer): row = lane & 31 of each 32-row MFMA tile, logical chunk
     // 2*st + (lane >> 5) of sub-step st, at its swizzled position
-    int fa[2][2], fb[2][2];
+    int fa[TM][2], fb[TN][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int st = 0; st < 2; ++st) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+        for (int t = 0; t < TM; ++t) {
+            const int ra = wm * (32 * TM) + t * 32 + (lane & 31);
             fa[t][st] = ra * RF + 4 * ((2 * st + (lane >> 5)) ^ bf_swz(ra));
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int rb = wn * (32 * TN) + t * 32 + (lane & 31);
             fb[t][st] = BM * RF + rb * RF + 4 * ((2 * st + (lane >> 5)) ^ bf_swz(rb));
         }
+    }
     auto multiply = [&](int buf) {
         const float *S = lds + buf * STEP;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(S + fa[0][st]);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(S + fa[1][st]);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(S + fb[0][st]);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(S + fb[1][st]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(S + fa[t][st]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(S + fb[t][st]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
     };
 
@@ -272,9 +280,9 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
     if (BF_ABL == 1) {                                       // keep the accumulators alive, store next to nothing
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) t += acc[i][j][0] + acc[i][j][15];
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][15];
         if (t == 1.2345e-30f) reinterpret_cast<float *>(yv)[0] = t;
         return;
     }
@@ -303,14 +311,14 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
     for (int pass = 0; pass < BM / RP; ++pass) {
         if (pass) __syncthreads();
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int row0 = wm * 64 + tm * 32;              // this wave's 32-row MFMA tile: staged in the pass that holds it
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row0 = wm * (32 * TM) + tm * 32;       // this wave's 32-row MFMA tile: staged in the pass that holds it
             if (row0 / RP == pass) {
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        T[(row0 % RP + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][e];
+                        T[(row0 % RP + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * (32 * TN) + tn * 32 + (lane & 31)] = acc[tm][tn][e];
             }
         }
         __syncthreads();
@@ -381,12 +389,12 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
     }
 }
 
-template <bool YF32, int WM, int WN, bool DENSE>
-__global__ __launch_bounds__(64 * WM * WN, BF_OCC) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
+template <bool YF32, int WM, int WN, bool DENSE, int TM = 2>
+__global__ __launch_bounds__(64 * WM * WN, TM == 4 ? 2 : BF_OCC) void conv_igemm_bf16_kernel(const rn_conv_desc d, const __bf16 *__restrict__ x,
                                                                  const __bf16 *__restrict__ w, void *__restrict__ yv,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                                  const __bf16 *__restrict__ add, const __bf16 *__restrict__ mask) {
-    conv_igemm_bf16_tile<YF32, WM, WN, DENSE>(d, x, w, yv, scale, shift, add, mask, bf_xcd_remap(blockIdx.x, gridDim.x));
+    conv_igemm_bf16_tile<YF32, WM, WN, DENSE, TM>(d, x, w, yv, scale, shift, add, mask, bf_xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch (rn_conv_igemm_grouped's form): up to RN_MAX_GROUP problems sharing weights and epilogue scalars -- the five
@@ -512,13 +520,20 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     if (rp || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     const bool big = bf16_big_tile(((M + 255) / 256) * ((d->Cout + 255) / 256), d->Cout, d->kh * d->kw * d->Cin, y_is_f32);
-    const int TR = big ? 256 : 128;
-    const int64_t tiles = ((M + TR - 1) / TR) * ((d->Cout + TR - 1) / TR);
+    // 256 x 128 tile (4 waves of 128 x 64, two workgroups per CU): 85 FLOP per staged byte instead of 64, for dense bf16
+    // results with a long K loop and enough tiles (RN_BF16_TALL_TILE=0 turns it off, =1 forces it where it is legal)
+    static const int tall_env = [] { const char *e = getenv("RN_BF16_TALL_TILE"); return e ? atoi(e) : -1; }();
+    const int64_t tall_tiles = ((M + 255) / 256) * ((d->Cout + 127) / 128);
+    const bool tall_ok = !big && !y_is_f32 && bf16_desc_is_dense(d) && (d->Cout & 127) == 0;
+    const bool tall = tall_ok && (tall_env == 1 || (tall_env != 0 && d->kh * d->kw * d->Cin >= 1024 && tall_tiles >= 512));
+    const int TR = big ? 256 : 128, TRM = (big || tall) ? 256 : 128;
+    const int64_t tiles = ((M + TRM - 1) / TRM) * ((d->Cout + TR - 1) / TR);
     if (tiles > 0x7fffffff) return RN_EINVAL;
     const dim3 grid((unsigned)tiles), block(big ? 1024 : 256);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(w_packed);
     const __bf16 *ab = reinterpret_cast<const __bf16 *>(add), *mb = reinterpret_cast<const __bf16 *>(mask);
     if (big) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 4, 4, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    else if (tall) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true, 4>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_kernel<true, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (bf16_desc_is_dense(d)) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
