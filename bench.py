@@ -440,9 +440,15 @@ def main():
         if world == 1 and args.dtype == "fp32" and timer is not None:
             del net, opt, params
             torch.cuda.empty_cache()
-            line["bf16"] = bf16_section(dev, args, B, H, W)
+            try:                                                    # supplementary sections never cost the headline its line
+                line["bf16"] = bf16_section(dev, args, B, H, W)
+            except Exception as e:
+                line["bf16"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": str(e)[:300]}
         print(json.dumps(line), flush=True)
     if world > 1:
         if args.ddp_timeline and rank == 0:
