@@ -399,8 +399,8 @@ __global__ __launch_bounds__(64 * WM * WN, TM == 4 ? 2 : BF_OCC) void conv_igemm
 
 // Grouped launch (rn_conv_igemm_grouped's form): up to RN_MAX_GROUP problems sharing weights and epilogue scalars -- the five
 // pyramid levels of a head layer -- as ONE grid; the workgroup looks up its problem by tile id (wave-uniform).
-template <bool YF32, int WM, int WN, bool DENSE>
-__global__ __launch_bounds__(64 * WM * WN, BF_OCC) void conv_igemm_bf16_grouped_kernel(const rn_conv_group g, const __bf16 *__restrict__ w,
+template <bool YF32, int WM, int WN, bool DENSE, int TM = 2>
+__global__ __launch_bounds__(64 * WM * WN, TM == 4 ? 2 : BF_OCC) void conv_igemm_bf16_grouped_kernel(const rn_conv_group g, const __bf16 *__restrict__ w,
                                                                          const float *__restrict__ scale,
                                                                          const float *__restrict__ shift) {
     const int tile = bf_xcd_remap(blockIdx.x, gridDim.x);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, BF_OCC) void conv_igemm_bf16_grouped_
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_igemm_bf16_tile<YF32, WM, WN, DENSE>(d, reinterpret_cast<const __bf16 *>(x), w, y, scale, shift,
+    conv_igemm_bf16_tile<YF32, WM, WN, DENSE, TM>(d, reinterpret_cast<const __bf16 *>(x), w, y, scale, shift,
                                        reinterpret_cast<const __bf16 *>(add), reinterpret_cast<const __bf16 *>(mask), tile - first);
 }
 
@@ -471,10 +471,24 @@ static inline bool bf16_tile_is_big(const rn_conv_group *g, int y_is_f32) {
     for (int i = 0; i < g->n; ++i) t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 255) / 256);
     return bf16_big_tile(t, g->d[0].Cout, g->d[0].kh * g->d[0].kw * g->d[0].Cin, y_is_f32);
 }
-// Rows (= columns) of the tile rn_conv_igemm_bf16_grouped will use for this group: the caller builds tile_end with it.
+// 256 x 128 tile for a group: dense bf16 results, Cout a multiple of 128, a long K loop and enough tiles (see the single launcher)
+static inline bool bf16_group_is_tall(const rn_conv_group *g, int y_is_f32) {
+    static const int tall_env = [] { const char *e = getenv("RN_BF16_TALL_TILE"); return e ? atoi(e) : -1; }();
+    if (y_is_f32 || tall_env == 0 || bf16_tile_is_big(g, y_is_f32) || (g->d[0].Cout & 127) != 0) return false;
+    int64_t t = 0;
+    for (int i = 0; i < g->n; ++i) {
+        if (!bf16_desc_is_dense(&g->d[i])) return false;
+        t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 127) / 128);
+    }
+    return tall_env == 1 || (g->d[0].kh * g->d[0].kw * g->d[0].Cin >= 1024 && t >= 512);
+}
+// Tile shape rn_conv_igemm_bf16_grouped will use for this group: the caller builds tile_end with it
+// (tile_end[i] = running sum of ceil(N*Ho*Wo / rows) * ceil(Cout / cols)).  Returns rows * 1000 + cols.
 extern "C" int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32) {
     if (g->n < 1 || g->n > RN_MAX_GROUP) return 0;
-    return bf16_tile_is_big(g, y_is_f32) ? 256 : 128;
+    if (bf16_tile_is_big(g, y_is_f32)) return 256 * 1000 + 256;
+    if (bf16_group_is_tall(g, y_is_f32)) return 256 * 1000 + 128;
+    return 128 * 1000 + 128;
 }
 
 extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int y_is_f32, const float *scale,
@@ -482,7 +496,8 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
     if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const rn_conv_desc &d0 = g->d[0];
     const bool big = bf16_tile_is_big(g, y_is_f32);          // the caller's tile_end must follow rn_conv_igemm_bf16_tile_rows()
-    const int TR = big ? 256 : 128;
+    const bool tall = bf16_group_is_tall(g, y_is_f32);
+    const int TR = big ? 256 : 128, TRM = (big || tall) ? 256 : 128;
     int prev = 0;
     for (int i = 0; i < g->n; ++i) {
         const rn_conv_desc &d = g->d[i];
@@ -492,7 +507,7 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
         if (rc) return rc;
         if (d.Cin != d0.Cin || d.Cout != d0.Cout || d.kh != d0.kh || d.kw != d0.kw || d.act != d0.act) return RN_EINVAL;
         const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-        const int64_t tiles = ((M + TR - 1) / TR) * ((d.Cout + TR - 1) / TR);
+        const int64_t tiles = ((M + TRM - 1) / TRM) * ((d.Cout + TR - 1) / TR);
         if (g->tile_end[i] - prev != tiles) return RN_EINVAL;
         prev = g->tile_end[i];
     }
@@ -505,6 +520,7 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
     } else {
         const dim3 grid((unsigned)prev), block(256);
         if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<true, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
+        else if (tall) hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 2, 2, true, 4>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
         else if (dense) hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 2, 2, true>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
         else hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
     }

@@ -564,11 +564,11 @@ def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_
                        False, None, pr.get("y_batch_stride"), None, None)
         g.d[i] = d
         g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
-    tr = lib.rn_conv_igemm_bf16_tile_rows(ctypes.byref(g), int(yf32))       # 128 or 256: the launcher's tile for this group
+    trm, trn = divmod(lib.rn_conv_igemm_bf16_tile_rows(ctypes.byref(g), int(yf32)), 1000)   # the launcher's tile for this group
     for i in range(g.n):
         d = g.d[i]
         M = d.N * d.Ho * d.Wo
-        total += ((M + tr - 1) // tr) * ((d.Cout + tr - 1) // tr)
+        total += ((M + trm - 1) // trm) * ((d.Cout + trn - 1) // trn)
         g.tile_end[i] = total
     kind = "conv_igemm_bf16" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16_grouped(

@@ -324,8 +324,9 @@ int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const void *w_packe
 /* Grouped form (see rn_conv_igemm_grouped): the pointers of rn_conv_group are bf16 (x, add, mask) / bf16 or fp32 (y). */
 int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int y_is_f32, const float *scale,
                                const float *shift, void *stream);
-/* Tile edge (128 or 256) the grouped bf16 launcher uses for this group -- tile_end[i] = running sum of
- * ceil(N*Ho*Wo / edge) * ceil(Cout / edge).  (tile_end is ignored on input by this query; d[] and n must be filled.) */
+/* Tile shape the grouped bf16 launcher uses for this group, as rows * 1000 + cols (128128, 256128 or 256256) --
+ * tile_end[i] = running sum of ceil(N*Ho*Wo / rows) * ceil(Cout / cols).  (tile_end is ignored on input by this query;
+ * d[], the pointers and n must be filled.) */
 int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32);
 /* dw[co][r][s][ci] (fp32, packed [Cout][Kpad] like rn_conv_wgrad, atomically accumulated) from bf16 dy [N,Ho,Wo,ldy>=Cout]
  * and bf16 x [N,Hi,Wi,Cin]; colsum (may be NULL) += column sums of dy.  Cin % 8 == 0, ldy % 8 == 0. */
