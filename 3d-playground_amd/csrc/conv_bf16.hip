@@ -567,6 +567,7 @@ struct WgradBf16Args {
     int ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad;
     int Kflat, Kpad;             // kh*kw*Cin and its round-up to 32
     int tiles_n, tiles, splits;
+    int xcd_map;                 // 1: whole K slices per XCD (the kernel)
     int64_t pixels, per_split;   // K extent and K per slice (multiple of 32)
 };
 
@@ -600,7 +601,20 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int slice = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
+    // Workgroup id -> (tile, K slice).  Ids are dealt round-robin to the 8 XCDs; all tiles of a slice stream the same dY / X
+    // slabs, so a slice is kept on ONE XCD (slice s on XCD s % 8, its tiles consecutive there): the slabs come through that
+    // L2 once instead of through all eight.  Without it the PMC counters showed an L2 hit rate of 39 % and 5.5x the
+    // algorithmic bytes fetched (profiles/r02_pmc_conv_bf16.txt); conv_wgrad.hip does the same for its many-tile shapes.
+    int slice, tile;
+    if (p.xcd_map) {
+        const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+        slice = (wi / p.tiles) * 8 + xcd;
+        tile = wi % p.tiles;
+    } else {
+        slice = blockIdx.x / p.tiles;
+        tile = blockIdx.x % p.tiles;
+    }
+    if (slice >= p.splits) return;                           // padding of the last group of 8 slices
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int64_t kbeg = (int64_t)slice * p.per_split;
     const int64_t kend = (kbeg + p.per_split < p.pixels) ? kbeg + p.per_split : p.pixels;
@@ -785,7 +799,10 @@ extern "C" int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float 
     }
     splits = (a.pixels + a.per_split - 1) / a.per_split;
     a.splits = (int)splits;
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(a.tiles * splits)), dim3(256), 0, (hipStream_t)stream, a);
+    static const int xcd_env = [] { const char *e = getenv("RN_WGRAD_BF16_XCD"); return e ? atoi(e) : 1; }();
+    a.xcd_map = xcd_env != 0 && a.tiles >= 4 && splits >= 8;
+    const int64_t grid_slices = a.xcd_map ? (splits + 7) / 8 * 8 : splits;
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(a.tiles * grid_slices)), dim3(256), 0, (hipStream_t)stream, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
