@@ -61,9 +61,12 @@ def main():
     ap.add_argument("--cams", type=int, default=18)
     ap.add_argument("--batch", type=int, default=3, help="cameras per detector call (18 cameras over 8 GPUs: 2-3 each)")
     ap.add_argument("--iters", type=int, default=5, help="time steps (one frame from every camera each)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: DESIGN.md 4.5 (opt-in, not the reference's arithmetic)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     net = detector(dev)
+    if args.dtype == "bf16":
+        net.set_compute_dtype("bf16")
     names = ["p%dc%d" % (p, c) for p in (1, 2, 3) for c in range(1, 7)][:args.cams]
     me = tracker(dev, names)
     g = torch.Generator().manual_seed(7)
@@ -112,7 +115,7 @@ def main():
             kept, parsed = kept + a, parsed + b
         return kept, parsed
 
-    print("%d cameras, %d per call, ResNet-50, %dx%d uint8 frames from pinned host memory" % (args.cams, args.batch, W, H))
+    print("%d cameras, %d per call, ResNet-50 (%s), %dx%d uint8 frames from pinned host memory" % (args.cams, args.batch, args.dtype, W, H))
     for label, pipelined in (("one stream (upload, then detect)", False), ("two streams (upload k+1 under detect k)", True)):
         time_step(pipelined)
         torch.cuda.synchronize()
