@@ -63,6 +63,13 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_grouped_kernel(const rn_con
     conv_igemm_tile<WM, WN, true, BK>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
+// conv_igemm_split.hip: the same instances with split-operand products
+int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, const float *x, const float *w, float *y,
+                          const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
+                          hipStream_t s);
+int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_group *g, const float *w, const float *scale,
+                                  const float *shift, hipStream_t s);
+
 extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_packed, const float *scale, const float *shift,
                                      void *stream) {
     if (g->n < 1 || g->n > RN_MAX_GROUP) return RN_EINVAL;
@@ -83,6 +90,7 @@ extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_pack
     }
     const dim3 grid((unsigned)prev), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (rn_get_fp32_mfma() == RN_FP32_SPLIT) return rn_igemm_split_grouped_launch(narrow, (unsigned)prev, g, w_packed, scale, shift, s);
     if (narrow) hipLaunchKernelGGL((conv_igemm_grouped_kernel<4, 1, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
     else hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
     RN_LAUNCH_CHECK();
@@ -111,6 +119,9 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     // K-step 16 (34-41 KB of LDS, four workgroups per CU) everywhere: with the operands arriving by direct-to-LDS loads it
     // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
     const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0;
+    if (rn_get_fp32_mfma() == RN_FP32_SPLIT)
+        return rn_igemm_split_launch(raw ? 0 : (d->in_relu ? 1 : (narrow ? (dense ? 2 : 3) : (dense ? 4 : 5))), (unsigned)tiles, d, x,
+                                     w_packed, y, scale, shift, add, mask, add2, s);
     if (raw) {                                                           // a plain GEMM: the Winograd stage
         hipLaunchKernelGGL((conv_igemm_kernel<2, 2, false, 16, false, true>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2);
     } else if (d->in_relu) {

@@ -1,0 +1,66 @@
+// The implicit-GEMM convolution with split-operand products (mfma_split.h): the tile of conv_igemm_tile.h with its eight
+// v_mfma_f32_32x32x2_f32 per 32x32x16 block replaced by six v_mfma_f32_32x32x16_bf16 on (h, m, l) splits of the fp32
+// fragments.  Same descriptors, same packed fp32 weights, same staging and epilogue as conv_igemm.hip, whose launchers
+// choose between the two (rn_fp32_split()).  Kept in its own translation unit: every instance of the force-inlined tile
+// costs compile time and memory.
+//
+// Register budget: the fragments (32 floats), their splits (48 registers) and the 64 accumulators do not fit the 128
+// registers four workgroups per CU leave, so these kernels run three per CU (168 registers, 34-41 KB of LDS each).
+#include "conv_igemm_tile.h"
+
+template <int WM, int WN, bool GENERAL, bool RELU, bool RAW>
+__global__ __launch_bounds__(256, 3) void conv_igemm_split_kernel(const rn_conv_desc d, const float *__restrict__ x,
+                                                                  const float *__restrict__ w, float *__restrict__ y,
+                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                  const float *__restrict__ add, const float *__restrict__ mask,
+                                                                  const float *__restrict__ add2) {
+    conv_igemm_tile<WM, WN, GENERAL, 16, RELU, RAW, true>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 3) void conv_igemm_split_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
+                                                                          const float *__restrict__ scale,
+                                                                          const float *__restrict__ shift) {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    rn_conv_desc d = g.d[0];
+    const float *x = g.x[0], *add = g.add[0], *mask = g.mask[0];
+    float *y = g.y[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
+    conv_igemm_tile<WM, WN, true, 16, false, false, true>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+}
+
+// variant: the instance conv_igemm.hip's launcher chose -- 0 raw GEMM, 1 input ReLU, 2 / 3 narrow dense / general,
+// 4 / 5 wide dense / general
+int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, const float *x, const float *w, float *y,
+                          const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
+                          hipStream_t s) {
+    const dim3 grid(tiles), block(256);
+#define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW) \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
+    switch (variant) {
+        case 0: RN_SPLIT_LAUNCH(2, 2, false, false, true); break;
+        case 1: RN_SPLIT_LAUNCH(2, 2, true, true, false); break;
+        case 2: RN_SPLIT_LAUNCH(4, 1, false, false, false); break;
+        case 3: RN_SPLIT_LAUNCH(4, 1, true, false, false); break;
+        case 4: RN_SPLIT_LAUNCH(2, 2, false, false, false); break;
+        case 5: RN_SPLIT_LAUNCH(2, 2, true, false, false); break;
+        default: return RN_EINVAL;
+    }
+#undef RN_SPLIT_LAUNCH
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_group *g, const float *w, const float *scale,
+                                  const float *shift, hipStream_t s) {
+    if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    else hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "mfma_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -96,7 +97,9 @@ __device__ __forceinline__ int lds_swz(int row) {
     return BK == 32 ? ((row & 7) ^ ((row >> 3) & 7)) : ((row >> 2) & 3);
 }
 
-template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false>
+// SPLIT: the products go through the bf16 matrix cores as six split-operand MFMAs per 32x32x16 block (mfma_split.h) instead
+// of eight v_mfma_f32_32x32x2_f32; staging, fragment reads and epilogue are the same code.
+template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false, bool SPLIT = false>
 __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const float *__restrict__ x,
                                                 const float *__restrict__ w, float *__restrict__ y,
                                                 const float *__restrict__ scale, const float *__restrict__ shift,
@@ -245,6 +248,29 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         }
     auto multiply = [&](int buf) {
         const float *S = lds + buf * STEP;
+        if constexpr (SPLIT) {
+            // a lane's eight k of a 16-wide step: chunks g and 2 + g of its row (g = lane >> 5), the same for A and B
+            static_assert(!SPLIT || BK == 16, "split-operand form: K-step 16");
+            Split8 sa[2], sb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][0]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][1]);
+                const float4 q0 = *reinterpret_cast<const float4 *>(S + fb[t][0]), q1 = *reinterpret_cast<const float4 *>(S + fb[t][1]);
+                float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                const float bv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                if (RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                }
+                sa[t] = split8(av);
+                sb[t] = split8(bv);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+            return;
+        }
 #pragma unroll
         for (int st = 0; st < BK / 8; ++st) {
             float4 a0 = *reinterpret_cast<const float4 *>(S + fa[0][st]);

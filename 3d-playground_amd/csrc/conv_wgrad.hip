@@ -38,6 +38,7 @@
 
 #include "common.h"
 #include "conv_wgrad_geom.h"
+#include "mfma_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WK_MAX 32                // pixels per K-step: 32 or 16 (the kernel's WK parameter)
@@ -58,8 +59,11 @@ struct WgradArgs {
 };
 
 // WK pixels per K-step, OCC workgroups per CU the register budget is cut for (LDS: 2 * WK * (BM + BN) * 4 + 8 KiB).
-template <int WM, int WN, bool RELU, int WK, int OCC>
+// SPLIT: split-operand products (mfma_split.h): the 16 pixels of a K-step are one v_mfma_f32_32x32x16_bf16 k extent, a lane's
+// eight of them are the ones it reads anyway (pixels 2j + (lane >> 5)), for both operands.
+template <int WM, int WN, bool RELU, int WK, int OCC, bool SPLIT = false>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p) {
+    static_assert(!SPLIT || WK == 16, "split-operand form: 16-pixel K-steps");
     using G = WgradGeom<WM, WN, WK>;                         // index arithmetic shared with the host-side range check
     constexpr int BM = G::BM, BN = G::BN;
     constexpr int TB = G::TB;                                // K-steps per pixel-table batch: one entry per thread
@@ -205,6 +209,28 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
             table_read(ks + 2 < nks ? ks + 2 : nks - 1);      // its batch was published by an earlier barrier (see below)
             const float *A = lds[buf] + fa0;
             const float *B = lds[buf] + WK * BM + fb0;
+            if constexpr (SPLIT) {
+                float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+                for (int kp = 0; kp < 8; ++kp) {
+                    const float2 va = *reinterpret_cast<const float2 *>(A + 2 * kp * BM);
+                    float2 vb = make_float2(B[2 * kp * BN], B[2 * kp * BN + 32]);
+                    if (RELU) { vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); }
+                    if (CS) { cs.x += va.x; cs.y += va.y; }
+                    a0[kp] = va.x; a1[kp] = va.y; b0[kp] = vb.x; b1[kp] = vb.y;
+                }
+                const Split8 sa0 = split8(a0), sb0 = split8(b0), sb1 = split8(b1);
+                RN_SPLIT_MFMA(acc[0][0], sa0, sb0);
+                const Split8 sa1 = split8(a1);
+                RN_SPLIT_MFMA(acc[0][1], sa0, sb1);
+                make_offsets();                               // step ks+2 (see the fp32 form below)
+                if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
+                RN_SPLIT_MFMA(acc[1][0], sa1, sb0);
+                RN_SPLIT_MFMA(acc[1][1], sa1, sb1);
+                rn_wait_dma();
+                __syncthreads();
+                continue;
+            }
             float2 fa[3], fb[3];                              // reads run two k-pairs ahead of the MFMAs that consume them
 #pragma unroll
             for (int pre = 0; pre < 2; ++pre) {
@@ -309,9 +335,13 @@ extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, f
     const dim3 grid((unsigned)(tiles * (a.xcd_map ? (splits + 7) / 8 * 8 : splits)));
     // 16-pixel K-steps: 40-48 KiB of LDS, four / three workgroups per CU (measured: +2..4 % over 32-pixel steps at two per CU
     // on the mid-size layers, equal on the largest; the 64 x 256 tile does not fit twice at 32).
+    const bool split = rn_get_fp32_mfma() == RN_FP32_SPLIT;
 #define RN_WGRAD_LAUNCH(WM_, WN_)                                                                                        \
     do {                                                                                                                 \
-        if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+        if (split) {                                                                                                     \
+            if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+            else hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, false, 16, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, a);         \
+        } else if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
         else hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, false, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);         \
     } while (0)
     if (shape == 0) RN_WGRAD_LAUNCH(1, 4);

@@ -1,4 +1,5 @@
 // Library identity and device check for libretinanet_mi355x.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -13,4 +14,19 @@ extern "C" int rn_check_device(void) {
     e = hipGetDeviceProperties(&prop, dev);
     if (e != hipSuccess) return (int)e;
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? RN_OK : RN_EINVAL;
+}
+
+// fp32 product mode of the convolution kernels (include/retinanet_mi355x.h): -1 = not set yet -> RN_FP32_MFMA from the environment.
+static int g_fp32_mode = -1;
+extern "C" int rn_get_fp32_mfma(void) {
+    if (g_fp32_mode < 0) {
+        const char *e = getenv("RN_FP32_MFMA");
+        g_fp32_mode = (e && strcmp(e, "native") == 0) ? RN_FP32_NATIVE : ((e && strcmp(e, "split") == 0) ? RN_FP32_SPLIT : RN_FP32_DEFAULT);
+    }
+    return g_fp32_mode;
+}
+extern "C" int rn_set_fp32_mfma(int mode) {
+    if (mode != RN_FP32_NATIVE && mode != RN_FP32_SPLIT) return RN_EINVAL;
+    g_fp32_mode = mode;
+    return RN_OK;
 }

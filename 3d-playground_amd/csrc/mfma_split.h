@@ -1,0 +1,64 @@
+// fp32 products on the bf16 matrix cores: split operands.
+//
+// An fp32 number x is written as h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), each rounded to
+// nearest.  The two subtractions are exact in fp32 (the subtrahend is the minuend rounded to fewer bits), and 3 x 8
+// significand bits plus the sign of each residual cover fp32's 24: h + m + l == x exactly (tools/probes/split_probe.hip
+// checks it on 2^20 values over 40 binades: maximum error 0).  A product of two such numbers is the sum of nine bf16 x bf16
+// products, every one of them exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the kernels issue the six
+// largest,
+//        a*b  ~=  ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm,
+// and drop am*bl, al*bm, al*bl: with |m| <= 2^-9 |x| and |l| <= 2^-18 |x| those are below 2^-26 |a*b| -- a quarter of the
+// 2^-24 |acc| rounding every fp32 accumulation step makes anyway, so the result is an fp32 computation in the same sense
+// as the v_mfma_f32_32x32x2_f32 kernels are (DESIGN.md 4.6 holds the measured errors of both against fp64).  Six bf16
+// MFMAs of K = 16 take 6 x 32 cycles where eight fp32 MFMAs of K = 2 take 8 x 64: 2.7x the matrix rate, paid for with the
+// vector ALU work below (4.5 instructions per element), which is what bounds the kernels that use it.
+//
+// Not IEEE in the corners: an infinite or NaN operand gives NaN (inf - inf in the residual), and residuals below the
+// bf16 normal range are flushed by the matrix core.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Split8 { bf16x8 h, m, l; };
+
+// Two values at a time: one v_cvt_pk_bf16_f32 per level, the residuals by shift / mask + one packed subtraction.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const bf16x2 hp = {(__bf16)x0, (__bf16)x1};
+    h = __builtin_bit_cast(unsigned, hp);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16);
+    const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const bf16x2 mp = {(__bf16)r0, (__bf16)r1};
+    m = __builtin_bit_cast(unsigned, mp);
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    const bf16x2 lp = {(__bf16)s0, (__bf16)s1};
+    l = __builtin_bit_cast(unsigned, lp);
+}
+
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+    u32x4 hh, mm, ll;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b, c;
+        split_pair(x[2 * j], x[2 * j + 1], a, b, c);
+        hh[j] = a; mm[j] = b; ll[j] = c;
+    }
+    Split8 s;
+    s.h = __builtin_bit_cast(bf16x8, hh);
+    s.m = __builtin_bit_cast(bf16x8, mm);
+    s.l = __builtin_bit_cast(bf16x8, ll);
+    return s;
+}
+
+// acc += a * b for one 32x32 tile and 16 values of k: the six products, smallest first.
+#define RN_SPLIT_MFMA(ACC, A, B)                                                          \
+    do {                                                                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).l, (B).h, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).h, (B).l, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).m, (B).m, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).m, (B).h, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).h, (B).m, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
+    } while (0)

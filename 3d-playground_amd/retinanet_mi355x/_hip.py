@@ -19,6 +19,8 @@ c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float,
 SIGNATURES = {
     "rn_version": (ctypes.c_char_p, []),
     "rn_check_device": (c_i32, []),
+    "rn_get_fp32_mfma": (c_i32, []),
+    "rn_set_fp32_mfma": (c_i32, [c_i32]),
     "rn_anchor_count": (c_i64, [c_i32, c_i32]),
     "rn_anchor_base_boxes": (None, [c_vp]),
     "rn_anchors_fwd": (c_i32, [c_vp, c_i32, c_i32, c_vp]),

@@ -94,6 +94,19 @@ def _make_desc(x, geom, act, add_mode, add_hw, mask_mode, in_relu, out_map, y_ba
 
 
 # ---------------------------------------------------------------------------------------------- Winograd F(4x4,3x3)
+FP32_MFMA_MODES = ("native", "split")            # RN_FP32_NATIVE, RN_FP32_SPLIT of include/retinanet_mi355x.h
+
+
+def set_fp32_mfma(mode):
+    """How the fp32 convolution kernels form their products: "native" (v_mfma_f32_32x32x2_f32) or "split" (three-term
+    bf16 splits of both fp32 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation; csrc/mfma_split.h).  Process-wide."""
+    _hip.check(_hip.load().rn_set_fp32_mfma(FP32_MFMA_MODES.index(mode)), "rn_set_fp32_mfma")
+
+
+def get_fp32_mfma():
+    return FP32_MFMA_MODES[_hip.load().rn_get_fp32_mfma()]
+
+
 def wino_weights(weight, mode=0, scale=None):
     """OIHW 3x3 parameter -> U [36, rows, Kpad] (mode 0: forward; mode 1: data gradient, batch-norm scale folded in)."""
     lib = _hip.load()

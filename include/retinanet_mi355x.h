@@ -261,6 +261,20 @@ typedef struct rn_conv_desc {
                                       be a multiple of 256 so that no tile spans two images */
 } rn_conv_desc;
 
+/* How the fp32 convolution kernels (rn_conv_igemm*, rn_conv_wgrad*, and through them the Winograd GEMMs) form their
+ * products.  Operands, accumulation, epilogue and results are fp32 either way.
+ *   RN_FP32_NATIVE  v_mfma_f32_32x32x2_f32 (157 TF peak).
+ *   RN_FP32_SPLIT   each fp32 operand is split in registers into three bf16 terms h + m + l (exactly equal to it) and a
+ *                   product is the sum of the six largest of the nine term products on v_mfma_f32_32x32x16_bf16 with the
+ *                   fp32 accumulator; the three dropped terms are below 2^-26 of the product, a quarter of one fp32
+ *                   rounding (csrc/mfma_split.h; DESIGN.md 4.6 has the measured errors of both modes against fp64).
+ * Process-wide; initial value from the environment variable RN_FP32_MFMA = native | split, else RN_FP32_DEFAULT. */
+#define RN_FP32_NATIVE 0
+#define RN_FP32_SPLIT 1
+#define RN_FP32_DEFAULT RN_FP32_NATIVE
+int rn_get_fp32_mfma(void);
+int rn_set_fp32_mfma(int mode);
+
 int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
                   const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
                   void *stream);

@@ -12,10 +12,15 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def cv(dev):
+@pytest.fixture(scope="module", params=["native", "split"])
+def cv(dev, request):
+    """Every test of this module runs in both product modes of the fp32 kernels (include/retinanet_mi355x.h:
+    RN_FP32_NATIVE / RN_FP32_SPLIT), against the same fp64 / fp32 references with the same tolerances."""
     from retinanet_mi355x import conv
-    return conv
+    before = conv.get_fp32_mfma()
+    conv.set_fp32_mfma(request.param)
+    yield conv
+    conv.set_fp32_mfma(before)
 
 
 def rnd(shape, seed, std=1.0):

@@ -25,7 +25,7 @@ import golden_cases as gc
 
 pytestmark = pytest.mark.gpu
 
-GRAD_L2 = {"direct": 3e-5, "wino": 5e-5}             # tight: ~10x measured, >= 90 % of the tensors
+GRAD_L2 = {"direct": 3e-5, "wino": 5e-5}             # tight: ~10x measured, >= FLIP_FREE of the tensors
 GRAD_L2_FLIP, GRAD_MAX = 2e-3, 5e-3                   # loose: a flipped ReLU mask upstream (see above), every tensor
 NORM_TOL = {"direct": 2e-5, "wino": 2e-4}
 CFG2_L2 = {"head": 1e-4, "backbone": 5e-3}            # measured 1.1e-5 / 6.1e-4
@@ -75,7 +75,10 @@ def grad_close(got, want, name, test, l2_tol=GRAD_L2_FLIP, max_tol=GRAD_MAX):
         assert l2 <= l2_tol and mx <= max_tol, "%s [%s]: L2-rel %.3e, max-rel %.3e" % (name, test, l2, mx)
 
 
-def most_within(test, tol, frac=0.9):
+FLIP_FREE = 0.8                                                # share of the tensors that must meet the tight bounds
+
+
+def most_within(test, tol, frac=FLIP_FREE):
     vals = [v[0] for v in STATS[test]["all"].values()]
     ok = sum(v <= tol for v in vals)
     if not MEASURE_ONLY:
@@ -109,9 +112,25 @@ def test_directional_eval_localize(dev, golden, arch):
     rel_close(boxes.cpu().numpy(), z["%s_dir_boxes" % arch], 1e-4)
 
 
+@pytest.fixture(params=["native", "split"])
+def mfma(request, dev):
+    """Both product modes of the fp32 convolution kernels (include/retinanet_mi355x.h: RN_FP32_NATIVE / RN_FP32_SPLIT)."""
+    from retinanet_mi355x import conv
+    before = conv.get_fp32_mfma()
+    conv.set_fp32_mfma(request.param)
+    yield request.param
+    conv.set_fp32_mfma(before)
+
+
 @pytest.mark.parametrize("mode", ["wino", "direct"])
 @pytest.mark.parametrize("arch", ARCHS)
-def test_directional_train_losses_and_gradients(dev, golden, arch, mode):
+def test_directional_train_losses_and_gradients(dev, golden, arch, mode, mfma):
+    """Losses within 1e-4; every parameter gradient within the loose bounds (GRAD_L2_FLIP / GRAD_MAX, and its norm within
+    GRAD_L2_FLIP), and at least FLIP_FREE of them within the tight ones (GRAD_L2 / NORM_TOL).  The two levels exist because
+    of ReLU-mask flips: an activation within one rounding of zero (measured: 6e-8 of its tensor's maximum,
+    tools/dbg/mode_flips.py) is zero on one side of the comparison only, and every gradient BELOW that layer moves by
+    2e-4 .. 1.3e-3 -- one such element in layer1 of ResNet-18 reaches 8 of the 58 tensors.  Which runs have one is a matter
+    of the last bit (kernel family, product mode), not of accuracy: profiles/r02_gradient_errors.txt."""
     z = golden(gc.MODEL_CASES[arch][0])
     net, img, ann, _ = _build(arch, True, dev, wino=(mode == "wino"))
     net.train()
@@ -120,19 +139,23 @@ def test_directional_train_losses_and_gradients(dev, golden, arch, mode):
     got = [float(cls_l.detach()), float(reg_l.detach()), float(vp_l.detach())]
     assert np.allclose(got, z["%s_dir_losses" % arch], rtol=1e-4), (got, z["%s_dir_losses" % arch])
     (cls_l + reg_l + vp_l).sum().backward()
-    checked = 0
+    checked, norm_err = 0, []
+    test = "train_%s_%s_%s" % (arch, mode, mfma)
     for name, p in net.named_parameters():
         assert p.grad is not None, name
         key = "%s_dir_gsum_%s" % (arch, name)
         g = p.grad.detach().cpu().numpy().astype(np.float64)
         ref_norm = z[key][2]
-        assert abs(np.sqrt((g ** 2).sum()) - ref_norm) <= NORM_TOL[mode] * ref_norm + 1e-9, (name, np.sqrt((g ** 2).sum()), ref_norm)
+        norm_err.append(abs(np.sqrt((g ** 2).sum()) - ref_norm) / (ref_norm + 1e-9))
+        assert MEASURE_ONLY or norm_err[-1] <= GRAD_L2_FLIP, (name, np.sqrt((g ** 2).sum()), ref_norm)
         full = "%s_dir_g_%s" % (arch, name)
         if full in z.files:
-            grad_close(g, z[full], name, "train_%s_%s" % (arch, mode))
+            grad_close(g, z[full], name, test)
             checked += 1
     assert checked > 30
-    most_within("train_%s_%s" % (arch, mode), GRAD_L2[mode])
+    most_within(test, GRAD_L2[mode])
+    tight = sum(e <= NORM_TOL[mode] for e in norm_err)
+    assert MEASURE_ONLY or tight >= FLIP_FREE * len(norm_err), "%s: only %d of %d gradient norms within %.0e" % (test, tight, len(norm_err), NORM_TOL[mode])
 
 
 def test_flat2d_train_and_eval(dev, golden):
@@ -377,7 +400,7 @@ CFG2_PARAMS = (["conv1.weight", "bn1.weight", "bn1.bias"]
 
 
 @pytest.mark.parametrize("mode", ["wino", "direct"])
-def test_cfg2_full_size_against_oracle(dev, mode):
+def test_cfg2_full_size_against_oracle(dev, mode, mfma):
     """BASELINE configs[1] at its real size (ResNet-50, 1920x1080, the benchmark's inputs, batch 1): HIP training forward +
     three losses + backward against the oracle on CPU -- the five real pyramid sizes 135x240 ... 9x15, both FPN crop
     branches, the grouped Winograd path with its padded tile count (mode "wino", what bench.py runs) and the direct
@@ -399,7 +422,7 @@ def test_cfg2_full_size_against_oracle(dev, mode):
     named = dict(net.named_parameters())
     for name in CFG2_PARAMS:
         group = "head" if name.startswith(("fpn.", "regressionModel.", "classificationModel.")) else "backbone"
-        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, "cfg2_full_%s" % mode,
+        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, "cfg2_full_%s_%s" % (mode, mfma),
                    l2_tol=CFG2_L2[group], max_tol=2 * GRAD_MAX)
     for name, p in named.items():                              # and every other gradient by its norm
         want = float(o["grads"][name].double().norm())

@@ -55,7 +55,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--mfma", default="", choices=["", "native", "split"], help="fp32 product mode (default: the library's)")
     args = ap.parse_args()
+    if args.mfma:
+        cv.set_fp32_mfma(args.mfma)
+    print("fp32 products:", cv.get_fp32_mfma())
     dev = torch.device("cuda:0")
     B = args.batch
     print("%-26s %9s %9s %9s   (TFLOP/s; %% of %.1f TF fp32 MFMA peak)" % ("layer", "fprop", "dgrad", "wgrad", PEAK))
