@@ -426,7 +426,7 @@ static inline bool bf16_desc_is_dense(const rn_conv_desc *d) {
 
 static inline int check_desc_bf16(const rn_conv_desc *d) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
-    if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3)) return RN_EINVAL;   // 16-byte chunks of 8 channels; 16-byte stores
+    if (d->Cin < 8 || (d->Cin & 7) || (d->Cout & 3) || d->w_format != 0) return RN_EINVAL;   // 16-byte chunks of 8 channels; 16-byte stores
     if ((int64_t)d->Hi * d->Wi * d->Cin * 2 > 0x7fffffffLL) return RN_EINVAL;
     const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 255 / HoWo + 2;    // images a 256-row tile can touch
     if (d->x_batch_stride < 0 || ((span - 1) * d->x_batch_stride + (int64_t)d->Hi * d->Wi * d->Cin) * 2 > 0x7fffffffLL) return RN_EINVAL;

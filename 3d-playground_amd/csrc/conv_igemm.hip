@@ -90,7 +90,11 @@ extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_pack
     }
     const dim3 grid((unsigned)prev), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (rn_get_fp32_mfma() == RN_FP32_SPLIT) return rn_igemm_split_grouped_launch(narrow, (unsigned)prev, g, w_packed, scale, shift, s);
+    for (int i = 0; i < g->n; ++i)
+        if (g->d[i].w_format != d0.w_format) return RN_EINVAL;
+    if (d0.w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;   // the pre-split form is an operand of the split kernels only
+    if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d0.w_format == 1 || d0.kh * d0.kw * d0.Cin >= rn_fp32_split_min_k()))
+        return rn_igemm_split_grouped_launch(narrow, (unsigned)prev, g, w_packed, scale, shift, s);
     if (narrow) hipLaunchKernelGGL((conv_igemm_grouped_kernel<4, 1, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
     else hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
     RN_LAUNCH_CHECK();
@@ -119,7 +123,8 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     // K-step 16 (34-41 KB of LDS, four workgroups per CU) everywhere: with the operands arriving by direct-to-LDS loads it
     // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
     const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0;
-    if (rn_get_fp32_mfma() == RN_FP32_SPLIT)
+    if (d->w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;
+    if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d->w_format == 1 || d->kh * d->kw * d->Cin >= rn_fp32_split_min_k()))
         return rn_igemm_split_launch(raw ? 0 : (d->in_relu ? 1 : (narrow ? (dense ? 2 : 3) : (dense ? 4 : 5))), (unsigned)tiles, d, x,
                                      w_packed, y, scale, shift, add, mask, add2, s);
     if (raw) {                                                           // a plain GEMM: the Winograd stage

@@ -8,16 +8,16 @@
 // registers four workgroups per CU leave, so these kernels run three per CU (168 registers, 34-41 KB of LDS each).
 #include "conv_igemm_tile.h"
 
-template <int WM, int WN, bool GENERAL, bool RELU, bool RAW>
+template <int WM, int WN, bool GENERAL, bool RELU, bool RAW, int SPLIT>
 __global__ __launch_bounds__(256, 3) void conv_igemm_split_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                                   const float *__restrict__ w, float *__restrict__ y,
                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
                                                                   const float *__restrict__ add, const float *__restrict__ mask,
                                                                   const float *__restrict__ add2) {
-    conv_igemm_tile<WM, WN, GENERAL, 16, RELU, RAW, true>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_igemm_tile<WM, WN, GENERAL, 16, RELU, RAW, SPLIT>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int SPLIT>
 __global__ __launch_bounds__(256, 3) void conv_igemm_split_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
                                                                           const float *__restrict__ scale,
                                                                           const float *__restrict__ shift) {
@@ -32,17 +32,20 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_split_grouped_kernel(const 
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_igemm_tile<WM, WN, true, 16, false, false, true>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_igemm_tile<WM, WN, true, 16, false, false, SPLIT>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // variant: the instance conv_igemm.hip's launcher chose -- 0 raw GEMM, 1 input ReLU, 2 / 3 narrow dense / general,
-// 4 / 5 wide dense / general
+// 4 / 5 wide dense / general.  d->w_format 1: w is the pre-split form (rn_split_weights).
 int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, const float *x, const float *w, float *y,
                           const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
                           hipStream_t s) {
     const dim3 grid(tiles), block(256);
-#define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW) \
-    hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
+#define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW)                                                                                              \
+    do {                                                                                                                                \
+        if (d->w_format == 1) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 2>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2); \
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 1>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);                 \
+    } while (0)
     switch (variant) {
         case 0: RN_SPLIT_LAUNCH(2, 2, false, false, true); break;
         case 1: RN_SPLIT_LAUNCH(2, 2, true, true, false); break;
@@ -59,8 +62,25 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
 
 int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_group *g, const float *w, const float *scale,
                                   const float *shift, hipStream_t s) {
-    if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
-    else hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    const bool pre = g->d[0].w_format == 1;
+    if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    else if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    else if (pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    else hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// ---- the pre-split form of a packed weight tensor
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ src, void *__restrict__ dst, int64_t chunks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < chunks) split_store_chunk(src, dst, i);
+}
+
+extern "C" int rn_split_weights(const float *w_packed, void *w_split, int64_t rows, int Kpad, void *stream) {
+    if (rows <= 0 || Kpad <= 0 || (Kpad & 15)) return RN_EINVAL;
+    const int64_t chunks = rows * Kpad / 8;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(rn_blocks(chunks, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, w_split, chunks);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

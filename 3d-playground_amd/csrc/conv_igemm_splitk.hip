@@ -77,6 +77,7 @@ extern "C" int rn_conv_igemm_splitk(const rn_conv_desc *d, const float *x, const
                                     void *workspace, void *stream) {
     const int rc = check_desc(d);
     if (rc) return rc;
+    if (d->w_format != 0) return RN_EINVAL;                  // the pre-split weight form: rn_conv_igemm only
     if ((d->add_mode != 0) != (add != nullptr)) return RN_EINVAL;
     if ((d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
     if ((d->add2_mode != 0) != (add2 != nullptr)) return RN_EINVAL;

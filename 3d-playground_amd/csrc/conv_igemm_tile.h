@@ -97,9 +97,15 @@ __device__ __forceinline__ int lds_swz(int row) {
     return BK == 32 ? ((row & 7) ^ ((row >> 3) & 7)) : ((row >> 2) & 3);
 }
 
-// SPLIT: the products go through the bf16 matrix cores as six split-operand MFMAs per 32x32x16 block (mfma_split.h) instead
-// of eight v_mfma_f32_32x32x2_f32; staging, fragment reads and epilogue are the same code.
-template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false, bool SPLIT = false>
+// SPLIT != 0: the products go through the bf16 matrix cores as six split-operand MFMAs per 32x32x16 block (mfma_split.h)
+// instead of eight v_mfma_f32_32x32x2_f32; activation staging, A fragment reads and epilogue are the same code.
+//   SPLIT 1: w is the packed fp32 tensor, both operands are split in registers.
+//   SPLIT 2: w is the PRE-SPLIT form of the packed tensor (rn_split_weights: [rows][Kpad/16][h,m,l][16] bf16, 96 bytes per
+//            row and K-step), staged as three bf16 planes [BN rows][32 bytes] and read as ready MFMA operands: half the
+//            vector ALU work of SPLIT 1.  Within a plane the two 16-byte chunks of a row swap places in rows 16-31 of
+//            every 32 (position 2*row + (chunk ^ ((row >> 4) & 1))), which makes the ds_read_b128 of [row = lane & 31]
+//            [chunk = lane >> 5] conflict-free (16 distinct 16-byte bank groups per servicing group of 16 lanes).
+template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false, int SPLIT = 0>
 __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const float *__restrict__ x,
                                                 const float *__restrict__ w, float *__restrict__ y,
                                                 const float *__restrict__ scale, const float *__restrict__ shift,
@@ -109,10 +115,19 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
     constexpr int RPI = 64 / CPK;                          // rows one wave instruction fills
-    constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;    // instructions per wave per K-step and operand
-    constexpr int STEP = (BM + BN) * BK;                   // floats per buffer: A rows, then B rows
+    constexpr int BPL = BN * 8;                            // SPLIT 2: floats' worth of one bf16 plane of the B tile (BN rows x 32 bytes)
+    constexpr int NBI = 3 * BN / 32;                       // SPLIT 2: wave instructions that fill the three planes
+    constexpr int IA = BM / RPI / 4, IB = SPLIT == 2 ? (NBI + 3) / 4 : BN / RPI / 4;    // instructions per wave per K-step and operand
+    constexpr int STEP = SPLIT == 2 ? BM * BK + 3 * BPL : (BM + BN) * BK;   // floats per buffer: A rows, then B rows (planes)
     constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
-    constexpr int NBUF = 2;                                // LDS ring (see the K loop for why not three)
+#ifndef RN_SPLIT_NBUF
+#define RN_SPLIT_NBUF 2
+#endif
+    // LDS ring: two buffers (see the K loop for why not three).  The split forms spend 2.7x less time in the MFMAs of a K-step,
+    // so a third buffer was tried for them again (-DRN_SPLIT_NBUF=3): faster on the long-K shapes in isolation (3x3 256->256 at
+    // P4 166 -> 189 TF), slower on the short ones (residency: 60 KB of LDS = two workgroups per CU), and per training step
+    // 89.2 against 90.6 images/s on the same GPU.
+    constexpr int NBUF = SPLIT ? RN_SPLIT_NBUF : 2;
     constexpr int EP = (BM * LDT > NBUF * STEP) ? 2 : 1;   // epilogue passes when the output tile outgrows the staging LDS
     constexpr int RP = BM / EP;                            // tile rows per pass
     constexpr int LDSF = NBUF * STEP > RP * LDT ? NBUF * STEP : RP * LDT;
@@ -139,7 +154,10 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     const int64_t x_floats = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
     const v4i32 rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride,
                                  (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
-    const v4i32 rs_b = make_rsrc(w + (int64_t)n_first * d.w_batch_stride, (unsigned)((int64_t)d.Cout * Kpad * 4));   // per-image weights: a batch of GEMMs
+    // per-image weights (w_batch_stride, in elements): a batch of GEMMs.  The pre-split form has 6 bytes per element.
+    const v4i32 rs_b = SPLIT == 2
+        ? make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * 6, (unsigned)((int64_t)d.Cout * Kpad * 6))
+        : make_rsrc(w + (int64_t)n_first * d.w_batch_stride, (unsigned)((int64_t)d.Cout * Kpad * 4));
 
     // ---- per-lane staging geometry: instruction j of this wave fills rows (wave*I + j)*RPI .. +RPI-1 of the operand;
     // the lane fills position pos of row rsub of them, i.e. fetches logical chunk pos ^ swz(row)
@@ -169,9 +187,16 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     unsigned b_voff[IB];                                   // fixed for the whole kernel; the K-step advance is scalar
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
-        const int row = (wave * IB + j) * RPI + rsub;
-        const int n = n0 + row;
-        b_voff[j] = n < d.Cout ? (unsigned)((n * Kpad + 4 * (pos ^ lds_swz<BK>(row))) * 4) : 0x80000000u;
+        if constexpr (SPLIT == 2) {
+            // instruction q fills 32 rows of one plane: lane -> (row, position), fetches chunk position ^ ((row >> 4) & 1)
+            const int q = wave * IB + j, plane = q / (BN / 32), row = (q % (BN / 32)) * 32 + (lane >> 1);
+            const int n = n0 + row;
+            b_voff[j] = (q < NBI && n < d.Cout) ? (unsigned)(n * Kpad * 6 + plane * 32 + (((lane & 1) ^ ((row >> 4) & 1)) << 4)) : 0x80000000u;
+        } else {
+            const int row = (wave * IB + j) * RPI + rsub;
+            const int n = n0 + row;
+            b_voff[j] = n < d.Cout ? (unsigned)((n * Kpad + 4 * (pos ^ lds_swz<BK>(row))) * 4) : 0x80000000u;
+        }
     }
 
     // Fast path (Cin a multiple of the K-step, i.e. every layer but the 4-channel stem and channel-padded head
@@ -194,7 +219,13 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         const unsigned A = lds0 + (unsigned)((buf * STEP + (wave_u * IA) * RPI * BK) * 4);
         const unsigned B = lds0 + (unsigned)((buf * STEP + BM * BK + (wave_u * IB) * RPI * BK) * 4);
 #pragma unroll
-        for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (RPI * BK * 4), b_voff[j], (unsigned)(ks * BK * 4));
+        for (int j = 0; j < IB; ++j) {
+            if constexpr (SPLIT == 2) {
+                if (wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BM * BK) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 96));
+            } else {
+                dma16(rs_b, B + j * (RPI * BK * 4), b_voff[j], (unsigned)(ks * BK * 4));
+            }
+        }
         if (fast) {
             if (f_c == 0 || f_new) {                       // new tap (wave-uniform)
                 f_new = false;
@@ -243,14 +274,44 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
         for (int st = 0; st < BK / 8; ++st) {
             const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
-            fa[t][st] = ra * BK + 4 * ((2 * st + (lane >> 5)) ^ lds_swz<BK>(ra));
-            fb[t][st] = BM * BK + rb * BK + 4 * ((2 * st + (lane >> 5)) ^ lds_swz<BK>(rb));
+            // split forms: a lane's eight k are CONSECUTIVE (chunks 2g, 2g + 1: the order of a pre-split record's half)
+            const int ch = SPLIT ? 2 * (lane >> 5) + st : 2 * st + (lane >> 5);
+            fa[t][st] = ra * BK + 4 * (ch ^ lds_swz<BK>(ra));
+            fb[t][st] = BM * BK + rb * BK + 4 * (ch ^ lds_swz<BK>(rb));
         }
+    int fbs[2];                                             // SPLIT 2: plane 0 of this lane's B operand of tile t (floats)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int rb = wn * 64 + t * 32 + (lane & 31);
+        fbs[t] = BM * BK + 4 * (2 * rb + ((lane >> 5) ^ ((rb >> 4) & 1)));
+    }
     auto multiply = [&](int buf) {
         const float *S = lds + buf * STEP;
-        if constexpr (SPLIT) {
-            // a lane's eight k of a 16-wide step: chunks g and 2 + g of its row (g = lane >> 5), the same for A and B
-            static_assert(!SPLIT || BK == 16, "split-operand form: K-step 16");
+        if constexpr (SPLIT == 2) {
+            static_assert(SPLIT != 2 || BK == 16, "split-operand form: K-step 16");
+            Split8 sa[2], sb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][0]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][1]);
+                float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                if (RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                }
+                sa[t] = split8(av);
+                sb[t].h = *reinterpret_cast<const bf16x8 *>(S + fbs[t]);
+                sb[t].m = *reinterpret_cast<const bf16x8 *>(S + fbs[t] + BPL);
+                sb[t].l = *reinterpret_cast<const bf16x8 *>(S + fbs[t] + 2 * BPL);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+            return;
+        }
+        if constexpr (SPLIT == 1) {
+            // a lane's eight k of a 16-wide step: k = 8g .. 8g + 7 (g = lane >> 5), the same for A and B
+            static_assert(SPLIT != 1 || BK == 16, "split-operand form: K-step 16");
             Split8 sa[2], sb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -302,9 +363,14 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // training step (igemm kernels): unrolled, 2 buffers, 3 per CU 118.6 ms; rolled, 3 buffers, 3 per CU 119.9; rolled,
     // 2 buffers, 4 per CU 112.0 -- residency beats prefetch distance, most of all on the small-K layers.
     constexpr int NLD = IA + IB;                           // loads one wave issues per K-step
+    // (SPLIT 2 with a 64-wide B tile: the last wave has no B plane to fill, its newest step is IA loads)
+    const bool b_loader = SPLIT != 2 || (wave_u + 1) * IB <= NBI;
+    static_assert(SPLIT != 2 || NBI % IB == 0, "a wave fills IB plane blocks or none");
     auto wait_but_newest = [&](bool newest_in_flight) {
-        if (NBUF > 2 && newest_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        else rn_wait_dma();
+        if (NBUF > 2 && newest_in_flight) {
+            if (b_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA) : "memory");
+        } else rn_wait_dma();
     };
     if (nks > 0) dma_step(0, 0);
     if (NBUF > 2 && nks > 1) dma_step(1, 1);
@@ -448,6 +514,7 @@ static inline int check_desc(const rn_conv_desc *d) {
     if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0 || (d->add2_mode != 0 && d->add2_mode != 3)) return RN_EINVAL;
     if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
     if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
+    if (d->w_format < 0 || d->w_format > 1) return RN_EINVAL;
     if (d->w_batch_stride < 0 || (d->w_batch_stride != 0 && ((int64_t)d->Ho * d->Wo) % 256 != 0)) return RN_EINVAL;
     return RN_OK;
 }

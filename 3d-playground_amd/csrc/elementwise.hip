@@ -6,6 +6,7 @@
 // gradients.  Weight re-packing (OIHW state_dict layout -> K-contiguous GEMM rows) has no reference counterpart:
 // it is the derived cache SURVEY.md 8b asks to keep behind the unchanged parameter layout.
 #include "common.h"
+#include "mfma_split.h"
 
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ void pack_weights_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int kh, int kw,
@@ -136,6 +137,10 @@ __global__ __launch_bounds__(256) void prep_batched_kernel(const rn_prep_job *__
         j.bn_scale[i] = sc;
         j.bn_shift[i] = j.beta[i] - j.mean[i] * sc;
         j.bn_rstd[i] = rs;
+        return;
+    }
+    if (j.kind == 4) {                                       // pre-split form of an already packed fp32 buffer (mfma_split.h): 8 values per thread
+        if (i < (int64_t)j.rows * j.Kpad / 8) split_store_chunk(j.src, j.dst, i);
         return;
     }
     if (i >= (int64_t)j.rows * j.Kpad) return;

@@ -30,3 +30,15 @@ extern "C" int rn_set_fp32_mfma(int mode) {
     g_fp32_mode = mode;
     return RN_OK;
 }
+
+// Convolutions whose reduction length kh*kw*Cin is below this stay on the fp32 MFMA kernels in RN_FP32_SPLIT mode: they are
+// bound by memory and launch shape, not by the matrix cores, and the split kernels' lower residency (three workgroups per CU
+// instead of four) costs them 5-25 % (measured per layer shape: profiles/r02_fp32_split_by_shape.txt).
+extern "C" int rn_fp32_split_min_k(void) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RN_FP32_SPLIT_MIN_K");
+        v = e ? atoi(e) : 192;
+    }
+    return v;
+}

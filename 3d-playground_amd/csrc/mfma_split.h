@@ -52,6 +52,19 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
     return s;
 }
 
+// Pre-split form of a packed fp32 tensor [rows][Kpad] (Kpad a multiple of 16): [rows][Kpad/16] records of 96 bytes, a
+// record = the h, m and l terms (3 x 16 bf16) of the row's 16 values of that K-step -- what one K-step of a kernel reads of a
+// row, contiguous.  Chunk i (8 consecutive values, i = index / 8) of the source goes to its record's three half-planes.
+__device__ __forceinline__ void split_store_chunk(const float *__restrict__ src, void *__restrict__ dst, int64_t i) {
+    const float4 p0 = reinterpret_cast<const float4 *>(src)[2 * i], p1 = reinterpret_cast<const float4 *>(src)[2 * i + 1];
+    const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const Split8 s = split8(v);
+    char *rec = reinterpret_cast<char *>(dst) + (i >> 1) * 96 + (i & 1) * 16;
+    *reinterpret_cast<bf16x8 *>(rec) = s.h;
+    *reinterpret_cast<bf16x8 *>(rec + 32) = s.m;
+    *reinterpret_cast<bf16x8 *>(rec + 64) = s.l;
+}
+
 // acc += a * b for one 32x32 tile and 16 values of k: the six products, smallest first.
 #define RN_SPLIT_MFMA(ACC, A, B)                                                          \
     do {                                                                                  \

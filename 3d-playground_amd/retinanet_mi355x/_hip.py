@@ -21,6 +21,8 @@ SIGNATURES = {
     "rn_check_device": (c_i32, []),
     "rn_get_fp32_mfma": (c_i32, []),
     "rn_set_fp32_mfma": (c_i32, [c_i32]),
+    "rn_fp32_split_min_k": (c_i32, []),
+    "rn_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "rn_anchor_count": (c_i64, [c_i32, c_i32]),
     "rn_anchor_base_boxes": (None, [c_vp]),
     "rn_anchors_fwd": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
@@ -68,7 +70,7 @@ class ConvDesc(ctypes.Structure):
                 ("os", c_i32), ("oo_h", c_i32), ("oo_w", c_i32), ("Hy", c_i32), ("Wy", c_i32),
                 ("add2_mode", c_i32), ("Ha2", c_i32), ("Wa2", c_i32), ("add2_batch_stride", c_i64),
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64),
-                ("w_batch_stride", c_i64)]
+                ("w_batch_stride", c_i64), ("w_format", c_i32)]
 
 
 RN_MAX_GROUP = 5

@@ -3,6 +3,7 @@
 These are the building blocks ``engine.py`` schedules; they do no autograd themselves.
 """
 import ctypes
+import os
 
 import torch
 
@@ -21,7 +22,7 @@ def out_size(n, k, stride, pad):
     return (n + 2 * pad - k) // stride + 1
 
 
-def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None):
+def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None, presplit=True):
     """OIHW parameter -> packed GEMM rows (mode 0: [Cout][kh][kw][Cin]; mode 1 (dgrad): [Cin][kh][kw][Cout]*scale;
     taps=(r0, nr, s0, ns): dgrad layout restricted to taps r0+2i, s0+2j -- one parity class of a stride-2 dgrad)."""
     lib = _hip.load()
@@ -40,7 +41,7 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None)
     out = torch.empty((rows, (ktaps * c_pad + 31) // 32 * 32), dtype=torch.float32, device=w.device)
     _hip.check(lib.rn_pack_weights(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kw_pad, c_pad, mode,
                                    _hip.ptr(scale), r0, nr, s0, ns, _hip.stream()), "rn_pack_weights")
-    return out
+    return _maybe_split(out) if presplit else out        # split mode: with the pre-split twin attached
 
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
@@ -64,6 +65,8 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
                  a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride, w_batch_stride)
     if kind is None:
         kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
+    if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
+        kind += " %dx%dx%d %d->%d k%d a%d b%d ds%d%s" % (N, Ho, Wo, Cin, Cout, kh, a, b, ds, " x36" if w_batch_stride else "")
     ws_bytes = 0 if w_batch_stride else lib.rn_conv_splitk_workspace_bytes(ctypes.byref(d))   # > 0: few output tiles, long K -> split-K
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
@@ -72,8 +75,9 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
             _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), ws.data_ptr(), _hip.stream()))
         _hip.check(rc, "rn_conv_igemm_splitk")
         return y
+    wptr, d.w_format = _w_operand(w_packed)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm(
-        ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
+        ctypes.byref(d), x.data_ptr(), wptr, y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
         _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm")
     return y
@@ -107,6 +111,48 @@ def get_fp32_mfma():
     return FP32_MFMA_MODES[_hip.load().rn_get_fp32_mfma()]
 
 
+PRESPLIT = os.environ.get("RN_FP32_PRESPLIT", "1") != "0"      # split mode: prepare the weights' three terms once (rn_split_weights)
+
+
+def split_weights(w_packed):
+    """Attach the pre-split twin of a packed fp32 weight tensor ([..., rows, Kpad] -> rows * Kpad * 6 bytes,
+    include/retinanet_mi355x.h: rn_split_weights) as w_packed._rn_split; the convolution wrappers pass it instead of the
+    fp32 tensor in split mode.  Whoever rewrites w_packed in place refreshes the twin (the engine's batched preparation does)."""
+    lib = _hip.load()
+    kpad = w_packed.shape[-1]
+    ws = getattr(w_packed, "_rn_split", None)
+    if ws is None:
+        ws = torch.empty(w_packed.numel() * 6, dtype=torch.uint8, device=w_packed.device)
+    _hip.check(lib.rn_split_weights(w_packed.data_ptr(), ws.data_ptr(), w_packed.numel() // kpad, kpad, _hip.stream()), "rn_split_weights")
+    w_packed._rn_split = ws
+    return w_packed
+
+
+def _maybe_split(w_packed):
+    """split mode: attach the pre-split twin -- for reductions long enough to run on the split kernels (rn_fp32_split_min_k;
+    the packed row is the reduction, padded)."""
+    if PRESPLIT and get_fp32_mfma() == "split" and w_packed.shape[-1] >= _hip.load().rn_fp32_split_min_k():
+        return split_weights(w_packed)
+    return w_packed
+
+
+def _carry_split(src, view):
+    """A view of a packed tensor keeps its pre-split twin."""
+    ws = getattr(src, "_rn_split", None)
+    if ws is not None:
+        view._rn_split = ws
+    return view
+
+
+def _w_operand(w_packed):
+    """(pointer, rn_conv_desc.w_format) of the weight operand for rn_conv_igemm / _grouped."""
+    if PRESPLIT:
+        ws = getattr(w_packed, "_rn_split", None)
+        if ws is not None and get_fp32_mfma() == "split":
+            return ws.data_ptr(), 1
+    return w_packed.data_ptr(), 0
+
+
 def wino_weights(weight, mode=0, scale=None):
     """OIHW 3x3 parameter -> U [36, rows, Kpad] (mode 0: forward; mode 1: data gradient, batch-norm scale folded in)."""
     lib = _hip.load()
@@ -118,7 +164,7 @@ def wino_weights(weight, mode=0, scale=None):
     U = torch.empty((36, rows, (k + 31) // 32 * 32), dtype=torch.float32, device=w.device)
     _hip.check(lib.rn_wino_weights(w.data_ptr(), U.data_ptr(), cout, cin, mode, _hip.ptr(scale), _hip.stream()),
                "rn_wino_weights")
-    return U
+    return _maybe_split(U)
 
 
 _WINO_WS = {}
@@ -182,7 +228,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     # rows past T hold whatever the scratch tensor held: they produce rows of M nobody reads
     Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
     Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)
-    conv_igemm(Vv, U.view(36 * cout, U.shape[2]), Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0),
+    conv_igemm(Vv, _carry_split(U, U.view(36 * cout, U.shape[2])), Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0),
                flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2])    # executed FLOPs: same kernel, same family
     if outs is None:
         outs = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in xs]
@@ -224,7 +270,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
     _wino_transform_in(gs, Z, cout, Tpad, 1)
     ku = (C + 31) // 32 * 32
     dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
-    rc = prof.timed("conv_wgrad", 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(    # executed FLOPs
+    rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(    # executed FLOPs
         Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
         1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0, _hip.stream()))
     _hip.check(rc, "rn_conv_wgrad_batched")
@@ -239,18 +285,23 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
     g = _hip.ConvGroup()
     g.n = len(problems)
     total = 0
+    wptr, wfmt = _w_operand(w_packed)
     for i, pr in enumerate(problems):
         x, geom = pr["x"], pr["geom"]
         add, mask = pr.get("add"), pr.get("mask")
         d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), (pr.get("mask_mode", 2) if mask is not None else 0),
                        False, None, pr.get("y_batch_stride"), None, None)
+        d.w_format = wfmt
         g.d[i] = d
         M = d.N * d.Ho * d.Wo
         total += (M + 255) // 256 if d.Cout <= 64 else ((M + 127) // 128) * ((d.Cout + 127) // 128)
         g.tile_end[i] = total
         g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
-    rc = prof.timed("conv_igemm_4x1" if problems[0]["geom"][2] <= 64 else "conv_igemm_2x2", flops, lambda: lib.rn_conv_igemm_grouped(
-        ctypes.byref(g), w_packed.data_ptr(), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
+    kind = "conv_igemm_4x1" if problems[0]["geom"][2] <= 64 else "conv_igemm_2x2"
+    if prof.BY_SHAPE:
+        kind += " grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh)
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_grouped(
+        ctypes.byref(g), wptr, _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm_grouped")
 
 
@@ -313,7 +364,8 @@ def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0
     lib = _hip.load()
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
-    rc = prof.timed("conv_wgrad", flops, lambda: lib.rn_conv_wgrad(
+    kind = "conv_wgrad" + (" %dx%dx%d %d->%d k%d s%d" % (N, Ho, Wo, Cin, cout, k, stride) if prof.BY_SHAPE else "")
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_wgrad(
         dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), N, Hi, Wi, Cin, Ho, Wo, cout, k,
         k if kw_pad is None else kw_pad, stride, pad, int(in_relu), _hip.stream()))
     _hip.check(rc, "rn_conv_wgrad")
@@ -455,7 +507,7 @@ def pack_weights_bf16(weight, mode=0, scale=None, c_pad=None, taps=None):
     cin, cout = weight.shape[1], weight.shape[0]
     if c_pad is None:
         c_pad = ((cin if mode == 0 else cout) + 7) // 8 * 8                  # 16-byte chunks hold 8 channels
-    return to_bf16(pack_weights(weight, mode, scale=scale, c_pad=c_pad, taps=taps))
+    return to_bf16(pack_weights(weight, mode, scale=scale, c_pad=c_pad, taps=taps, presplit=False))
 
 
 def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,

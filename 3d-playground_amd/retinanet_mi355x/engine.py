@@ -440,7 +440,8 @@ class Engine:
         """Per-step preparation of a TRAINING step in two launches (rn_prep_batched): every batch-norm fold and forward
         weight pack, then every data-gradient pack (they read the folded scale).  The job tables and the destination
         buffers persist; they are rebuilt when a parameter tensor has been replaced."""
-        key = tuple(P[n].data_ptr() for n in sorted(P) if n.endswith((".weight", ".bias", "running_mean", "running_var")))
+        key = tuple(P[n].data_ptr() for n in sorted(P) if n.endswith((".weight", ".bias", "running_mean", "running_var"))) \
+            + (cv.get_fp32_mfma(), cv.PRESPLIT)
         prep = getattr(self, "_prep", None)
         if prep is None or prep["key"] != key:
             prep = self._prep = self._build_prep(P, key)
@@ -465,6 +466,19 @@ class Engine:
             add(2, j, src.numel())
             return dst
 
+        presplit = cv.PRESPLIT and cv.get_fp32_mfma() == "split" and not self.bf16
+
+        def split_job(src):
+            """split mode: the pre-split twin of a packed fp32 buffer (cv.split_weights' attribute), filled by launch 2."""
+            if not presplit or src.shape[-1] < _hip.load().rn_fp32_split_min_k():
+                return
+            dst = torch.empty(src.numel() * 6, dtype=torch.uint8, device=dev)
+            j = _hip.PrepJob()
+            j.kind, j.rows, j.Kpad = 4, src.numel() // src.shape[-1], src.shape[-1]
+            j.src, j.dst = src.data_ptr(), dst.data_ptr()
+            add(2, j, src.numel() // 8)
+            src._rn_split = dst
+
         def add(which, job, nelem):
             jobs, chunks = launches[which]
             jobs.append(job)
@@ -487,6 +501,7 @@ class Engine:
             b = bufs[name] = {}
             b["wf"] = torch.empty((cout, (kh * L.kw_pad * L.cin_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
             add(0, pack_job(w, b["wf"], 0, L.kw_pad, L.cin_pad, None), b["wf"].numel())
+            split_job(b["wf"])
             if L.bf16:
                 b["wf16"] = cast_job(b["wf"])
             scale = None
@@ -508,6 +523,7 @@ class Engine:
                     j.rows, j.Kpad = dst.shape[1], dst.shape[2]
                     j.src, j.dst, j.scale = w.data_ptr(), dst.data_ptr(), None if (mode == 0 or scale is None) else scale.data_ptr()
                     add(which, j, dst.shape[1] * dst.shape[2])
+                    split_job(dst)
                 b["wino"] = (uf, ud)
                 continue
             if name == "conv1":
@@ -518,12 +534,14 @@ class Engine:
                     r0, nr, s0, ns = c[2]
                     d = torch.empty((cin, (nr * ns * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
                     add(1, pack_job(w, d, 2, kw, L.cout_pad, scale, c[2]), d.numel())
+                    split_job(d)
                     b["wd"].append(d)
                 if L.bf16:
                     b["wd16"] = [cast_job(d) for d in b["wd"]]
             else:
                 d = b["wd"] = torch.empty((cin, (kh * kw * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
                 add(1, pack_job(w, d, 1, kw, L.cout_pad, scale), d.numel())
+                split_job(d)
                 if L.bf16:
                     b["wd16"] = cast_job(d)
         out = []

@@ -12,8 +12,10 @@ all on inputs already resident in HBM.  With N > 1 every rank trains on its own 
 gradients are averaged over RCCL inside backward (retinanet_mi355x.ddp).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel (fp32 MFMA implicit-GEMM conv, 128x128 tile): algorithmic FLOPs of its launches
-                inside the timed steps / their HIP-event durations, against the 157.3 TF fp32 MFMA peak
+  roofline      the dominant kernel (implicit-GEMM conv, 128x128 tile): algorithmic (fp32) FLOPs of its launches inside the
+                timed steps / their HIP-event durations, against the peak of the instruction it runs on: 2500 / 6 = 416.7 TF
+                in split-operand mode (six bf16 MFMAs per fp32 product), 157.3 TF on the fp32 MFMA
+  fp32_native_mfma  (split mode) the same step on v_mfma_f32_32x32x2_f32, measured in the same run
   kernels       the same for the other timed kernels, plus the fused IoU+focal loss against the HBM roof
   cpu_baseline  the CPU restatement (oracle/, torch CPU kernels = what the reference runs on a GPU-less host)
                 timed on this box's host cores on a bounded sample (1 image, forward+loss+backward), rank 0, N=1 only
@@ -32,7 +34,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-PEAK_BF16_MFMA_TF = 2500.0        # dense bf16 MFMA (same guide); only for the kernels of --dtype bf16
+PEAK_BF16_MFMA_TF = 2500.0        # dense bf16 MFMA (same guide): the kernels of --dtype bf16, and --
+PEAK_SPLIT_TF = PEAK_BF16_MFMA_TF / 6   # -- the fp32 kernels in split-operand mode: six bf16 MFMAs per fp32 product (csrc/mfma_split.h)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec; 6.29 TB/s measured copy
 
 
@@ -48,6 +51,9 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the reference's arithmetic = the headline (BASELINE configs[1]); bf16 = configs[2]'s storage "
                          "format (bf16 activations / MFMA, fp32 accumulation and master weights), reported with dtype bf16")
+    ap.add_argument("--fp32-mfma", default="", choices=["", "split", "native"],
+                    help="how the fp32 convolution kernels form their products (include/retinanet_mi355x.h: RN_FP32_SPLIT / "
+                         "RN_FP32_NATIVE); default: the library's (RN_FP32_DEFAULT, or the environment's RN_FP32_MFMA)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (forward, loss, backward, clip + Adam) into one hipGraph after the warm-up and "
                          "replay it in the timed region (single GPU)")
@@ -183,12 +189,64 @@ def bf16_section(dev, args, B, H, W):
     return out
 
 
+def native_section(dev, args, B, H, W):
+    """Supplementary: the SAME training step with the fp32 convolutions on v_mfma_f32_32x32x2_f32 (RN_FP32_NATIVE), on this GPU
+    in this run -- the reader's yardstick for the split-operand headline."""
+    from retinanet_mi355x import conv as cv, modules, optim, prof, synth
+    cv.set_fp32_mfma("native")
+    try:
+        net = getattr(modules, args.arch)(num_classes=8)
+        net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))
+        net = net.to(dev)
+        net.train()
+        net.freeze_bn()
+        net.use_flat_gradients()
+        opt = optim.ClipAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, max_norm=0.1)
+        img = torch.randn(B, 3, H, W, generator=torch.Generator(device=dev).manual_seed(1000), device=dev)
+        ann = synth.labels_dir(B, 10, H, W, 8, seed=1).to(dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = sum(l.mean() for l in net([img, ann]))
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        n = max(args.steps, 3)
+        t0 = time.time()
+        for _ in range(n):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        out = {"value": round(B * n / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / n, 2), "steps": n,
+               "final_loss": round(float(loss.detach()), 5), "products": "v_mfma_f32_32x32x2_f32"}
+        t = prof.ACTIVE = prof.KernelTimer()
+        for _ in range(2):
+            step()
+        summ = t.summary()
+        prof.ACTIVE = None
+        for kind in ("conv_igemm_2x2", "conv_igemm_4x1", "conv_wgrad"):
+            a = summ.get(kind)
+            if a and a["ms_total"] > 0:
+                tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12
+                out[kind] = {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TF, 4),
+                             "ms_per_step": round(a["ms_total"] / 2, 2)}
+        return out
+    finally:
+        prof.ACTIVE = None
+        cv.set_fp32_mfma("split")
+
+
 def pmc_traffic(kind):
     """Average HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command
     (tools/collect_traffic.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).
     PMC counters cannot be read from inside the process, so the number is the last collected one, or None."""
-    prefix = {"conv_igemm_2x2": ("conv_igemm_kernel<2, 2", "conv_igemm_grouped_kernel<2, 2"),
-              "conv_igemm_4x1": ("conv_igemm_kernel<4, 1", "conv_igemm_grouped_kernel<4, 1"),
+    prefix = {"conv_igemm_2x2": ("conv_igemm_kernel<2, 2", "conv_igemm_grouped_kernel<2, 2", "conv_igemm_split_kernel<2, 2",
+                                 "conv_igemm_split_grouped_kernel<2, 2"),
+              "conv_igemm_4x1": ("conv_igemm_kernel<4, 1", "conv_igemm_grouped_kernel<4, 1", "conv_igemm_split_kernel<4, 1",
+                                 "conv_igemm_split_grouped_kernel<4, 1"),
               "conv_wgrad": ("conv_wgrad_kernel",)}.get(kind)
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if prefix is None or not os.path.exists(path):
@@ -293,6 +351,12 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     B, H, W = args.batch, args.height, args.width
+    from retinanet_mi355x import conv as cv
+    if args.fp32_mfma:
+        cv.set_fp32_mfma(args.fp32_mfma)
+    fp32_mode = cv.get_fp32_mfma()
+    split = fp32_mode == "split" and args.dtype == "fp32"
+    conv_peak = PEAK_SPLIT_TF if split else PEAK_F32_MFMA_TF      # what the fp32 conv kernels are priced against
 
     net = getattr(modules, args.arch)(num_classes=8)
     net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))          # same weights on every rank
@@ -385,6 +449,13 @@ def main():
                                           "bf16 activations / MFMA with fp32 accumulation and master weights",
                                           1 if args.dtype == "fp32" else 2),
                            "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)}}
+        if args.dtype == "fp32":
+            line["config"]["fp32_products"] = (
+                "split operands: every fp32 operand as three bf16 terms (h + m + l == x exactly), six v_mfma_f32_32x32x16_bf16 "
+                "products per block into the fp32 accumulator, dropped terms < 2^-26 of a product; operands, accumulation, "
+                "epilogues, gradients and optimizer fp32; measured errors against fp64 equal to the fp32 MFMA kernels' "
+                "(DESIGN.md 4.6, profiles/r02_fp32_split_errors.txt); fp32_native_mfma below = the same step on v_mfma_f32_32x32x2_f32"
+                if split else "v_mfma_f32_32x32x2_f32")
         if graph_note:
             line["config"]["launch"] = graph_note
         if timer is not None:
@@ -398,10 +469,14 @@ def main():
                                      "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
                     continue
                 tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12 if a["ms_total"] > 0 else 0.0
-                peak = PEAK_BF16_MFMA_TF if kind.endswith("_bf16") else PEAK_F32_MFMA_TF
-                kernels[kind] = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                peak = PEAK_BF16_MFMA_TF if kind.endswith("_bf16") else conv_peak
+                kernels[kind] = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                  "frac": round(tf / peak, 4), "launches_per_step": a["launches"] // args.steps,
                                  "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
+                if split and not kind.endswith("_bf16"):
+                    # achieved = fp32 FLOPs of the convolution; the kernel executes 6 bf16 MFMA FLOPs for each of them
+                    kernels[kind]["peak_note"] = "2500 TF dense bf16 MFMA / 6 MFMAs per fp32 product"
+                    kernels[kind]["frac_of_fp32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TF, 4)
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             r = dict(kernels[dom])
             r["kernel"] = dom
@@ -426,9 +501,11 @@ def main():
             eng.use_wino = wino_was
             fwork, fms = sum(a["work_total"] for a in fs), sum(a["ms_total"] for a in fs)
             ftf = fwork / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
-            kernels["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": PEAK_F32_MFMA_TF,
-                                        "unit": "TFLOP/s", "frac": round(ftf / PEAK_F32_MFMA_TF, 4),
+            kernels["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": round(conv_peak, 1),
+                                        "unit": "TFLOP/s", "frac": round(ftf / conv_peak, 4),
                                         "ms_per_pass": round(fms / 3, 2), "gflop_per_image": round(fwork / 3 / B / 1e9, 1)}
+            if split:
+                kernels["forward_convs"]["frac_of_fp32_mfma_peak"] = round(ftf / PEAK_F32_MFMA_TF, 4)
             if wino_was:
                 # the forward as the training step runs it (Winograd F(4x4,3x3) in the head towers): same algorithmic FLOPs
                 # over the time of every conv-path kernel, transforms included -- a throughput, not an MFMA utilisation
@@ -440,7 +517,12 @@ def main():
         if world == 1 and args.dtype == "fp32" and timer is not None:
             del net, opt, params
             torch.cuda.empty_cache()
-            try:                                                    # supplementary sections never cost the headline its line
+            if split:
+                try:                                                # supplementary sections never cost the headline its line
+                    line["fp32_native_mfma"] = native_section(dev, args, B, H, W)
+                except Exception as e:
+                    line["fp32_native_mfma"] = {"error": str(e)[:300]}
+            try:
                 line["bf16"] = bf16_section(dev, args, B, H, W)
             except Exception as e:
                 line["bf16"] = {"error": str(e)[:300]}

@@ -259,6 +259,8 @@ typedef struct rn_conv_desc {
     int64_t w_batch_stride;        /* 0: one weight tensor.  != 0 (floats): image n uses w_packed + n * w_batch_stride -- a batch of
                                       independent GEMMs in one launch (the 36 positions of the Winograd path); Ho*Wo must then
                                       be a multiple of 256 so that no tile spans two images */
+    int w_format;                  /* 0: w_packed is the fp32 tensor of rn_pack_weights; 1: its pre-split form (rn_split_weights),
+                                      accepted in RN_FP32_SPLIT mode only (RN_EINVAL otherwise; not by the split-K form) */
 } rn_conv_desc;
 
 /* How the fp32 convolution kernels (rn_conv_igemm*, rn_conv_wgrad*, and through them the Winograd GEMMs) form their
@@ -271,9 +273,17 @@ typedef struct rn_conv_desc {
  * Process-wide; initial value from the environment variable RN_FP32_MFMA = native | split, else RN_FP32_DEFAULT. */
 #define RN_FP32_NATIVE 0
 #define RN_FP32_SPLIT 1
-#define RN_FP32_DEFAULT RN_FP32_NATIVE
+#define RN_FP32_DEFAULT RN_FP32_SPLIT
 int rn_get_fp32_mfma(void);
 int rn_set_fp32_mfma(int mode);
+/* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (192; environment RN_FP32_SPLIT_MIN_K);
+ * shorter reductions are memory-bound and keep the fp32 MFMA kernel.  (A pre-split weight operand, w_format 1, is always
+ * taken by the split kernels: prepare it for the long reductions only.) */
+int rn_fp32_split_min_k(void);
+/* RN_FP32_SPLIT: the weights' three bf16 terms can be prepared once per optimizer step instead of in every workgroup:
+ * w_split [rows][Kpad/16][3][16] bf16 (6 bytes per element of w_packed [rows][Kpad], Kpad % 16 == 0; for a batch of GEMMs
+ * rows = batch * rows).  Pass it as w_packed with rn_conv_desc.w_format = 1.  (rn_prep_batched: job kind 4.) */
+int rn_split_weights(const float *w_packed, void *w_split, int64_t rows, int Kpad, void *stream);
 
 int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
                   const float *scale, const float *shift, const float *add, const float *mask, const float *add2,

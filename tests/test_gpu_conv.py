@@ -12,15 +12,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["native", "split"])
+@pytest.fixture(scope="module", params=["native", "split", "split-in-kernel"])
 def cv(dev, request):
     """Every test of this module runs in both product modes of the fp32 kernels (include/retinanet_mi355x.h:
-    RN_FP32_NATIVE / RN_FP32_SPLIT), against the same fp64 / fp32 references with the same tolerances."""
+    RN_FP32_NATIVE / RN_FP32_SPLIT), the split mode with the weights' terms prepared by rn_split_weights (w_format 1) and
+    with both operands split inside the kernels, against the same fp64 / fp32 references with the same tolerances."""
     from retinanet_mi355x import conv
-    before = conv.get_fp32_mfma()
-    conv.set_fp32_mfma(request.param)
+    before = conv.get_fp32_mfma(), conv.PRESPLIT
+    conv.set_fp32_mfma(request.param.split("-")[0])
+    conv.PRESPLIT = request.param == "split"
     yield conv
-    conv.set_fp32_mfma(before)
+    conv.set_fp32_mfma(before[0])
+    conv.PRESPLIT = before[1]
 
 
 def rnd(shape, seed, std=1.0):
@@ -445,3 +448,29 @@ def test_splitk_fprop_and_dgrad(cv, dev, case):
         wd = cv.pack_weights(wg, 1, c_pad=cpad)
         dx = cv.dgrad(gyg.contiguous(), wd, (H, W), cin, k, stride, pad)
         close(nchw(dx), xr.grad)
+
+
+def test_split_weights_terms_add_up_exactly(cv, dev):
+    """rn_split_weights: [rows][Kpad/16][h, m, l][16] bf16 with h + m + l == w exactly (csrc/mfma_split.h)."""
+    w = rnd((40, 64), 5) * torch.logspace(-12, 12, 40 * 64).view(40, 64)
+    w[3, 7] = 0.0
+    wp = w.to(dev).contiguous()
+    cv.split_weights(wp)
+    rec = wp._rn_split.view(torch.bfloat16).view(40, 4, 3, 16).cpu()
+    total = rec.double().sum(dim=2).reshape(40, 64)
+    assert torch.equal(total, w.double())
+    assert torch.equal(rec[:, :, 0].reshape(40, 64), w.to(torch.bfloat16))            # h is the nearest bf16
+
+
+def test_presplit_operand_is_refused_in_native_mode(cv, dev):
+    import ctypes
+    from retinanet_mi355x import _hip
+    if cv.get_fp32_mfma() != "native":
+        pytest.skip("native mode only")
+    x = rnd((1, 8, 8, 16), 1).to(dev)
+    wp = cv.pack_weights(rnd((32, 16, 1, 1), 2).to(dev), 0)
+    cv.split_weights(wp)
+    y = torch.empty((1, 8, 8, 32), device=dev)
+    d = _hip.ConvDesc(1, 8, 8, 16, 8, 8, 32, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 8, 8, 0, 0, 0, 0, 8 * 8 * 16, 8 * 8 * 32, 8 * 8 * 32, 0, 1)
+    rc = _hip.load().rn_conv_igemm(ctypes.byref(d), x.data_ptr(), wp._rn_split.data_ptr(), y.data_ptr(), None, None, None, None, None, _hip.stream())
+    assert rc != 0

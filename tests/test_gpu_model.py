@@ -8,8 +8,15 @@ with the Winograd F(4x4,3x3) layers on; the bounds are ~10x that (GRAD_L2).  ONE
 error of the kernels: an activation that lies within rounding of zero (|x| ~ 1e-6 of the layer's max) comes out on the
 other side of the ReLU than in the CPU run, its mask flips, and everything upstream of that element moves -- measured:
 ResNet-18, batch 2, ONE flipped mask in 17 920 (regressionModel.conv3 at the P4 level, activation 1.4e-6 against a max of
-27) puts fpn.P4_2.bias at 3.8e-4 (tools/dbg/wino_bias.py).  So: at least 90 % of the compared tensors must meet the tight
-bound and every tensor the loose one (GRAD_L2_FLIP / GRAD_MAX); a systematic error 10x the measured one fails the first.
+27) puts fpn.P4_2.bias at 3.8e-4 (tools/dbg/wino_bias.py).  Which run has such an element is a matter of its last bit
+-- kernel family, product mode (tools/dbg/mode_flips.py: one element at 6e-8 of its tensor's maximum in layer1.1 of
+ResNet-18 moves the 8 tensors below it by 2e-4 .. 1.3e-3; one at 8e-8 in layer4.0 of ResNet-101, 3x4 pixels there at the
+golden's size, moves the 189 tensors below it by ~8e-4 and layer4.0.bn1.bias by 4.8e-3).  So: at least FLIP_FREE of
+the compared tensors must meet the tight bound and every tensor the loose one (GRAD_L2_FLIP / GRAD_MAX) -- a systematic
+error 10x the measured one fails the first -- OR the test finds the flipped element itself (the zero pattern of the saved
+activations differs between the two product modes of the kernels, relu_flips()) and every tensor meets the bounds a flip
+can reach at these sizes (FLIPPED_L2 / FLIPPED_MAX).  The kernels themselves are held to 1e-4 .. 2e-5 against fp64 in
+every mode by tests/test_gpu_conv.py, where no ReLU intervenes.
 At the full benchmark size (test_cfg2_full_size_against_oracle: 1e8 activations, hundreds of such flips, accumulating
 towards the stem) heads and FPN stay at <= 1.1e-5 and the backbone reaches 1e-4 .. 6e-4 with EITHER kernel family, so
 that test has its own bounds per group, again ~10x the measured values.
@@ -122,15 +129,43 @@ def mfma(request, dev):
     conv.set_fp32_mfma(before)
 
 
+FLIPPED_L2, FLIPPED_MAX = 1e-2, 5e-2                           # reach of one flipped mask at the goldens' sizes (see the module docstring)
+
+
+def _activation_patterns(net, img):
+    from retinanet_mi355x import conv
+    pats = {}
+
+    def walk(o, path):
+        if isinstance(o, torch.Tensor):
+            if o.dtype == torch.float32 and o.numel() > 0 and "wino_v" not in path:
+                pats[path] = o > 0
+        elif isinstance(o, dict):
+            for k, v in o.items():
+                walk(v, "%s/%s" % (path, k))
+        elif isinstance(o, (list, tuple)):
+            for i, v in enumerate(o):
+                walk(v, "%s/%d" % (path, i))
+    walk(net._engine.forward(net._tensor_dict(), img, save=True)[2], "S")
+    return pats
+
+
+def relu_flips(net, img):
+    """Elements of the saved forward activations that are zero in exactly one of the two product modes."""
+    from retinanet_mi355x import conv
+    before = conv.get_fp32_mfma()
+    pats = []
+    for m in conv.FP32_MFMA_MODES:
+        conv.set_fp32_mfma(m)
+        pats.append(_activation_patterns(net, img))
+    conv.set_fp32_mfma(before)
+    return sum(int((pats[0][k] != pats[1][k]).sum()) for k in pats[0] if k in pats[1] and pats[0][k].shape == pats[1][k].shape)
+
+
 @pytest.mark.parametrize("mode", ["wino", "direct"])
 @pytest.mark.parametrize("arch", ARCHS)
 def test_directional_train_losses_and_gradients(dev, golden, arch, mode, mfma):
-    """Losses within 1e-4; every parameter gradient within the loose bounds (GRAD_L2_FLIP / GRAD_MAX, and its norm within
-    GRAD_L2_FLIP), and at least FLIP_FREE of them within the tight ones (GRAD_L2 / NORM_TOL).  The two levels exist because
-    of ReLU-mask flips: an activation within one rounding of zero (measured: 6e-8 of its tensor's maximum,
-    tools/dbg/mode_flips.py) is zero on one side of the comparison only, and every gradient BELOW that layer moves by
-    2e-4 .. 1.3e-3 -- one such element in layer1 of ResNet-18 reaches 8 of the 58 tensors.  Which runs have one is a matter
-    of the last bit (kernel family, product mode), not of accuracy: profiles/r02_gradient_errors.txt."""
+    """Losses within 1e-4; parameter gradients by the two-level rule of the module docstring."""
     z = golden(gc.MODEL_CASES[arch][0])
     net, img, ann, _ = _build(arch, True, dev, wino=(mode == "wino"))
     net.train()
@@ -139,23 +174,33 @@ def test_directional_train_losses_and_gradients(dev, golden, arch, mode, mfma):
     got = [float(cls_l.detach()), float(reg_l.detach()), float(vp_l.detach())]
     assert np.allclose(got, z["%s_dir_losses" % arch], rtol=1e-4), (got, z["%s_dir_losses" % arch])
     (cls_l + reg_l + vp_l).sum().backward()
-    checked, norm_err = 0, []
     test = "train_%s_%s_%s" % (arch, mode, mfma)
+    errs, norm_err = {}, {}
     for name, p in net.named_parameters():
         assert p.grad is not None, name
-        key = "%s_dir_gsum_%s" % (arch, name)
         g = p.grad.detach().cpu().numpy().astype(np.float64)
-        ref_norm = z[key][2]
-        norm_err.append(abs(np.sqrt((g ** 2).sum()) - ref_norm) / (ref_norm + 1e-9))
-        assert MEASURE_ONLY or norm_err[-1] <= GRAD_L2_FLIP, (name, np.sqrt((g ** 2).sum()), ref_norm)
+        ref_norm = z["%s_dir_gsum_%s" % (arch, name)][2]
+        norm_err[name] = abs(np.sqrt((g ** 2).sum()) - ref_norm) / (ref_norm + 1e-9)
         full = "%s_dir_g_%s" % (arch, name)
         if full in z.files:
-            grad_close(g, z[full], name, test)
-            checked += 1
-    assert checked > 30
-    most_within(test, GRAD_L2[mode])
-    tight = sum(e <= NORM_TOL[mode] for e in norm_err)
-    assert MEASURE_ONLY or tight >= FLIP_FREE * len(norm_err), "%s: only %d of %d gradient norms within %.0e" % (test, tight, len(norm_err), NORM_TOL[mode])
+            want = z[full].astype(np.float64)
+            l2 = np.sqrt(((g - want) ** 2).sum()) / (np.sqrt((want ** 2).sum()) + 1e-30)
+            mx = np.abs(g - want).max() / (np.abs(want).max() + 1e-30)
+            errs[name] = (float(l2), float(mx))
+            _note(test, name, float(l2), float(mx))
+    assert len(errs) > 30
+    if MEASURE_ONLY:
+        return
+    worst = max(errs, key=lambda n: errs[n][0])
+    tight = sum(e[0] <= GRAD_L2[mode] for e in errs.values()) >= FLIP_FREE * len(errs) and \
+        sum(e <= NORM_TOL[mode] for e in norm_err.values()) >= FLIP_FREE * len(norm_err)
+    loose = all(e[0] <= GRAD_L2_FLIP and e[1] <= GRAD_MAX for e in errs.values()) and all(e <= GRAD_L2_FLIP for e in norm_err.values())
+    if tight and loose:
+        return
+    flips = relu_flips(net, img)
+    assert flips > 0, "%s: worst %s %s and no ReLU mask differs between the product modes" % (test, worst, errs[worst])
+    assert all(e[0] <= FLIPPED_L2 and e[1] <= FLIPPED_MAX for e in errs.values()) and all(e <= FLIPPED_L2 for e in norm_err.values()), \
+        "%s: %d flipped mask(s), worst %s %s" % (test, flips, worst, errs[worst])
 
 
 def test_flat2d_train_and_eval(dev, golden):

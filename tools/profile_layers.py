@@ -22,7 +22,8 @@ def main():
     net = modules.resnet50(num_classes=8)
     net.load_state_dict(synth.state_dict("resnet50", 8, 12, seed=2))
     net = net.to(dev)
-    net.set_compute_dtype(args.dtype)
+    if args.dtype != "fp32":
+        net.set_compute_dtype(args.dtype)
     net.train()
     net.freeze_bn()
     net.use_flat_gradients()
@@ -46,7 +47,7 @@ def main():
     prof.ACTIVE = None
     tot = sum(a["ms_total"] for _, a in rows) / args.steps
     print("%-64s %6s %9s %9s" % ("kernel / shape (N x Ho x Wo Cin->Cout)", "n/step", "ms/step", "TFLOP/s"))
-    for k, a in rows[:45]:
+    for k, a in rows[:60]:
         print("%-64s %6d %9.3f %9.1f" % (k, a["launches"] // args.steps, a["ms_total"] / args.steps,
                                          a["work_total"] / (a["ms_total"] * 1e-3) / 1e12 if a["ms_total"] else 0))
     print("total timed %.2f ms/step" % tot)
