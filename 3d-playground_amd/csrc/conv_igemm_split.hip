@@ -4,21 +4,24 @@
 // choose between the two (rn_fp32_split()).  Kept in its own translation unit: every instance of the force-inlined tile
 // costs compile time and memory.
 //
+// K-step: 16, like the fp32 form.  32 (template parameter BK; two MFMA steps per barrier, 64-80 KB of LDS, two workgroups per CU)
+// was measured on the training step: 87.5 against 89.3 images/s on the same GPU, and no layer shape gained in isolation.
+//
 // Register budget: the fragments (32 floats), their splits (48 registers) and the 64 accumulators do not fit the 128
 // registers four workgroups per CU leave, so these kernels run three per CU (168 registers, 34-41 KB of LDS each).
 #include "conv_igemm_tile.h"
 
-template <int WM, int WN, bool GENERAL, bool RELU, bool RAW, int SPLIT>
-__global__ __launch_bounds__(256, 3) void conv_igemm_split_kernel(const rn_conv_desc d, const float *__restrict__ x,
+template <int WM, int WN, bool GENERAL, bool RELU, bool RAW, int SPLIT, int BK = 16>
+__global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                                   const float *__restrict__ w, float *__restrict__ y,
                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
                                                                   const float *__restrict__ add, const float *__restrict__ mask,
                                                                   const float *__restrict__ add2) {
-    conv_igemm_tile<WM, WN, GENERAL, 16, RELU, RAW, SPLIT>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_igemm_tile<WM, WN, GENERAL, BK, RELU, RAW, SPLIT>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-template <int WM, int WN, int SPLIT>
-__global__ __launch_bounds__(256, 3) void conv_igemm_split_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
+template <int WM, int WN, int SPLIT, int BK = 16>
+__global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
                                                                           const float *__restrict__ scale,
                                                                           const float *__restrict__ shift) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_split_grouped_kernel(const 
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_igemm_tile<WM, WN, true, 16, false, false, SPLIT>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_igemm_tile<WM, WN, true, BK, false, false, SPLIT>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // variant: the instance conv_igemm.hip's launcher chose -- 0 raw GEMM, 1 input ReLU, 2 / 3 narrow dense / general,

@@ -115,10 +115,11 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
     constexpr int RPI = 64 / CPK;                          // rows one wave instruction fills
+    constexpr int SUB = BK / 16;                           // split forms: 16-wide MFMA steps per staged K-step
     constexpr int BPL = BN * 8;                            // SPLIT 2: floats' worth of one bf16 plane of the B tile (BN rows x 32 bytes)
-    constexpr int NBI = 3 * BN / 32;                       // SPLIT 2: wave instructions that fill the three planes
+    constexpr int NBI = SUB * 3 * BN / 32;                 // SPLIT 2: wave instructions that fill the planes: (sub-step, plane, 32 rows)
     constexpr int IA = BM / RPI / 4, IB = SPLIT == 2 ? (NBI + 3) / 4 : BN / RPI / 4;    // instructions per wave per K-step and operand
-    constexpr int STEP = SPLIT == 2 ? BM * BK + 3 * BPL : (BM + BN) * BK;   // floats per buffer: A rows, then B rows (planes)
+    constexpr int STEP = SPLIT == 2 ? BM * BK + SUB * 3 * BPL : (BM + BN) * BK;   // floats per buffer: A rows, then B rows (planes)
     constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
 #ifndef RN_SPLIT_NBUF
 #define RN_SPLIT_NBUF 2
@@ -189,9 +190,9 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     for (int j = 0; j < IB; ++j) {
         if constexpr (SPLIT == 2) {
             // instruction q fills 32 rows of one plane: lane -> (row, position), fetches chunk position ^ ((row >> 4) & 1)
-            const int q = wave * IB + j, plane = q / (BN / 32), row = (q % (BN / 32)) * 32 + (lane >> 1);
+            const int q = wave * IB + j, sub = q / (3 * BN / 32), plane = (q / (BN / 32)) % 3, row = (q % (BN / 32)) * 32 + (lane >> 1);
             const int n = n0 + row;
-            b_voff[j] = (q < NBI && n < d.Cout) ? (unsigned)(n * Kpad * 6 + plane * 32 + (((lane & 1) ^ ((row >> 4) & 1)) << 4)) : 0x80000000u;
+            b_voff[j] = (q < NBI && n < d.Cout) ? (unsigned)(n * Kpad * 6 + sub * 96 + plane * 32 + (((lane & 1) ^ ((row >> 4) & 1)) << 4)) : 0x80000000u;
         } else {
             const int row = (wave * IB + j) * RPI + rsub;
             const int n = n0 + row;
@@ -221,7 +222,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
         for (int j = 0; j < IB; ++j) {
             if constexpr (SPLIT == 2) {
-                if (wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BM * BK) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 96));
+                if (wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BM * BK) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * SUB * 96));
             } else {
                 dma16(rs_b, B + j * (RPI * BK * 4), b_voff[j], (unsigned)(ks * BK * 4));
             }
@@ -275,7 +276,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         for (int st = 0; st < BK / 8; ++st) {
             const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
             // split forms: a lane's eight k are CONSECUTIVE (chunks 2g, 2g + 1: the order of a pre-split record's half)
-            const int ch = SPLIT ? 2 * (lane >> 5) + st : 2 * st + (lane >> 5);
+            const int ch = SPLIT ? 4 * (st >> 1) + 2 * (lane >> 5) + (st & 1) : 2 * st + (lane >> 5);
             fa[t][st] = ra * BK + 4 * (ch ^ lds_swz<BK>(ra));
             fb[t][st] = BM * BK + rb * BK + 4 * (ch ^ lds_swz<BK>(rb));
         }
@@ -287,49 +288,35 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     }
     auto multiply = [&](int buf) {
         const float *S = lds + buf * STEP;
-        if constexpr (SPLIT == 2) {
-            static_assert(SPLIT != 2 || BK == 16, "split-operand form: K-step 16");
-            Split8 sa[2], sb[2];
+        if constexpr (SPLIT != 0) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][0]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][1]);
-                float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-                if (RELU) {
+            for (int sub = 0; sub < SUB; ++sub) {
+                Split8 sa[2], sb[2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                for (int t = 0; t < 2; ++t) {
+                    const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub + 1]);
+                    float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                    if (RELU) {                             // input ReLU, on the fragments
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                    }
+                    sa[t] = split8(av);
+                    if constexpr (SPLIT == 2) {
+                        const float *Bp = S + fbs[t] + sub * 3 * BPL;
+                        sb[t].h = *reinterpret_cast<const bf16x8 *>(Bp);
+                        sb[t].m = *reinterpret_cast<const bf16x8 *>(Bp + BPL);
+                        sb[t].l = *reinterpret_cast<const bf16x8 *>(Bp + 2 * BPL);
+                    } else {
+                        const float4 q0 = *reinterpret_cast<const float4 *>(S + fb[t][2 * sub]), q1 = *reinterpret_cast<const float4 *>(S + fb[t][2 * sub + 1]);
+                        const float bv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                        sb[t] = split8(bv);
+                    }
                 }
-                sa[t] = split8(av);
-                sb[t].h = *reinterpret_cast<const bf16x8 *>(S + fbs[t]);
-                sb[t].m = *reinterpret_cast<const bf16x8 *>(S + fbs[t] + BPL);
-                sb[t].l = *reinterpret_cast<const bf16x8 *>(S + fbs[t] + 2 * BPL);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
             }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
-            return;
-        }
-        if constexpr (SPLIT == 1) {
-            // a lane's eight k of a 16-wide step: k = 8g .. 8g + 7 (g = lane >> 5), the same for A and B
-            static_assert(SPLIT != 1 || BK == 16, "split-operand form: K-step 16");
-            Split8 sa[2], sb[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][0]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][1]);
-                const float4 q0 = *reinterpret_cast<const float4 *>(S + fb[t][0]), q1 = *reinterpret_cast<const float4 *>(S + fb[t][1]);
-                float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-                const float bv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                if (RELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
-                }
-                sa[t] = split8(av);
-                sb[t] = split8(bv);
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
             return;
         }
 #pragma unroll
