@@ -39,6 +39,13 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsi
 
 __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
     u32x4 hh, mm, ll;
+#if defined(RN_SPLIT_ABL) && RN_SPLIT_ABL == 1                 // knock-out (timing only, wrong results): no vector ALU work
+    Split8 k;
+    k.h = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])});
+    k.m = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, x[4]), __builtin_bit_cast(unsigned, x[5]), __builtin_bit_cast(unsigned, x[6]), __builtin_bit_cast(unsigned, x[7])});
+    k.l = k.h;
+    return k;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         unsigned a, b, c;
@@ -66,6 +73,13 @@ __device__ __forceinline__ void split_store_chunk(const float *__restrict__ src,
 }
 
 // acc += a * b for one 32x32 tile and 16 values of k: the six products, smallest first.
+#if defined(RN_SPLIT_ABL) && RN_SPLIT_ABL == 2                 // knock-out (timing only, wrong results): one MFMA of the six
+#define RN_SPLIT_MFMA(ACC, A, B)                                                          \
+    do {                                                                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).l, (B).h, ACC, 0, 0, 0);        \
+        ACC[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, (A).h)[0] ^ __builtin_bit_cast(u32x4, (A).m)[1] ^ __builtin_bit_cast(u32x4, (B).m)[2] ^ __builtin_bit_cast(u32x4, (B).l)[3]) * 1e-30f; \
+    } while (0)
+#else
 #define RN_SPLIT_MFMA(ACC, A, B)                                                          \
     do {                                                                                  \
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).l, (B).h, ACC, 0, 0, 0);        \
@@ -75,3 +89,4 @@ __device__ __forceinline__ void split_store_chunk(const float *__restrict__ src,
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).h, (B).m, ACC, 0, 0, 0);        \
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
     } while (0)
+#endif
