@@ -15,13 +15,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "3d-playground_amd"))
 from retinanet_mi355x import conv as cv  # noqa: E402
 
-SHAPES = [  # name, cin, cout, k, stride, pad, N, H, W
-    ("3x3 256->256 (K 2304)", 256, 256, 3, 1, 1, 1, 68, 120),
-    ("3x3 512->512 (K 4608)", 512, 512, 3, 1, 1, 1, 34, 60),
-    ("1x1 1024->256", 1024, 256, 1, 1, 0, 1, 68, 120),
-    ("1x1 64->256", 64, 256, 1, 1, 0, 1, 135, 240),
-    ("3x3 64->64", 64, 64, 3, 1, 1, 1, 135, 240),
-    ("3x3 s2 128->128", 128, 128, 3, 2, 1, 1, 136, 240),
+SHAPES = [  # name, cin, cout, k, stride, pad, N, H, W   (large enough that none takes the split-K path, which stays on the fp32 MFMA)
+    ("3x3 256->256 (K 2304)", 256, 256, 3, 1, 1, 4, 68, 120),
+    ("3x3 512->512 (K 4608)", 512, 512, 3, 1, 1, 8, 34, 60),
+    ("1x1 1024->256", 1024, 256, 1, 1, 0, 4, 68, 120),
+    ("1x1 256->1024", 256, 1024, 1, 1, 0, 4, 68, 120),
+    ("3x3 64->64", 64, 64, 3, 1, 1, 2, 135, 240),
+    ("3x3 s2 128->128", 128, 128, 3, 2, 1, 4, 136, 240),
+    ("7x7 s2 4->64 (stem)", 4, 64, 7, 2, 3, 2, 270, 480),
 ]
 
 
@@ -38,6 +39,20 @@ def err(got, want):
     return float(d.max() / want.abs().max()), float(d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
 
 
+def conv64(x, w, gy, stride, pad):
+    """fp64 convolution, data gradient and weight gradient as unfold + matmul + fold (rocBLAS dgemm; MIOpen's fp64 convolution
+    takes minutes at these sizes)."""
+    N, cin, H, W = x.shape
+    cout, _, k, _ = w.shape
+    cols = F.unfold(x.double(), k, padding=pad, stride=stride)              # [N, cin*k*k, L]
+    wm = w.double().view(cout, -1)
+    y = (wm @ cols).view(N, cout, gy.shape[2], gy.shape[3])
+    g = gy.double().view(N, cout, -1)
+    dx = F.fold(wm.t() @ g, (H, W), k, padding=pad, stride=stride)
+    dw = torch.einsum("ncl,nkl->ck", g, cols).view_as(w)
+    return y, dx, dw
+
+
 def main():
     dev = torch.device("cuda:0")
     torch.backends.cudnn.allow_tf32 = False
@@ -49,9 +64,7 @@ def main():
         w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dev)
         Ho, Wo = cv.out_size(H, k, stride, pad), cv.out_size(W, k, stride, pad)
         gy = torch.randn(N, cout, Ho, Wo, generator=g).to(dev)
-        xd, wd_ = x.double().requires_grad_(True), w.double().requires_grad_(True)
-        yd = F.conv2d(xd, wd_, stride=stride, padding=pad)
-        yd.backward(gy.double())
+        yd, dxd, dwd = conv64(x, w, gy, stride, pad)
         xt, wt = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
         yt = F.conv2d(xt, wt, stride=stride, padding=pad)
         yt.backward(gy)
@@ -68,12 +81,24 @@ def main():
             dw = torch.zeros_like(wp)
             cv.wgrad(nhwc(gy), nhwc(x), dw, cout, k, stride, pad)
             dwu = cv.unpack_wgrad(dw, wp, tuple(w.shape))[0]
-            res[mode] = (err(nchw(y), yd.detach()), err(nchw(dx), xd.grad), err(dwu, wd_.grad))
-        res["torch"] = (err(yt.detach(), yd.detach()), err(xt.grad, xd.grad), err(wt.grad, wd_.grad))
+            res[mode] = (err(nchw(y), yd), err(nchw(dx), dxd), err(dwu, dwd))
+        res["torch"] = (err(yt.detach(), yd), err(xt.grad, dxd), err(wt.grad, dwd))
         for i, what in enumerate(("fprop", "dgrad", "wgrad")):
             print("%-24s %-6s %s" % (name if i == 0 else "", what, "   ".join(
                 "%.2e / %.2e" % res[m][i] for m in ("native", "split", "torch"))))
-    cv.set_fp32_mfma("native")
+    # the Winograd path (transforms in fp32, its 36 GEMMs in the mode under test)
+    x = torch.randn(2, 256, 68, 120, generator=g).to(dev)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * (2.0 / 2304) ** 0.5).to(dev)
+    yd = conv64(x, w, torch.zeros(2, 256, 68, 120, device=dev), 1, 1)[0]
+    yt = F.conv2d(x, w, padding=1)
+    row = []
+    for mode in ("native", "split"):
+        cv.set_fp32_mfma(mode)
+        y = cv.wino_conv_group([nhwc(x)], cv.wino_weights(w, 0))[0]
+        row.append(err(nchw(y), yd))
+    row.append(err(yt, yd))
+    print("%-24s %-6s %s" % ("Winograd F(4x4,3x3) 256->256", "fprop", "   ".join("%.2e / %.2e" % r for r in row)))
+    cv.set_fp32_mfma("split")
 
 
 if __name__ == "__main__":
