@@ -21,6 +21,10 @@ echo "traffic done"
 timeout -k 10 300 python3 tools/bench_loss.py > "$O/loss_microbench.txt" 2>&1
 timeout -k 10 300 python3 tools/bench_conv_bf16.py > "$O/conv_bf16_microbench.txt" 2>&1
 timeout -k 10 300 python3 tools/profile_layers.py > "$O/bf16_step_by_shape.txt" 2>&1
+timeout -k 10 300 python3 tools/bench_conv.py --mfma native > "$O/conv_microbench_native.txt" 2>&1
+timeout -k 10 300 python3 tools/bench_conv.py --mfma split > "$O/conv_microbench_split.txt" 2>&1
 timeout -k 10 300 python3 tools/bench_infer.py > "$O/infer_cfg4.txt" 2>&1
+timeout -k 10 300 python3 tools/bench_infer.py --dtype bf16 >> "$O/infer_cfg4.txt" 2>&1
+RN_FP32_MFMA=native timeout -k 10 300 python3 tools/bench_infer.py >> "$O/infer_cfg4.txt" 2>&1
 timeout -k 10 500 bash tools/rehearse_ddp.sh > "$O/ddp_rehearsal.txt" 2>&1
 echo "all done"
