@@ -7,6 +7,10 @@
 // K-step: 16, like the fp32 form.  32 (template parameter BK; two MFMA steps per barrier, 64-80 KB of LDS, two workgroups per CU)
 // was measured on the training step: 87.5 against 89.3 images/s on the same GPU, and no layer shape gained in isolation.
 //
+// One tile per workgroup, also for the plain GEMMs of the Winograd layers (thousands of 16-step tiles per launch): letting a
+// workgroup run 2 / 4 consecutive tiles, so that a tile's stores drain under the next one's set-up, measured 87.6 / 86.3 against
+// 88.1 images/s.
+//
 // Register budget: the fragments (32 floats), their splits (48 registers) and the 64 accumulators do not fit the 128
 // registers four workgroups per CU leave, so these kernels run three per CU (168 registers, 34-41 KB of LDS each).
 #include "conv_igemm_tile.h"

@@ -24,7 +24,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "3d-playground_amd"))
 import homography as hgm  # noqa: E402
 import mc3d_post  # noqa: E402
-from retinanet_mi355x import modules, synth  # noqa: E402
+from retinanet_mi355x import conv as cv, modules, synth  # noqa: E402
 
 H, W = 1080, 1920
 
@@ -115,7 +115,8 @@ def main():
             kept, parsed = kept + a, parsed + b
         return kept, parsed
 
-    print("%d cameras, %d per call, ResNet-50 (%s), %dx%d uint8 frames from pinned host memory" % (args.cams, args.batch, args.dtype, W, H))
+    label = args.dtype if args.dtype != "fp32" else "fp32, %s products" % cv.get_fp32_mfma()
+    print("%d cameras, %d per call, ResNet-50 (%s), %dx%d uint8 frames from pinned host memory" % (args.cams, args.batch, label, W, H))
     for label, pipelined in (("one stream (upload, then detect)", False), ("two streams (upload k+1 under detect k)", True)):
         time_step(pipelined)
         torch.cuda.synchronize()
