@@ -7,11 +7,14 @@
 // products, every one of them exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the kernels issue the six
 // largest,
 //        a*b  ~=  ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm,
-// and drop am*bl, al*bm, al*bl: with |m| <= 2^-9 |x| and |l| <= 2^-18 |x| those are below 2^-26 |a*b| -- a quarter of the
-// 2^-24 |acc| rounding every fp32 accumulation step makes anyway, so the result is an fp32 computation in the same sense
-// as the v_mfma_f32_32x32x2_f32 kernels are (DESIGN.md 4.6 holds the measured errors of both against fp64).  Six bf16
+// and drop am*bl, al*bm, al*bl.  With |m| <= 2^-8 |x| and |l| <= 2^-16 |x| (round to nearest at each level) the dropped terms
+// are at most 2^-23 |a*b| and 2^-25 |a*b| in the root mean square over random operands -- the size of the rounding an fp32
+// accumulation step makes anyway (2^-24 |acc|), and the v_mfma_f32_32x32x16_bf16 adds its sixteen exact products before it
+// rounds into the accumulator where the fp32 MFMA rounds after every two.  Measured against fp64 the results are as accurate
+// as those of the v_mfma_f32_32x32x2_f32 kernels or slightly better (DESIGN.md 4.6 has the table for both modes).  Six bf16
 // MFMAs of K = 16 take 6 x 32 cycles where eight fp32 MFMAs of K = 2 take 8 x 64: 2.7x the matrix rate, paid for with the
-// vector ALU work below (4.5 instructions per element), which is what bounds the kernels that use it.
+// vector ALU work below (4.5 instructions per element, the conversions and packed subtractions at half rate), which is what
+// bounds the kernels that use it.
 //
 // Not IEEE in the corners: an infinite or NaN operand gives NaN (inf - inf in the residual), and residuals below the
 // bf16 normal range are flushed by the matrix core.

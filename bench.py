@@ -452,7 +452,7 @@ def main():
         if args.dtype == "fp32":
             line["config"]["fp32_products"] = (
                 "split operands: every fp32 operand as three bf16 terms (h + m + l == x exactly), six v_mfma_f32_32x32x16_bf16 "
-                "products per block into the fp32 accumulator, dropped terms < 2^-26 of a product; operands, accumulation, "
+                "products per block into the fp32 accumulator, dropped terms <= 2^-23 of a product (2^-25 rms); operands, accumulation, "
                 "epilogues, gradients and optimizer fp32; measured errors against fp64 equal to the fp32 MFMA kernels' "
                 "(DESIGN.md 4.6, profiles/r02_fp32_split_errors.txt); fp32_native_mfma below = the same step on v_mfma_f32_32x32x2_f32"
                 if split else "v_mfma_f32_32x32x2_f32")

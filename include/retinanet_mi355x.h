@@ -268,8 +268,8 @@ typedef struct rn_conv_desc {
  *   RN_FP32_NATIVE  v_mfma_f32_32x32x2_f32 (157 TF peak).
  *   RN_FP32_SPLIT   each fp32 operand is split in registers into three bf16 terms h + m + l (exactly equal to it) and a
  *                   product is the sum of the six largest of the nine term products on v_mfma_f32_32x32x16_bf16 with the
- *                   fp32 accumulator; the three dropped terms are below 2^-26 of the product, a quarter of one fp32
- *                   rounding (csrc/mfma_split.h; DESIGN.md 4.6 has the measured errors of both modes against fp64).
+ *                   fp32 accumulator; the three dropped terms are at most 2^-23 of the product (2^-25 rms), the size of
+ *                   one fp32 rounding (csrc/mfma_split.h; DESIGN.md 4.6 has the measured errors of both modes against fp64).
  * Process-wide; initial value from the environment variable RN_FP32_MFMA = native | split, else RN_FP32_DEFAULT. */
 #define RN_FP32_NATIVE 0
 #define RN_FP32_SPLIT 1

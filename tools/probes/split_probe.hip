@@ -1,5 +1,5 @@
 // Probe for the split-operand fp32 GEMM idea: x (fp32) = h + m + l with h, m, l bf16 (RNE of the running residual), and
-// a*b ~= ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm on v_mfma_f32_32x32x16_bf16 (dropped terms <= 2^-25 |ab|).
+// a*b ~= ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm on v_mfma_f32_32x32x16_bf16 (dropped terms <= 2^-23 |ab|, 2^-25 rms).
 // Measures cycles per K=16 step of a 64x64 wave tile (4 fragments of 8 floats from LDS, split, 24 MFMAs) against the
 // same loop with (a) 24 MFMAs and no split, (b) the 32 fp32 MFMAs 32x32x2 of the native kernel; and checks that the
 // v_dot2c_f32_bf16 form of the residual is exact.
