@@ -233,6 +233,22 @@ def native_section(dev, args, B, H, W):
                 tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12
                 out[kind] = {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TF, 4),
                              "ms_per_step": round(a["ms_total"] / 2, 2)}
+        # north_star's forward target on the fp32 MFMA: conv kernels of forward-only passes, DIRECT kernels everywhere
+        eng = net._engine
+        wino_was, eng.use_wino = eng.use_wino, False
+        t = prof.ACTIVE = prof.KernelTimer()
+        with torch.no_grad():
+            for _ in range(3):
+                net([img, ann])
+        fs = t.summary().values()
+        prof.ACTIVE = None
+        eng.use_wino = wino_was
+        fwork, fms = sum(a["work_total"] for a in fs), sum(a["ms_total"] for a in fs)
+        if fms > 0:
+            ftf = fwork / (fms * 1e-3) / 1e12
+            out["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                                    "frac": round(ftf / PEAK_F32_MFMA_TF, 4), "ms_per_pass": round(fms / 3, 2),
+                                    "gflop_per_image": round(fwork / 3 / B / 1e9, 1)}
         return out
     finally:
         prof.ACTIVE = None
