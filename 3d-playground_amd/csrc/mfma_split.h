@@ -26,7 +26,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct Split8 { bf16x8 h, m, l; };
 
-// Two values at a time: one v_cvt_pk_bf16_f32 per level, the residuals by shift / mask + one packed subtraction.
+// Two values at a time: one v_cvt_pk_bf16_f32 for h and for m, the residuals by shift / mask + one packed subtraction.
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     const bf16x2 hp = {(__bf16)x0, (__bf16)x1};
     h = __builtin_bit_cast(unsigned, hp);
@@ -36,8 +36,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsi
     m = __builtin_bit_cast(unsigned, mp);
     const float s0 = r0 - __builtin_bit_cast(float, m << 16);
     const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-    const bf16x2 lp = {(__bf16)s0, (__bf16)s1};
-    l = __builtin_bit_cast(unsigned, lp);
+    // the last residual has at most 8 significant bits (x has 24, h and m took 8 each): its bf16 is its upper half, one
+    // v_perm_b32 for the pair instead of a half-rate conversion
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
 }
 
 __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
