@@ -474,3 +474,17 @@ def test_presplit_operand_is_refused_in_native_mode(cv, dev):
     d = _hip.ConvDesc(1, 8, 8, 16, 8, 8, 32, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 8, 8, 0, 0, 0, 0, 8 * 8 * 16, 8 * 8 * 32, 8 * 8 * 32, 0, 1)
     rc = _hip.load().rn_conv_igemm(ctypes.byref(d), x.data_ptr(), wp._rn_split.data_ptr(), y.data_ptr(), None, None, None, None, None, _hip.stream())
     assert rc != 0
+
+
+def test_product_mode_follows_the_environment(dev):
+    """RN_FP32_MFMA selects the library's initial mode (include/retinanet_mi355x.h); without it: RN_FP32_DEFAULT = split."""
+    import os
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from retinanet_mi355x import conv; print(conv.get_fp32_mfma())" % os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-playground_amd")
+    for env, want in (({"RN_FP32_MFMA": "native"}, "native"), ({"RN_FP32_MFMA": "split"}, "split"), ({}, "split")):
+        e = {k: v for k, v in os.environ.items() if k != "RN_FP32_MFMA"}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.stdout.strip().splitlines()[-1] == want, (env, out.stdout, out.stderr[-500:])
