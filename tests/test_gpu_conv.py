@@ -488,3 +488,29 @@ def test_product_mode_follows_the_environment(dev):
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
         assert out.stdout.strip().splitlines()[-1] == want, (env, out.stdout, out.stderr[-500:])
+
+
+def test_wide_dynamic_range_elementwise(cv, dev):
+    """Positive operands spread over 17 decades (no cancellation): EVERY output, gradient and weight-gradient element within 1e-5
+    RELATIVE of fp64 -- in split mode this holds only if the three terms of an operand really add up to it and the dropped
+    products are as small as csrc/mfma_split.h says (a two-term split would sit at 4e-6 per product, a bf16 product at 4e-3)."""
+    g = torch.Generator().manual_seed(3)
+    N, H, W, cin, cout = 2, 24, 40, 512, 256
+    x = torch.exp((torch.rand(N, cin, H, W, generator=g) - 0.5) * 40).float()
+    w = torch.exp((torch.rand(cout, cin, 1, 1, generator=g) - 0.5) * 40).float()
+    gy = torch.exp((torch.rand(N, cout, H, W, generator=g) - 0.5) * 40).float()
+    xd, wd = x.double(), w.double().view(cout, cin)
+    y_ref = torch.einsum("oc,nchw->nohw", wd, xd)
+    dx_ref = torch.einsum("oc,nohw->nchw", wd, gy.double())
+    dw_ref = torch.einsum("nohw,nchw->oc", gy.double(), xd)
+    finite = lambda t: bool(torch.isfinite(t.float()).all())           # the references must fit fp32 for the comparison to mean anything
+    assert finite(y_ref) and finite(dx_ref) and finite(dw_ref)
+    wp, wdp = cv.pack_weights(w.to(dev), 0), cv.pack_weights(w.to(dev), 1)
+    y = cv.fprop(nhwc(x).to(dev), wp, cout, 1, 1, 0)
+    dx = cv.dgrad(nhwc(gy).to(dev), wdp, (H, W), cin, 1, 1, 0)
+    dw = torch.zeros_like(wp)
+    cv.wgrad(nhwc(gy).to(dev), nhwc(x).to(dev), dw, cout, 1, 1, 0)
+    dwu = cv.unpack_wgrad(dw, wp, tuple(w.shape))[0]
+    for got, ref in ((nchw(y), y_ref), (nchw(dx), dx_ref), (dwu.view(cout, cin), dw_ref)):
+        rel = ((got.cpu().double() - ref).abs() / ref.abs()).max()
+        assert float(rel) <= 1e-5, float(rel)

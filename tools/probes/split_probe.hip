@@ -290,6 +290,53 @@ __global__ __launch_bounds__(256, OCC) void staged_kernel(const float *src, floa
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+
+// MODE 7 / 8: the same loop with v_mfma_f32_16x16x32_bf16 (twice as many, half the cycles each) -- 7: no split, 8: with the split.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void loop16_kernel(const float *src, float *out, int iters) {
+    __shared__ float lds[2][4096];
+    for (int i = threadIdx.x; i < 8192; i += 256) (&lds[0][0])[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, g = lane >> 5;
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        float a[2][8], b[2][8];
+        read_frags(lds[it & 1], wave, r, g, a, b);
+        bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (MODE == 7) {
+                u32x4 q, p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { q[j] = __builtin_bit_cast(unsigned, a[t][2 * j]); p[j] = __builtin_bit_cast(unsigned, b[t][2 * j]); }
+                ah[t] = am[t] = al[t] = __builtin_bit_cast(bf16x8, q);
+                bh[t] = bm[t] = bl[t] = __builtin_bit_cast(bf16x8, p);
+            } else {
+                split8<1>(a[t], ah[t], am[t], al[t]);
+                split8<1>(b[t], bh[t], bm[t], bl[t]);
+            }
+        }
+        // 48 MFMAs of 16x16x32 = the FLOPs of 24 of 32x32x16 (operand shapes are immaterial to the timing)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tm = (q >> 1) & 1, tn = q & 1;
+            f32x4 &c0 = acc[2 * q], &c1 = acc[2 * q + 1];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[tm], bm[tn], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[tm], bh[tn], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bm[tn], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], c1, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // exactness: per element, h + m + l (as doubles) against x, both split forms; and the two forms against each other
 __global__ void exact_kernel(const float *x, unsigned *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,10 +381,10 @@ int main() {
     float *dout2; hipMalloc(&dout2, 4096 * 256 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 4000;
-    const char *names[7] = {"24 bf16 MFMAs, no split", "split (shift/and + v_pk_add)", "split (v_dot2c)", "32 fp32 MFMAs 32x32x2 (native)",
-                            "split, interleaved within the step", "split one step ahead, interleaved", "split one step ahead, hand-staged"};
+    const char *names[9] = {"24 bf16 MFMAs, no split", "split (shift/and + v_pk_add)", "split (v_dot2c)", "32 fp32 MFMAs 32x32x2 (native)",
+                            "split, interleaved within the step", "split one step ahead, interleaved", "split one step ahead, hand-staged", "48 bf16 MFMAs 16x16x32, no split", "48 bf16 MFMAs 16x16x32, split"};
     for (int wgs_per_cu = 1; wgs_per_cu <= 4; ++wgs_per_cu)
-        for (int mode = 0; mode < 7; ++mode) {
+        for (int mode = 0; mode < 9; ++mode) {
             if (mode == 2) continue;
             const int grid = 256 * wgs_per_cu;
             float ms = 0;
@@ -350,6 +397,8 @@ int main() {
                 if (mode == 4) hipLaunchKernelGGL((sched_kernel<4, 3>), dim3(grid), dim3(256), 0, 0, dx, dout2, iters);
                 if (mode == 5) hipLaunchKernelGGL((sched_kernel<5, 2>), dim3(grid), dim3(256), 0, 0, dx, dout2, iters);
                 if (mode == 6) hipLaunchKernelGGL((staged_kernel<2>), dim3(grid), dim3(256), 0, 0, dx, dout2, iters);
+                if (mode == 7) hipLaunchKernelGGL(loop16_kernel<7>, dim3(grid), dim3(256), 0, 0, dx, dout2, iters);
+                if (mode == 8) hipLaunchKernelGGL(loop16_kernel<8>, dim3(grid), dim3(256), 0, 0, dx, dout2, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms, e0, e1);
             }
