@@ -30,10 +30,14 @@ struct Split8 { bf16x8 h, m, l; };
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     const bf16x2 hp = {(__bf16)x0, (__bf16)x1};
     h = __builtin_bit_cast(unsigned, hp);
+    // (the empty asm pins the PACKED value: without it the compiler derives h << 16 from a second, single-value conversion of
+    // x0 -- seen in the weight-gradient kernel: 64 conversions per K-step instead of 32)
+    asm volatile("" : "+v"(h));
     const float r0 = x0 - __builtin_bit_cast(float, h << 16);
     const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
     const bf16x2 mp = {(__bf16)r0, (__bf16)r1};
     m = __builtin_bit_cast(unsigned, mp);
+    asm volatile("" : "+v"(m));
     const float s0 = r0 - __builtin_bit_cast(float, m << 16);
     const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
     // the last residual has at most 8 significant bits (x has 24, h and m took 8 each): its bf16 is its upper half, one
