@@ -91,6 +91,13 @@ class PrepJob(ctypes.Structure):
                 ("var", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp), ("bn_rstd", c_vp)]
 
 
+class UnpackJob(ctypes.Structure):
+    """rn_unpack_job of include/retinanet_mi355x.h."""
+    _fields_ = [("dw", c_vp), ("w_packed", c_vp), ("dweight", c_vp)] + \
+               [(n, c_i32) for n in ("Cout", "Cin", "kh", "kw", "kw_pad", "c_pad", "Kpad")] + \
+               [("scale", c_vp), ("mean", c_vp), ("rstd", c_vp), ("colsum", c_vp), ("dgamma", c_vp), ("dbeta", c_vp)]
+
+
 class WinoGroup(ctypes.Structure):
     """rn_wino_group of include/retinanet_mi355x.h."""
     _fields_ = [("n", c_i32), ("N", c_i32 * RN_MAX_GROUP), ("H", c_i32 * RN_MAX_GROUP), ("W", c_i32 * RN_MAX_GROUP),
@@ -99,6 +106,7 @@ class WinoGroup(ctypes.Structure):
 
 
 SIGNATURES.update({
+    "rn_unpack_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "rn_prep_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "rn_wino_input_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "rn_wino_output_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),

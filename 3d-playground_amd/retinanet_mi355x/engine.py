@@ -554,6 +554,34 @@ class Engine:
             out.append((jt, ct, len(chunks)))
         return {"key": key, "launches": out, "bufs": bufs}
 
+    def _unpack_bucket(self, index, layers, views):
+        """rn_unpack_batched over the layers of one bucket: accumulated packed gradients -> the parameters' slots of the flat
+        buffer.  The job table lives on the device and is rebuilt only when one of the pointers in it has changed."""
+        key = tuple((L.dw.data_ptr(), L.wf.data_ptr(), views[L.grad_names()[0]].data_ptr(), _hip.ptr(L.scale) or 0, _hip.ptr(L.mean) or 0)
+                    for L in layers)
+        cache = self.__dict__.setdefault("_unpack_tables", {})
+        hit = cache.get(index)
+        if hit is None or hit[0] != key:
+            jobs, chunks = [], []
+            for L in layers:
+                s, names = L.spec, L.grad_names()
+                cout, cin, kh, kw = L.weight.shape
+                j = _hip.UnpackJob()
+                j.dw, j.w_packed, j.dweight = L.dw.data_ptr(), L.wf.data_ptr(), views[names[0]].data_ptr()
+                j.Cout, j.Cin, j.kh, j.kw, j.kw_pad, j.c_pad, j.Kpad = cout, cin, kh, kw, L.kw_pad, L.cin_pad, L.wf.shape[1]
+                j.scale, j.mean, j.rstd, j.colsum = _hip.ptr(L.scale), _hip.ptr(L.mean), _hip.ptr(L.rstd), L.cs.data_ptr()
+                j.dgamma = views[names[1]].data_ptr() if s.bn else None
+                j.dbeta = views[names[-1]].data_ptr() if len(names) > 1 else None
+                chunks.extend((len(jobs), co) for co in range(cout))
+                jobs.append(j)
+            arr = (_hip.UnpackJob * len(jobs))(*jobs)
+            dev = layers[0].dw.device
+            hit = cache[index] = (key, torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev),
+                                  torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks))
+        _hip.check(_hip.load().rn_unpack_batched(hit[1].data_ptr(), hit[2].data_ptr(), hit[3], _hip.stream()), "rn_unpack_batched")
+        for L in layers:
+            L.dw = L.cs = L.wd = L.uf = L.ud = L.saved_v = None
+
     def _zero_grad_accumulators(self, device):
         """Weight-gradient and column-sum accumulators of every layer as views of ONE buffer, zeroed by one fill per step
         (they are atomically accumulated into: ~140 separate zero-fills per step otherwise)."""
@@ -674,13 +702,25 @@ class Engine:
             flat, views = self._flat_views(dreg.device)
             buckets = self._flat["buckets"]
 
+        # Flat buffer and no per-layer hook: the layers of a bucket are unpacked by ONE launch when the bucket's last layer
+        # retires (rn_unpack_batched) instead of one launch per layer.
+        batched = flat is not None and self.grad_hook is None and os.environ.get("RN_BATCHED_UNPACK", "1") != "0"
+        pending = []
+
         def done(layer):
             nonlocal next_bucket
-            g = layer.finish(views)
-            grads.update(g)
-            if self.grad_hook is not None:
-                self.grad_hook(g)
+            if batched:
+                pending.append(layer)
+                grads.update({n: views[n] for n in layer.grad_names()})
+            else:
+                g = layer.finish(views)
+                grads.update(g)
+                if self.grad_hook is not None:
+                    self.grad_hook(g)
             if flat is not None and layer.spec.name == buckets[next_bucket][2]:
+                if batched:
+                    self._unpack_bucket(next_bucket, pending, views)
+                    pending.clear()
                 if self.bucket_hook is not None:             # every gradient of this slice is final: release it
                     self.bucket_hook(next_bucket, flat[buckets[next_bucket][0]:buckets[next_bucket][1]])
                 next_bucket += 1

@@ -444,6 +444,18 @@ int rn_unpack_wgrad(const float *dw, const float *w_packed, float *dweight, int 
                     int kw_pad, int c_pad, const float *scale, const float *mean, const float *rstd,
                     const float *colsum, float *dgamma, float *dbeta, void *stream);
 
+/* rn_unpack_wgrad for many layers in one launch.  jobs_dev: device array of rn_unpack_job (the arguments of rn_unpack_wgrad; Kpad
+ * = roundup(kh*kw_pad*c_pad, 32)); chunks_dev: device array of nchunks (job index, output channel) pairs -- every output
+ * channel of every job exactly once.  The engine issues one per all-reduce bucket (or one per backward pass). */
+typedef struct rn_unpack_job {
+    const float *dw, *w_packed;
+    float *dweight;
+    int Cout, Cin, kh, kw, kw_pad, c_pad, Kpad;
+    const float *scale, *mean, *rstd, *colsum;
+    float *dgamma, *dbeta;
+} rn_unpack_job;
+int rn_unpack_batched(const rn_unpack_job *jobs_dev, const int32_t *chunks_dev, int nchunks, void *stream);
+
 /* Frozen batch-norm folding (eval-mode BatchNorm2d, eps 1e-5, D/model.py:278-282):
  *   scale = gamma / sqrt(var + eps), shift = beta - mean*scale, rstd = 1/sqrt(var + eps). */
 int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
