@@ -208,7 +208,7 @@ def _wino_workspace(device, floats_v, floats_m):
 
 
 def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
-                    flops=0.0, keep_v=False, y_batch_stride=0):
+                    flops=0.0, keep_v=False, y_batch_stride=0, V_in=None):
     """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
     [36, Cout, Kpad]: one grouped input transform into V, ONE batched GEMM launch, one grouped output transform with
     the epilogue (outs: dense tensors, or slices with y_batch_stride).  Returns the outputs (and, with keep_v, the
@@ -221,10 +221,15 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     T = sum(tiles)
     Tpad = (T + 255) // 256 * 256
     V, M = _wino_workspace(dev, 0 if keep_v else 36 * Tpad * C, 36 * Tpad * cout)
-    if keep_v:                                       # the caller keeps B^T d B of the inputs for the weight gradient
+    shapes = tuple(tuple(x.shape) for x in xs)
+    reuse = keep_v and V_in is not None and V_in[1] == shapes and V_in[0].numel() == 36 * Tpad * C   # (V, shapes) of the same inputs
+    if reuse:
+        V = V_in[0]
+    elif keep_v:                                     # the caller keeps B^T d B of the inputs for the weight gradient
         V = torch.empty(36 * Tpad * C, dtype=torch.float32, device=dev)
     assert all(x.is_contiguous() for x in xs)
-    _wino_transform_in(xs, V, C, Tpad, 0)
+    if not reuse:
+        _wino_transform_in(xs, V, C, Tpad, 0)
     # rows past T hold whatever the scratch tensor held: they produce rows of M nobody reads
     Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
     Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)

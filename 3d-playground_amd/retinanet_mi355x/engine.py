@@ -145,9 +145,10 @@ class Layer:
                       y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo))
         return out
 
-    def fwd_group(self, xs, act=cv.ACT_NONE, outs=None, y_batch_stride=None, wino=False):
+    def fwd_group(self, xs, act=cv.ACT_NONE, outs=None, y_batch_stride=None, wino=False, shared_v=None):
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
-        (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only)."""
+        (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only).  shared_v: the kept
+        input transform of ANOTHER layer that read the same xs (both towers' conv1 read the pyramid): reused, not recomputed."""
         s = self.spec
         if self.bf16:                                  # the levels of a head layer as one grouped bf16 launch
             probs, ys, fl = [], [], 0.0
@@ -163,7 +164,7 @@ class Layer:
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
             r = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift, act=act, flops=fl,
-                                   keep_v=self.keep_v, y_batch_stride=y_batch_stride or 0)
+                                   keep_v=self.keep_v, y_batch_stride=y_batch_stride or 0, V_in=shared_v if self.keep_v else None)
             ys, self.saved_v = r if self.keep_v else (r, None)
             return ys
         probs, ys, fl = [], [], 0.0
@@ -668,7 +669,10 @@ class Engine:
             ts = pyramid
             acts = []                                                     # acts[i][level]
             for i in range(1, 5):                                         # one launch per tower conv, all 5 levels
-                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16)
+                first = Ls["regressionModel.conv1"]                       # both towers' conv1 transform the same pyramid: once
+                shared = first.saved_v if (i == 1 and prefix == "classificationModel") else None
+                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16,
+                                                             shared_v=shared)
                 acts.append(ts)
             views, off = [], 0
             for cnt in counts:
