@@ -466,12 +466,19 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
     unsigned long long removed = 0ull;
     int nkeep = 0;
     const int chunks = (n + 63) / 64;
+    // The diagonal word of a chunk's rows depends on nothing the scan computes: it is fetched one chunk ahead, so that of the
+    // two global-memory round trips a chunk used to pay in sequence (diagonal, then the kept rows) only the second remains.
+    auto diag_of = [&](int c) -> unsigned long long {
+        const int row = c * 64 + t;
+        return (t < 64 && c < chunks && row < n) ? mask[(int64_t)row * words + c] : 0ull;
+    };
+    unsigned long long diag_next = diag_of(0);
     for (int c = 0; c < chunks; ++c) {
+        const unsigned long long diag = diag_next;
+        diag_next = diag_of(c + 1);
         s_removed[t] = removed;
         __syncthreads();
         if (t < 64) {
-            const int row = c * 64 + t;
-            const unsigned long long diag = row < n ? mask[(int64_t)row * words + c] : 0ull;
             unsigned long long cur = s_removed[c];
             unsigned long long kb = 0ull;
             const int lim = (n - c * 64) < 64 ? (n - c * 64) : 64;
@@ -489,14 +496,23 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
         const unsigned long long kb = s_keepbits;
         nkeep += __popcll(kb);
         if (t > c && t < words) {
-            unsigned long long acc = 0ull;
+            // the kept rows' words, four loads in flight at a time
+            unsigned long long a0 = 0ull, a1 = 0ull, a2 = 0ull, a3 = 0ull;
             unsigned long long bits = kb;
             while (bits) {
-                const int r = __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                acc |= mask[(int64_t)(c * 64 + r) * words + t];
+                int r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    r[k] = bits ? __ffsll((long long)bits) - 1 : -1;
+                    bits &= bits - 1;                         // (0 stays 0)
+                }
+                const unsigned long long v0 = mask[(int64_t)(c * 64 + r[0]) * words + t];
+                const unsigned long long v1 = r[1] >= 0 ? mask[(int64_t)(c * 64 + r[1]) * words + t] : 0ull;
+                const unsigned long long v2 = r[2] >= 0 ? mask[(int64_t)(c * 64 + r[2]) * words + t] : 0ull;
+                const unsigned long long v3 = r[3] >= 0 ? mask[(int64_t)(c * 64 + r[3]) * words + t] : 0ull;
+                a0 |= v0; a1 |= v1; a2 |= v2; a3 |= v3;
             }
-            removed |= acc;
+            removed |= (a0 | a1) | (a2 | a3);
         }
         __syncthreads();
     }
