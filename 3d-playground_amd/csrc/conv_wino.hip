@@ -110,7 +110,12 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int h = h0 + i;
+#ifdef RN_WINO_ABL       // knock-out (timing only, wrong results): no halo loads.  Measured on the head-tower group: 0.249 -> 0.227 ms,
+                         // i.e. the 2.25x re-reads through L2 cost 9 %; the rest is the HBM stream itself (1.17 GB at 5.1 TB/s)
+            const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && i >= 1 && i <= 4 && j >= 1 && j <= 4;
+#else
             const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+#endif
             d[i] = ok ? *reinterpret_cast<const float4 *>(xb + ((int64_t)h * W + w) * C) : f4(0.f);
         }
         bt6(d, o);
