@@ -198,12 +198,14 @@ def _wino_transform_in(xs, V, C, Tpad, dy_form):
 
 
 def _wino_workspace(device, floats_v, floats_m):
-    """V and M of the Winograd path: two scratch tensors per device, grown on demand and reused by every layer."""
-    ws = _WINO_WS.get(device)
+    """V and M of the Winograd path: two scratch tensors per device AND stream (layers launched on different streams run
+    concurrently), grown on demand and reused by every layer of that stream."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WINO_WS.get(key)
     if ws is None or ws[0].numel() < floats_v or ws[1].numel() < floats_m:
         ws = (torch.empty(max(floats_v, ws[0].numel() if ws else 0), dtype=torch.float32, device=device),
               torch.empty(max(floats_m, ws[1].numel() if ws else 0), dtype=torch.float32, device=device))
-        _WINO_WS[device] = ws
+        _WINO_WS[key] = ws
     return ws
 
 
