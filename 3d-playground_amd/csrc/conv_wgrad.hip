@@ -34,6 +34,7 @@
 // shadow) and finish with one atomic per channel.
 //
 // Roofline: MFMA (fp32 157.3 TF).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -311,7 +312,10 @@ extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, f
     // enough K slices for ~2048 workgroups -- two rounds of what the chip holds (4 per CU at 40 KB of LDS); measured per
     // training step: 512 -> 66.0 ms, 1024 -> 57.3, 1536 -> 55.2, 2048 -> 54.2, 4096 -> 54.9, 8192 -> 55.1 -- each at
     // least 512 pixels long
-    int64_t splits = (2048 + tiles - 1) / tiles;
+    static const int wgs_native = getenv("RN_WGRAD_WGS") ? atoi(getenv("RN_WGRAD_WGS")) : 2048;
+    static const int wgs_split = getenv("RN_WGRAD_SPLIT_WGS") ? atoi(getenv("RN_WGRAD_SPLIT_WGS")) : 1536;   // split kernels: three per CU -> two rounds of 768 (measured 768 / 1024 / 1536 / 2048 / 3072: 21.8 / 21.5 / 20.6 / 21.0 / 21.5 ms per step)
+    const int wg_target = rn_get_fp32_mfma() == RN_FP32_SPLIT ? wgs_split : wgs_native;
+    int64_t splits = (wg_target + tiles - 1) / tiles;
     const int64_t max_splits = (a.pixels + 16 * WK_MAX - 1) / (16 * WK_MAX);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
