@@ -205,6 +205,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // are recomputed only when the tap changes (every Cin/BK steps); in between a step costs the vector ALU nothing --
     // the channel advance rides in the scalar offset of the load.
     const bool fast = (d.Cin % BK) == 0;
+    const bool stem = d.Cin == 4 && d.kw == 8;             // the 7x7 stem as the engine packs it (NHWC4 input, taps padded to 8)
     int f_r = 0, f_s = 0, f_c = 0;                         // tap (r,s) and channel offset of the NEXT step to load
     bool f_new = true;                                     // the first step computes its tap even when it starts mid-tap
     if (fast && ks_lo > 0) {
@@ -248,9 +249,12 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
             for (int j = 0; j < IA; ++j) {
                 const int k = ks * BK + a_c[j];
-                const int tap = k / d.Cin;
-                const int c0 = k - tap * d.Cin;
-                const int r = tap / d.kw, s_ = tap - r * d.kw;
+                int tap, c0, r, s_;
+                if (stem) {                                // 4 channels, 8-wide (padded) taps: the two divisions are shifts
+                    tap = k >> 2; c0 = k & 3; r = tap >> 3; s_ = tap & 7;
+                } else {
+                    tap = k / d.Cin; c0 = k - tap * d.Cin; r = tap / d.kw; s_ = tap - r * d.kw;
+                }
                 const int nh = a_h[j] + r * d.b, nw = a_w[j] + s_ * d.b;
                 const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
                 const bool ok = (r < d.kh) & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
