@@ -1,7 +1,7 @@
 // The implicit-GEMM convolution with split-operand products (mfma_split.h): the tile of conv_igemm_tile.h with its eight
 // v_mfma_f32_32x32x2_f32 per 32x32x16 block replaced by six v_mfma_f32_32x32x16_bf16 on (h, m, l) splits of the fp32
 // fragments.  Same descriptors, same packed fp32 weights, same staging and epilogue as conv_igemm.hip, whose launchers
-// choose between the two (rn_fp32_split()).  Kept in its own translation unit: every instance of the force-inlined tile
+// choose between the two (rn_get_fp32_mfma()).  Kept in its own translation unit: every instance of the force-inlined tile
 // costs compile time and memory.
 //
 // K-step: 16, like the fp32 form.  32 (template parameter BK; two MFMA steps per barrier, 64-80 KB of LDS, two workgroups per CU)

@@ -451,15 +451,19 @@ def test_splitk_fprop_and_dgrad(cv, dev, case):
 
 
 def test_split_weights_terms_add_up_exactly(cv, dev):
-    """rn_split_weights: [rows][Kpad/16][h, m, l][16] bf16 with h + m + l == w exactly (csrc/mfma_split.h)."""
-    w = rnd((40, 64), 5) * torch.logspace(-12, 12, 40 * 64).view(40, 64)
+    """rn_split_weights: [rows][Kpad/16][h, m, l][16] bf16 with h + m + l == w exactly for 2^20 values spread over 24 decades
+    (csrc/mfma_split.h: the kernels' in-register split is the same code), h the nearest bf16, and the residuals within their bounds."""
+    w = rnd((1024, 1024), 5) * torch.logspace(-12, 12, 1024 * 1024).view(1024, 1024)
     w[3, 7] = 0.0
     wp = w.to(dev).contiguous()
     cv.split_weights(wp)
-    rec = wp._rn_split.view(torch.bfloat16).view(40, 4, 3, 16).cpu()
-    total = rec.double().sum(dim=2).reshape(40, 64)
+    rec = wp._rn_split.view(torch.bfloat16).view(1024, 64, 3, 16).cpu()
+    total = rec.double().sum(dim=2).reshape(1024, 1024)
     assert torch.equal(total, w.double())
-    assert torch.equal(rec[:, :, 0].reshape(40, 64), w.to(torch.bfloat16))            # h is the nearest bf16
+    h, m, l = (rec[:, :, k].reshape(1024, 1024).double() for k in range(3))
+    assert torch.equal(h.float(), w.to(torch.bfloat16).float())                   # h is the nearest bf16
+    ax = w.double().abs()
+    assert bool((m.abs() <= ax * 2.0 ** -8).all()) and bool((l.abs() <= ax * 2.0 ** -16).all())
 
 
 def test_presplit_operand_is_refused_in_native_mode(cv, dev):
