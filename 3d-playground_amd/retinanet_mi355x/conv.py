@@ -256,7 +256,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     return (outs, (V, tuple(tuple(x.shape) for x in xs))) if keep_v else outs   # V + the shapes it belongs to
 
 
-def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
+def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None):
     """Weight gradient of a 3x3 / stride 1 / padding 1 convolution over several problems (gs[i] = dY [N,H,W,Cout],
     xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum."""
     lib = _hip.load()
@@ -276,7 +276,8 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None):
         _wino_transform_in(xs, V, C, Tpad, 0)
     _wino_transform_in(gs, Z, cout, Tpad, 1)
     ku = (C + 31) // 32 * 32
-    dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
+    if dU is None or tuple(dU.shape) != (36, cout, ku):      # dU: a ZEROED [36, cout, ku] accumulator of the caller (used once)
+        dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
     rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(    # executed FLOPs
         Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
         1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0, _hip.stream()))

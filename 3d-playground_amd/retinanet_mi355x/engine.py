@@ -227,7 +227,8 @@ class Layer:
                           colsum=self.cs)
             return
         if self.wino_active and not in_relu and g.shape[3] == s.cout and g.is_contiguous() and x.is_contiguous():
-            cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v)
+            du, self.du = getattr(self, "du", None), None          # the zeroed slot is good for one accumulation
+            cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v, dU=du)
             self.saved_v = None
             return
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
@@ -241,7 +242,8 @@ class Layer:
                 self.dw = torch.zeros_like(self.wf)
                 self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
-            cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v)
+            du, self.du = getattr(self, "du", None), None
+            cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v, dU=du)
             self.saved_v = None
             return
         for g, x in zip(gs, xs):
@@ -584,19 +586,26 @@ class Engine:
             L.dw = L.cs = L.wd = L.uf = L.ud = L.saved_v = None
 
     def _zero_grad_accumulators(self, device):
-        """Weight-gradient and column-sum accumulators of every layer as views of ONE buffer, zeroed by one fill per step
-        (they are atomically accumulated into: ~140 separate zero-fills per step otherwise)."""
-        sizes = [(L, L.wf.numel(), (L.spec.cout + 3) // 4 * 4) for L in self.layers.values()]
-        total = sum(a + b for _, a, b in sizes)
+        """Weight-gradient and column-sum accumulators of every layer -- and the Winograd-domain accumulators dU of the layers that
+        take that path -- as views of ONE buffer, zeroed by one fill per step (they are atomically accumulated into: ~160 separate
+        zero-fills per step otherwise)."""
+        wino = self.use_wino and not self.bf16
+        sizes = []
+        for L in self.layers.values():
+            s = L.spec
+            du = 36 * s.cout * ((s.cin + 31) // 32 * 32) if (wino and L.wino_layer) else 0
+            sizes.append((L, L.wf.numel(), (s.cout + 3) // 4 * 4, du))
+        total = sum(a + b + c for _, a, b, c in sizes)
         arena = getattr(self, "_arena", None)
         if arena is None or arena.numel() != total or arena.device != device:
             arena = self._arena = torch.empty(total, dtype=torch.float32, device=device)
         arena.zero_()
         o = 0
-        for L, a, b in sizes:
+        for L, a, b, c in sizes:
             L.dw = arena[o:o + a].view_as(L.wf)
             L.cs = arena[o + a:o + a + L.spec.cout]
-            o += a + b
+            L.du = arena[o + a + b:o + a + b + c].view(36, L.spec.cout, -1) if c else None
+            o += a + b + c
 
     # ------------------------------------------------------------------------------------------- forward
     def forward(self, P, img, save, x4=None):
