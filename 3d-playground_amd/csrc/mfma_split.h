@@ -10,8 +10,8 @@
 // and drop am*bl, al*bm, al*bl.  With |m| <= 2^-8 |x| and |l| <= 2^-16 |x| (round to nearest at each level) the dropped terms
 // are at most 2^-23 |a*b| and 2^-25 |a*b| in the root mean square over random operands -- the size of the rounding an fp32
 // accumulation step makes anyway (2^-24 |acc|), and the v_mfma_f32_32x32x16_bf16 adds its sixteen exact products before it
-// rounds into the accumulator where the fp32 MFMA rounds after every two.  Measured against fp64 the results are as accurate
-// as those of the v_mfma_f32_32x32x2_f32 kernels or slightly better (DESIGN.md 4.6 has the table for both modes).  Six bf16
+// rounds into the accumulator where the fp32 MFMA rounds after every two.  Measured against fp64 the kernels land within
+// -15 .. +25 % of the v_mfma_f32_32x32x2_f32 kernels' error (DESIGN.md 4.6 has the tables for both modes).  Six bf16
 // MFMAs of K = 16 take 6 x 32 cycles where eight fp32 MFMAs of K = 2 take 8 x 64: 2.7x the matrix rate, paid for with the
 // vector ALU work below (4.5 instructions per element, the conversions and packed subtractions at half rate), which is what
 // bounds the kernels that use it.

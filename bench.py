@@ -469,7 +469,7 @@ def main():
             line["config"]["fp32_products"] = (
                 "split operands: every fp32 operand as three bf16 terms (h + m + l == x exactly), six v_mfma_f32_32x32x16_bf16 "
                 "products per block into the fp32 accumulator, dropped terms <= 2^-23 of a product (2^-25 rms); operands, accumulation, "
-                "epilogues, gradients and optimizer fp32; measured against fp64: kernels at or below the fp32 MFMA kernels' error, "
+                "epilogues, gradients and optimizer fp32; measured against fp64: kernels within -15..+25 % of the fp32 MFMA kernels' error, "
                 "whole-model gradients 7e-7..1e-6 vs 3e-7..5e-7 (DESIGN.md 4.6, profiles/r02_fp32_split_errors.txt, r02_grad_vs_fp64.txt); "
                 "fp32_native_mfma below = the same step on v_mfma_f32_32x32x2_f32"
                 if split else "v_mfma_f32_32x32x2_f32")
