@@ -537,6 +537,9 @@ def main():
             if split:
                 try:                                                # supplementary sections never cost the headline its line
                     line["fp32_native_mfma"] = native_section(dev, args, B, H, W)
+                    line["note"] = ("value: fp32 step with split-operand products on the bf16 MFMA (config.fp32_products); the same step "
+                                    "with every product on v_mfma_f32_32x32x2_f32, same run: %s images/sec (fp32_native_mfma)"
+                                    % line["fp32_native_mfma"].get("value"))
                 except Exception as e:
                     line["fp32_native_mfma"] = {"error": str(e)[:300]}
             try:
