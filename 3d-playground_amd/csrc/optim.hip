@@ -37,7 +37,17 @@ __global__ __launch_bounds__(256) void opt_sqnorm_kernel(const OptTensor *__rest
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(1024) void opt_norm_final_kernel(const double *__restrict__ partial, int n, float *__restrict__ out) {
+// hp (device, optional): [lr, max_norm, beta1, beta2, eps, grad_scale] -- hyper-parameters a replayed hipGraph must be able to see
+// change (a scheduler's lr) and the 1/world of a data-parallel gradient SUM, folded in here instead of a pass over the buffer.
+#define HP_LR 0
+#define HP_MAX_NORM 1
+#define HP_BETA1 2
+#define HP_BETA2 3
+#define HP_EPS 4
+#define HP_GSCALE 5
+
+__global__ __launch_bounds__(1024) void opt_norm_final_kernel(const double *__restrict__ partial, int n, float *__restrict__ out,
+                                                              const float *__restrict__ hp) {
     __shared__ double red[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) s += partial[i];
@@ -47,7 +57,8 @@ __global__ __launch_bounds__(1024) void opt_norm_final_kernel(const double *__re
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int k = 0; k < 16; ++k) t += red[k];
-        out[0] = (float)sqrt(t);                                  // total L2 norm (clip_grad_norm_'s return value)
+        const double gs = hp != nullptr ? (double)hp[HP_GSCALE] : 1.0;
+        out[0] = (float)(sqrt(t) * gs);                           // total L2 norm of the (scaled) gradients: clip_grad_norm_'s return value
     }
 }
 
@@ -58,7 +69,12 @@ __global__ void opt_step_inc_kernel(int *__restrict__ step) { step[0] += 1; }
 __global__ __launch_bounds__(256) void opt_adam_kernel(const OptTensor *__restrict__ T, const OptChunk *__restrict__ C,
                                                        const float *__restrict__ total_norm, float max_norm, float lr,
                                                        float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                       int write_clipped, const int *__restrict__ step_dev) {
+                                                       int write_clipped, const int *__restrict__ step_dev,
+                                                       const float *__restrict__ hp) {
+    float gscale = 1.0f;
+    if (hp != nullptr) {                                          // wave-uniform scalar loads
+        lr = hp[HP_LR]; max_norm = hp[HP_MAX_NORM]; beta1 = hp[HP_BETA1]; beta2 = hp[HP_BETA2]; eps = hp[HP_EPS]; gscale = hp[HP_GSCALE];
+    }
     if (step_dev != nullptr) {                                    // wave-uniform: same value for every thread
         const int st = step_dev[0];
         bc1 = (float)(1.0 - pow((double)beta1, (double)st));
@@ -74,6 +90,7 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const OptTensor *__restri
         coef = coef > 1.0f ? 1.0f : coef;
     }
     const float step = lr / bc1;
+    coef *= gscale;                                               // (gscale == 1: bit-identical to the unscaled form)
     for (int64_t i = base + threadIdx.x; i < end; i += 256) {
         const float g = t.g[i] * coef;
         const float m = beta1 * t.m[i] + (1.0f - beta1) * g;      // exp_avg.lerp_(grad, 1 - beta1)
@@ -90,7 +107,7 @@ extern "C" int64_t rn_opt_workspace_bytes(int n_chunks) { return (int64_t)n_chun
 
 static int opt_clip_adam_impl(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
                               float beta1, float beta2, float eps, int step, int *step_dev, int write_clipped, void *workspace,
-                              float *total_norm, void *stream);
+                              float *total_norm, void *stream, const float *hp = nullptr);
 
 extern "C" int rn_opt_clip_adam(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
                                 float beta1, float beta2, float eps, int step, int write_clipped, void *workspace,
@@ -110,9 +127,21 @@ extern "C" int rn_opt_clip_adam_dev(const void *tensor_table, const void *chunk_
                               workspace, total_norm, stream);
 }
 
+// The hyper-parameters in DEVICE memory (hp: six floats, [lr, max_norm, beta1, beta2, eps, grad_scale]) as well as the step
+// number: nothing in the launch sequence is baked into a captured graph, so a ReduceLROnPlateau step between two replays
+// reaches the kernels (the caller rewrites hp with an asynchronous copy outside the graph).  grad_scale multiplies every
+// gradient before the norm and the update: 1/world for a data-parallel gradient SUM (ddp.GradReducer(defer_scale=True)).
+// The norm / clip launches always run (max_norm <= 0 in hp disables the clip inside the kernel).
+extern "C" int rn_opt_clip_adam_hp(const void *tensor_table, const void *chunk_table, int n_chunks, const float *hp, int *step_dev,
+                                   int write_clipped, void *workspace, float *total_norm, void *stream) {
+    if (step_dev == nullptr || hp == nullptr) return RN_EINVAL;
+    return opt_clip_adam_impl(tensor_table, chunk_table, n_chunks, 1.0f, 0.f, 0.f, 0.f, 0.f, 1, step_dev, write_clipped, workspace,
+                              total_norm, stream, hp);
+}
+
 static int opt_clip_adam_impl(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
                               float beta1, float beta2, float eps, int step, int *step_dev, int write_clipped, void *workspace,
-                              float *total_norm, void *stream) {
+                              float *total_norm, void *stream, const float *hp) {
     if (n_chunks <= 0) return RN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const OptTensor *T = reinterpret_cast<const OptTensor *>(tensor_table);
@@ -120,12 +149,12 @@ static int opt_clip_adam_impl(const void *tensor_table, const void *chunk_table,
     double *partial = reinterpret_cast<double *>(workspace);
     if (max_norm > 0.f) {
         hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, s, T, C, partial);
-        hipLaunchKernelGGL(opt_norm_final_kernel, dim3(1), dim3(1024), 0, s, (const double *)partial, n_chunks, total_norm);
+        hipLaunchKernelGGL(opt_norm_final_kernel, dim3(1), dim3(1024), 0, s, (const double *)partial, n_chunks, total_norm, hp);
     }
     if (step_dev != nullptr) hipLaunchKernelGGL(opt_step_inc_kernel, dim3(1), dim3(1), 0, s, step_dev);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(opt_adam_kernel, dim3(n_chunks), dim3(256), 0, s, T, C, (const float *)total_norm, max_norm, lr, beta1,
-                       beta2, eps, (float)bc1, (float)sqrt(bc2), write_clipped, (const int *)step_dev);
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), write_clipped, (const int *)step_dev, hp);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

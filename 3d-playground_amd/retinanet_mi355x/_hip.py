@@ -147,6 +147,7 @@ SIGNATURES.update({
     "rn_opt_workspace_bytes": (c_i64, [c_i32]),
     "rn_opt_clip_adam": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rn_opt_clip_adam_dev": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "rn_opt_clip_adam_hp": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
 })
 
 

@@ -25,8 +25,14 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, bucket_bytes=32 << 20, group=None, timeline=False):
+    def __init__(self, bucket_bytes=32 << 20, group=None, timeline=False, tail_bytes=6 << 20, defer_scale=False):
+        """tail_bytes: size the last (fully exposed) bucket is cut down to (Engine.set_flat_grads).  defer_scale: leave the
+        gradient SUM in the flat buffer -- the caller's optimizer multiplies by 1/world while it reads the gradients anyway
+        (optim.ClipAdam(grad_scale=reducer.grad_scale)): saves one pass over the 147 MB buffer after the last bucket.  Off by
+        default because torch.optim.Adam / clip_grad_norm_ (the reference's loop) expect averaged p.grad."""
         self.bucket_bytes = bucket_bytes
+        self.tail_bytes = tail_bytes
+        self.defer_scale = defer_scale
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.timeline = [] if timeline else None      # per step: [{bucket, bytes, launch_ms, done_ms}], backward_ms
@@ -41,8 +47,13 @@ class GradReducer:
 
     # ---- flat path: slices of the engine's persistent gradient buffer
     def attach(self, engine):
-        engine.set_flat_grads(self.bucket_bytes)
+        engine.set_flat_grads(self.bucket_bytes, self.tail_bytes)
         engine.bucket_hook = self.bucket_ready
+
+    @property
+    def grad_scale(self):
+        """What the optimizer must multiply the gradients by: 1/world with defer_scale, else 1."""
+        return 1.0 / self.world if (self.defer_scale and self.world > 1) else 1.0
 
     def backward_begins(self):
         if self.timeline is not None and torch.cuda.is_available():
@@ -70,7 +81,7 @@ class GradReducer:
                 f[5] = time.perf_counter()
 
     def finalize_flat(self, arena):
-        """Wait for every bucket and scale the whole buffer by 1/world (one launch)."""
+        """Wait for every bucket and scale the whole buffer by 1/world (one launch; with defer_scale the optimizer does it)."""
         if self.world == 1:
             return
         end = None
@@ -81,7 +92,8 @@ class GradReducer:
             f[1].wait()
             if f[5] is None:
                 f[5] = time.perf_counter()
-        arena.mul_(1.0 / self.world)
+        if not self.defer_scale:
+            arena.mul_(1.0 / self.world)
         if self.t0 is not None:
             torch.cuda.synchronize()
             self.timeline.append({
@@ -129,6 +141,22 @@ class GradReducer:
                 out[name] = flat[off:off + n].view(shape)
         self._reset()
         return out
+
+
+def mean_losses(*losses, group=None):
+    """Mean over the ranks of the step's loss scalars, as ONE all-reduce of len(losses) floats issued after backward; returns a
+    device tensor [len(losses)] (no host synchronisation here).
+
+    The reference's DataParallel gathers the replicas' losses and takes their mean (train_detector_3D_angle.py:374-378); that
+    mean is what is printed, kept in epoch_loss and handed to ReduceLROnPlateau (:338, 389-395, 412).  With one process per GPU
+    a scheduler stepped on a rank-LOCAL loss would give the ranks different learning rates and then different weights: every
+    rank must step its scheduler with THIS value (identical on all ranks: same bits from the same collective)."""
+    dev = losses[0].device
+    t = torch.stack([l.detach().reshape(-1)[0].float() for l in losses]).to(dev)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t /= dist.get_world_size(group)
+    return t
 
 
 def init_from_env(backend=None):

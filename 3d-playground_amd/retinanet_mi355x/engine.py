@@ -345,6 +345,7 @@ class Engine:
         # slices of it (no packing copy) handed to bucket_hook the moment their last layer retires, and (b) gradient
         # pointers are the same every step (the optimizer's pointer table is uploaded once).
         self.flat_bucket_bytes = None
+        self.flat_tail_bytes = None
         self.bucket_hook = None                    # callable(bucket index, flat slice) when a bucket is complete
         self._flat = None
         # Winograd for the head towers when activations are saved (= training); RN_WINOGRAD=0 keeps the direct kernels
@@ -385,14 +386,19 @@ class Engine:
         assert sorted(order) == sorted(self.layers), "finish_order does not cover the layer set"
         return order
 
-    def set_flat_grads(self, bucket_bytes=32 << 20):
-        """Turn the persistent flat gradient buffer on (bucket_bytes: all-reduce bucket size; None turns it off)."""
+    def set_flat_grads(self, bucket_bytes=32 << 20, tail_bytes=6 << 20):
+        """Turn the persistent flat gradient buffer on (bucket_bytes: all-reduce bucket size; None turns it off).
+        tail_bytes: the LAST bucket is final only when the backward ends, so its all-reduce is fully exposed -- it is cut down
+        to the last whole layers that fit in tail_bytes (ResNet-50: layer2 + layer1 + stem = 5.8 MB) and what was in front
+        of them becomes a bucket of its own, released while those layers still compute."""
         self.flat_bucket_bytes = bucket_bytes
+        self.flat_tail_bytes = tail_bytes
         self._flat = None
 
     def _flat_plan(self, device):
         """Slots (64-float aligned) of every parameter gradient in finish order + the buckets: [start, end, last layer]."""
         slots, buckets, off, start = {}, [], 0, 0
+        ends = []                                   # (end offset, layer name) per layer, in finish order
         for lname in self.finish_order():
             L = self.layers[lname]
             shapes = [tuple(L.weight.shape)] + [(L.spec.cout,)] * (len(L.grad_names()) - 1)
@@ -402,11 +408,22 @@ class Engine:
                     n *= d
                 slots[pname] = (off, n, shp)
                 off += (n + 63) // 64 * 64
+            ends.append((off, lname))
             if 4 * (off - start) >= self.flat_bucket_bytes:
                 buckets.append((start, off, lname))
                 start = off
         if off > start:
             buckets.append((start, off, self.finish_order()[-1]))
+        tail = getattr(self, "flat_tail_bytes", None)
+        if tail and buckets and 4 * (buckets[-1][1] - buckets[-1][0]) > tail:
+            b0, b1, last = buckets[-1]
+            cut = None
+            for e, lname in ends:                   # first layer boundary inside the bucket from which the rest fits in `tail`
+                if b0 < e < b1 and 4 * (b1 - e) <= tail:
+                    cut = (e, lname)
+                    break
+            if cut is not None:
+                buckets[-1:] = [(b0, cut[0], cut[1]), (cut[0], b1, last)]
         return {"slots": slots, "buckets": buckets, "total": off, "device": device, "arena": None}
 
     def _flat_views(self, device):

@@ -139,13 +139,15 @@ _LABEL_FLAGS = []             # [(pinned flag tensor, event)] of training forwar
 
 
 def check_labels(ann, directional, eager=None):
-    """The reference stacks an empty list when no image of the batch has a label (D/losses.py:362) and raises.
-    Testing that needs one word from the device.  Read on the spot it stalls the host once per training step (nothing of
-    step k+1 can be enqueued while step k drains), so by default the word travels asynchronously and is looked at when the
-    NEXT call comes by (or in ``flush_label_checks``): the same RuntimeError, one call late -- that step's vp loss is NaN
-    (the kernel's 0/0 over zero labelled images) and its gradients must not be applied, which is what the reference's
-    trainer does with any exception in an iteration (train_detector_3D_angle.py:406-408).  RN_EAGER_LABEL_CHECK=1 (or
-    eager=True) reads it immediately, exactly like the reference."""
+    """The reference stacks an empty list when no image of the batch has a label (D/losses.py:362) and raises INSIDE the
+    forward, so its trainer's try / except skips backward and optimizer.step for that iteration
+    (train_detector_3D_angle.py:367-408).  The default here is the same: the one word the test needs is read from the
+    device on the spot and the RuntimeError comes out of this forward (the reference's own loop synchronises every
+    iteration anyway, at ``if bool(loss == 0)``, :380).
+    RN_DEFERRED_LABEL_CHECK=1 (or eager=False) is the opt-in for loops that must not stall the host -- bench.py and
+    captured-graph replays: the word travels asynchronously and is looked at when the NEXT call comes by (or in
+    ``flush_label_checks``): the same RuntimeError, one call late; that step's vp loss is NaN (the kernel's 0/0 over
+    zero labelled images) and the caller must not apply its gradients."""
     if not directional:
         return
     if ann.shape[1] == 0:
@@ -153,7 +155,7 @@ def check_labels(ann, directional, eager=None):
     if ann.is_cuda and torch.cuda.is_current_stream_capturing():
         return                                          # graph capture: nothing may leave the device; the labels were checked eagerly in the warm-up
     if eager is None:
-        eager = os.environ.get("RN_EAGER_LABEL_CHECK", "0") == "1"
+        eager = os.environ.get("RN_DEFERRED_LABEL_CHECK", "0") != "1" or os.environ.get("RN_EAGER_LABEL_CHECK", "0") == "1"
     flush_label_checks(block=False)
     any_label = (ann[:, :, 20] != -1).any().reshape(1).to(torch.uint8)
     if eager or not ann.is_cuda:

@@ -505,6 +505,12 @@ int rn_opt_clip_adam(const void *tensor_table, const void *chunk_table, int n_ch
 int rn_opt_clip_adam_dev(const void *tensor_table, const void *chunk_table, int n_chunks, float max_norm, float lr,
                          float beta1, float beta2, float eps, int *step_dev, int write_clipped, void *workspace,
                          float *total_norm, void *stream);
+/* The same step with the hyper-parameters on the device as well: hp = six floats [lr, max_norm, beta1, beta2, eps, grad_scale].
+ * A scheduler's new lr (ReduceLROnPlateau, train_detector_3D_angle.py:338, 412) reaches a replayed hipGraph because the caller
+ * rewrites hp outside the graph.  grad_scale multiplies every gradient before the norm and the update (1/world for a
+ * data-parallel gradient SUM, so no separate pass scales the gradient buffer); max_norm <= 0 disables the clip. */
+int rn_opt_clip_adam_hp(const void *tensor_table, const void *chunk_table, int n_chunks, const float *hp, int *step_dev,
+                        int write_clipped, void *workspace, float *total_norm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,28 +40,38 @@ def _conv(x, sd, key, stride=1, padding=0):
     return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride, padding)
 
 
-def _block(x, sd, pre, kind, stride):
+def _tap(taps, name, t):
+    """taps: optional dict the caller passes to collect every ReLU OUTPUT of the network under the name of the convolution
+    that produced it (tests/test_gpu_model.py locates activations whose sign differs between this CPU run and the GPU run)."""
+    if taps is not None:
+        taps[name] = t.detach()
+    return t
+
+
+def _block(x, sd, pre, kind, stride, taps=None):
     res = x
     if kind == "basic":                                            # D/utils.py:25-43
-        out = F.relu(_bn(_conv(x, sd, pre + ".conv1", stride, 1), sd, pre + ".bn1"))
+        out = _tap(taps, pre + ".conv1", F.relu(_bn(_conv(x, sd, pre + ".conv1", stride, 1), sd, pre + ".bn1")))
         out = _bn(_conv(out, sd, pre + ".conv2", 1, 1), sd, pre + ".bn2")
+        last = pre + ".conv2"
     else:                                                          # D/utils.py:60-80, stride on conv2
-        out = F.relu(_bn(_conv(x, sd, pre + ".conv1"), sd, pre + ".bn1"))
-        out = F.relu(_bn(_conv(out, sd, pre + ".conv2", stride, 1), sd, pre + ".bn2"))
+        out = _tap(taps, pre + ".conv1", F.relu(_bn(_conv(x, sd, pre + ".conv1"), sd, pre + ".bn1")))
+        out = _tap(taps, pre + ".conv2", F.relu(_bn(_conv(out, sd, pre + ".conv2", stride, 1), sd, pre + ".bn2")))
         out = _bn(_conv(out, sd, pre + ".conv3"), sd, pre + ".bn3")
+        last = pre + ".conv3"
     if (pre + ".downsample.0.weight") in sd:
         res = _bn(_conv(x, sd, pre + ".downsample.0", stride), sd, pre + ".downsample.1")
-    return F.relu(out + res)
+    return _tap(taps, last, F.relu(out + res))
 
 
-def backbone(img, sd, arch):
+def backbone(img, sd, arch, taps=None):
     kind, counts = LAYERS[arch]
-    x = F.relu(_bn(_conv(img, sd, "conv1", 2, 3), sd, "bn1"))
+    x = _tap(taps, "conv1", F.relu(_bn(_conv(img, sd, "conv1", 2, 3), sd, "bn1")))
     x = F.max_pool2d(x, 3, 2, 1)
     feats = []
     for li, n in enumerate(counts, start=1):
         for b in range(n):
-            x = _block(x, sd, "layer%d.%d" % (li, b), kind, 2 if (li > 1 and b == 0) else 1)
+            x = _block(x, sd, "layer%d.%d" % (li, b), kind, 2 if (li > 1 and b == 0) else 1, taps)
         feats.append(x)
     return feats[1], feats[2], feats[3]
 
@@ -75,7 +85,7 @@ def _add_cropped(up, lat):
     return up[:, :, :h, :w] + lat[:, :, :h, :w]
 
 
-def pyramid(c3, c4, c5, sd):
+def pyramid(c3, c4, c5, sd, taps=None):
     p5 = _conv(c5, sd, "fpn.P5_1")
     p5_up = F.interpolate(p5, scale_factor=2, mode="nearest")
     p5 = _conv(p5, sd, "fpn.P5_2", 1, 1)
@@ -85,26 +95,26 @@ def pyramid(c3, c4, c5, sd):
     p3 = _add_cropped(p4_up, _conv(c3, sd, "fpn.P3_1"))
     p3 = _conv(p3, sd, "fpn.P3_2", 1, 1)
     p6 = _conv(c5, sd, "fpn.P6", 2, 1)
-    p7 = _conv(F.relu(p6), sd, "fpn.P7_2", 2, 1)
+    p7 = _conv(_tap(taps, "fpn.P6", F.relu(p6)), sd, "fpn.P7_2", 2, 1)
     return [p3, p4, p5, p6, p7]
 
 
-def head_tower(x, sd, pre, width, sigmoid):
+def head_tower(x, sd, pre, width, sigmoid, taps=None, level=0):
     for i in range(1, 5):
-        x = F.relu(_conv(x, sd, "%s.conv%d" % (pre, i), 1, 1))
+        x = _tap(taps, "%s.conv%d@%d" % (pre, i, level), F.relu(_conv(x, sd, "%s.conv%d" % (pre, i), 1, 1)))
     x = _conv(x, sd, pre + ".output", 1, 1)
     if sigmoid:
         x = torch.sigmoid(x)
     return x.permute(0, 2, 3, 1).contiguous().view(x.shape[0], -1, width)
 
 
-def forward_heads(img, sd, arch):
+def forward_heads(img, sd, arch, taps=None):
     """-> (regression [B,A,n], classification [B,A,C], anchors [1,A,4])."""
     n_reg = sd["regressionModel.output.weight"].shape[0] // 9
     n_cls = sd["classificationModel.output.weight"].shape[0] // 9
-    feats = pyramid(*backbone(img, sd, arch), sd)
-    reg = torch.cat([head_tower(f, sd, "regressionModel", n_reg, False) for f in feats], dim=1)
-    cls = torch.cat([head_tower(f, sd, "classificationModel", n_cls, True) for f in feats], dim=1)
+    feats = pyramid(*backbone(img, sd, arch, taps), sd, taps)
+    reg = torch.cat([head_tower(f, sd, "regressionModel", n_reg, False, taps, li) for li, f in enumerate(feats)], dim=1)
+    cls = torch.cat([head_tower(f, sd, "classificationModel", n_cls, True, taps, li) for li, f in enumerate(feats)], dim=1)
     anc = torch.from_numpy(oanchors.anchors_for_image(img.shape[2], img.shape[3])).to(img.device)
     return reg, cls, anc
 
