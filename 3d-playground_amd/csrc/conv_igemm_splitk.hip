@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
 
 // Slices worth using for this problem (1 = do not split) -- few output tiles and a long K loop.
 static int splitk_slices(const rn_conv_desc *d) {
+    if (!rn_get_option(RN_OPT_SPLITK)) return 1;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     const bool narrow = d->Cout <= 64 && !d->in_relu;      // the input-ReLU form exists for the 128 x 128 tile only
     const int64_t tiles = narrow ? (M + 255) / 256 : ((M + 127) / 128) * ((d->Cout + 127) / 128);

@@ -57,6 +57,11 @@ struct WgradArgs {
     int colsum_batch;            // the batch entry whose dy column sums are wanted
     int64_t dy_bstride, x_bstride, dw_bstride;   // floats between the operands of consecutive batch entries
     int64_t pixels, per_split;   // K extent and K per slice (multiple of WK)
+    // Deterministic form (RN_OPT_DETERMINISTIC): instead of atomics, K slice s stores its partial tiles into slab s -- an image
+    // of the whole result, slab_stride floats -- and its column sums into cs_slab + s * Cout; wgrad_combine_kernel adds the slabs
+    // in slice order.  NULL: fp32 atomics.
+    float *slab, *cs_slab;
+    int64_t slab_stride;
 };
 
 // WK pixels per K-step, OCC workgroups per CU the register budget is cut for (LDS: 2 * WK * (BM + BN) * 4 + 8 KiB).
@@ -269,10 +274,18 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
         cs.y += __shfl_xor(cs.y, 32);
         const int c = m0 + wm * 64 + 2 * (lane & 31);
         if (lane < 32) {
-            if (c + 0 < p.Cout) atomicAdd(p.colsum + c + 0, cs.x);
-            if (c + 1 < p.Cout) atomicAdd(p.colsum + c + 1, cs.y);
+            if (p.cs_slab != nullptr) {                       // one writer per (slice, channel): plain stores
+                float *q = p.cs_slab + (int64_t)slice * p.Cout;
+                if (c + 0 < p.Cout) q[c + 0] = cs.x;
+                if (c + 1 < p.Cout) q[c + 1] = cs.y;
+            } else {
+                if (c + 0 < p.Cout) atomicAdd(p.colsum + c + 0, cs.x);
+                if (c + 1 < p.Cout) atomicAdd(p.colsum + c + 1, cs.y);
+            }
         }
     }
+    float *out = dw_b;
+    if (p.slab != nullptr) out = p.slab + (int64_t)slice * p.slab_stride + (int64_t)batch * p.dw_bstride;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -281,15 +294,72 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) + tm;   // tile tm: channels 2*i + tm
-                if (row < p.Cout && col < p.Kflat) atomicAdd(dw_b + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                if (row < p.Cout && col < p.Kflat) {
+                    if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = acc[tm][tn][e];
+                    else atomicAdd(out + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                }
             }
         }
 }
+
+// Deterministic form, second pass: dw[b][row][col] += slab[0] + slab[1] + ... in slice order (one thread per element, col
+// fastest: coalesced over every slab), colsum[c] likewise from the column-sum slabs.
+__global__ __launch_bounds__(256) void wgrad_combine_kernel(float *__restrict__ dw, const float *__restrict__ slab, int64_t slab_stride,
+                                                            int splits, int nbatch, int64_t dw_bstride, int Cout, int Kflat, int Kpad,
+                                                            float *__restrict__ colsum, const float *__restrict__ cs_slab) {
+    const int64_t per = (int64_t)Cout * Kflat, total = per * nbatch;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const int64_t b = i / per, r = i - b * per;
+        const int row = (int)(r / Kflat), col = (int)(r - (int64_t)row * Kflat);
+        const int64_t e = b * dw_bstride + (int64_t)row * Kpad + col;
+        float v = dw[e];
+        for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * slab_stride + e];
+        dw[e] = v;
+    }
+    if (colsum != nullptr && i < Cout) {
+        float v = colsum[i];
+        for (int s = 0; s < splits; ++s) v += cs_slab[(int64_t)s * Cout + i];
+        colsum[i] = v;
+    }
+}
+
+static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
+                        int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
+                        int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                        int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes);
 
 extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                                      int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                                      int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                      int in_relu, void *stream) {
+    return wgrad_launch(dy, ldy, x, dw, colsum, nbatch, dy_bstride, x_bstride, dw_bstride, colsum_batch, N, Hi, Wi, Cin, Ho, Wo, Cout,
+                        kh, kw, stride, pad, in_relu, stream, false, nullptr, 0, nullptr);
+}
+
+// Fixed-order reduction (RN_OPT_DETERMINISTIC): same kernel, K slices store into slabs of `workspace`, one ordered combine.
+extern "C" int rn_conv_wgrad_batched_det(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
+                                         int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
+                                         int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                         int in_relu, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (workspace == nullptr) return RN_EINVAL;
+    return wgrad_launch(dy, ldy, x, dw, colsum, nbatch, dy_bstride, x_bstride, dw_bstride, colsum_batch, N, Hi, Wi, Cin, Ho, Wo, Cout,
+                        kh, kw, stride, pad, in_relu, stream, true, workspace, workspace_bytes, nullptr);
+}
+
+// Bytes of workspace rn_conv_wgrad_batched_det needs for this problem (slices x (result image + Cout column sums)).
+extern "C" int64_t rn_conv_wgrad_det_workspace_bytes(int ldy, int nbatch, int64_t dw_bstride, int N, int Hi, int Wi, int Cin, int Ho,
+                                                     int Wo, int Cout, int kh, int kw) {
+    int64_t need = 0;
+    const int rc = wgrad_launch(nullptr, ldy, nullptr, nullptr, nullptr, nbatch, 0, 0, dw_bstride, 0, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw,
+                                1, 0, 0, nullptr, true, nullptr, 0, &need);
+    return rc == RN_OK ? need : -1;
+}
+
+static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
+                        int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
+                        int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                        int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
         return RN_EINVAL;
     if (nbatch < 1 || nbatch > 4096 || dy_bstride < 0 || x_bstride < 0 || dw_bstride < 0 || colsum_batch < 0 || colsum_batch >= nbatch)
@@ -336,6 +406,16 @@ extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, f
     splits = (a.pixels + a.per_split - 1) / a.per_split;
     a.tiles = tiles;
     a.splits = (int)splits;
+    a.slab = a.cs_slab = nullptr;
+    a.slab_stride = 0;
+    if (det) {
+        a.slab_stride = nbatch > 1 ? (int64_t)nbatch * dw_bstride : (int64_t)Cout * a.Kpad;
+        const int64_t need = splits * (a.slab_stride + Cout) * (int64_t)sizeof(float);
+        if (need_bytes != nullptr) { *need_bytes = need; return RN_OK; }
+        if (workspace_bytes < need) return RN_EINVAL;
+        a.slab = reinterpret_cast<float *>(workspace);
+        a.cs_slab = a.slab + splits * a.slab_stride;
+    }
     const dim3 grid((unsigned)(tiles * (a.xcd_map ? (splits + 7) / 8 * 8 : splits)));
     // 16-pixel K-steps: 40-48 KiB of LDS, four / three workgroups per CU (measured: +2..4 % over 32-pixel steps at two per CU
     // on the mid-size layers, equal on the largest; the 64 x 256 tile does not fit twice at 32).
@@ -353,6 +433,13 @@ extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, f
     else RN_WGRAD_LAUNCH(2, 2);
 #undef RN_WGRAD_LAUNCH
     RN_LAUNCH_CHECK();
+    if (det) {
+        const int64_t total = (int64_t)nbatch * Cout * a.Kflat;
+        hipLaunchKernelGGL(wgrad_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dw,
+                           (const float *)a.slab, a.slab_stride, a.splits, nbatch, dw_bstride, Cout, a.Kflat, a.Kpad, colsum,
+                           (const float *)a.cs_slab);
+        RN_LAUNCH_CHECK();
+    }
     return RN_OK;
 }
 

@@ -42,3 +42,21 @@ extern "C" int rn_fp32_split_min_k(void) {
     }
     return v;
 }
+
+// Run-time options (include/retinanet_mi355x.h: RN_OPT_*).  -1 = not set yet -> the environment variable, else the default.
+static int g_opt[RN_OPT_COUNT] = {-1, -1};
+extern "C" int rn_get_option(int option) {
+    if (option < 0 || option >= RN_OPT_COUNT) return -1;
+    if (g_opt[option] < 0) {
+        static const char *const env[RN_OPT_COUNT] = {"RN_SPLITK", "RN_DETERMINISTIC"};
+        static const int dflt[RN_OPT_COUNT] = {1, 0};
+        const char *e = getenv(env[option]);
+        g_opt[option] = e ? (atoi(e) != 0) : dflt[option];
+    }
+    return g_opt[option];
+}
+extern "C" int rn_set_option(int option, int value) {
+    if (option < 0 || option >= RN_OPT_COUNT || (value != 0 && value != 1)) return RN_EINVAL;
+    g_opt[option] = value;
+    return RN_OK;
+}

@@ -153,6 +153,37 @@ def _w_operand(w_packed):
     return w_packed.data_ptr(), 0
 
 
+OPT_SPLITK, OPT_DETERMINISTIC = 0, 1             # RN_OPT_* of include/retinanet_mi355x.h
+
+
+def set_option(option, on):
+    _hip.check(_hip.load().rn_set_option(option, int(bool(on))), "rn_set_option")
+
+
+def get_option(option):
+    return bool(_hip.load().rn_get_option(option))
+
+
+def set_deterministic(on=True):
+    """Fixed-order weight-gradient reductions (RN_OPT_DETERMINISTIC; environment RN_DETERMINISTIC=1): two runs of a training
+    step give bit-identical gradients.  fp32 engine (the bf16 weight gradient keeps its atomics)."""
+    set_option(OPT_DETERMINISTIC, on)
+
+
+def _wgrad_call(lib, dev, dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, geom):
+    """rn_conv_wgrad_batched, or its fixed-order form with a slab workspace when the deterministic option is on.
+    geom = (N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu)."""
+    if not lib.rn_get_option(OPT_DETERMINISTIC):
+        return lib.rn_conv_wgrad_batched(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, _hip.stream())
+    N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw = geom[:9]
+    nb = lib.rn_conv_wgrad_det_workspace_bytes(ldy, nbatch, dw_bs, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw)
+    if nb < 0:
+        return 1
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)      # caching allocator: same stream, reused by the next layer
+    return lib.rn_conv_wgrad_batched_det(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom,
+                                         ws.data_ptr(), nb, _hip.stream())
+
+
 def wino_weights(weight, mode=0, scale=None):
     """OIHW 3x3 parameter -> U [36, rows, Kpad] (mode 0: forward; mode 1: data gradient, batch-norm scale folded in)."""
     lib = _hip.load()
@@ -278,9 +309,9 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None):
     ku = (C + 31) // 32 * 32
     if dU is None or tuple(dU.shape) != (36, cout, ku):      # dU: a ZEROED [36, cout, ku] accumulator of the caller (used once)
         dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
-    rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: lib.rn_conv_wgrad_batched(    # executed FLOPs
-        Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
-        1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0, _hip.stream()))
+    rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: _wgrad_call(    # executed FLOPs
+        lib, dev, Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
+        (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0)))
     _hip.check(rc, "rn_conv_wgrad_batched")
     _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
     return dw
@@ -373,9 +404,9 @@ def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
     kind = "conv_wgrad" + (" %dx%dx%d %d->%d k%d s%d" % (N, Ho, Wo, Cin, cout, k, stride) if prof.BY_SHAPE else "")
-    rc = prof.timed(kind, flops, lambda: lib.rn_conv_wgrad(
-        dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), N, Hi, Wi, Cin, Ho, Wo, cout, k,
-        k if kw_pad is None else kw_pad, stride, pad, int(in_relu), _hip.stream()))
+    rc = prof.timed(kind, flops, lambda: _wgrad_call(
+        lib, dy.device, dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), 1, 0, 0, 0, 0,
+        (N, Hi, Wi, Cin, Ho, Wo, cout, k, k if kw_pad is None else kw_pad, stride, pad, int(in_relu))))
     _hip.check(rc, "rn_conv_wgrad")
     return dw
 

@@ -386,6 +386,52 @@ class Engine:
         assert sorted(order) == sorted(self.layers), "finish_order does not cover the layer set"
         return order
 
+    # ------------------------------------------------------------------------------------------- ReLU outputs and their reach
+    def relu_outputs(self, S):
+        """{name: NHWC tensor} of every ReLU output among the saved activations S of forward(save=True), under the name of the
+        convolution that produced it ("layer2.0.conv1", "fpn.P6", "regressionModel.conv3@<pyramid level>"): the naming of
+        oracle.model's taps.  (fpn.P6 is stored before its ReLU -- the sign pattern is the same.)"""
+        out = {"conv1": S["stem"]}
+        for (pre, roles), (xin, t1, t2, x) in zip(self.blocks, S["blocks"]):
+            out[pre + ".conv1"] = t1
+            if t2 is not None:
+                out[pre + ".conv2"] = t2
+            out[pre + (".conv2" if self.kind == "basic" else ".conv3")] = x
+        out["fpn.P6"] = S["fpn"][6]
+        for prefix, acts in S["towers"].items():
+            for level, per_conv in enumerate(acts):
+                for i, t in enumerate(per_conv):
+                    out["%s.conv%d@%d" % (prefix, i + 1, level)] = t
+        return out
+
+    def backward_cone(self, act_name):
+        """Names of the parameters whose gradient the ReLU MASK of activation `act_name` (relu_outputs' naming) can reach: the
+        layer that produced it and everything the backward pass runs after it along the data-gradient path.  An activation
+        within rounding of zero that lands on the other side of the ReLU than in a reference run changes exactly these."""
+        order = self.finish_order()
+        backbone = [n for n in order if n.startswith("layer") or n == "conv1"]
+        base, _, level = act_name.partition("@")
+        if base.startswith(("regressionModel.", "classificationModel.")):
+            prefix, conv = base.split(".")
+            layers = ["%s.conv%d" % (prefix, j) for j in range(1, int(conv[-1]) + 1)]
+            # pyramid level -> FPN layers its gradient flows through (top-down path: dP3sum -> dP4sum -> dP5lat)
+            layers += {0: ["fpn.P3_2", "fpn.P3_1", "fpn.P4_1", "fpn.P5_1"], 1: ["fpn.P4_2", "fpn.P4_1", "fpn.P5_1"],
+                       2: ["fpn.P5_2", "fpn.P5_1"], 3: ["fpn.P6"], 4: ["fpn.P7_2", "fpn.P6"]}[int(level)]
+            layers += backbone                      # through C3 / C4 / C5 (every level reaches C5 or, for P3 / P4, layer2 / layer3 below it)
+        elif base == "fpn.P6":
+            layers = ["fpn.P6"] + backbone
+        elif base == "conv1":
+            layers = ["conv1"]
+        else:
+            layers = order[order.index(base):]      # the rest of the backbone's backward
+            pre, _, role = base.rpartition(".")
+            if role in ("conv1", "conv2") and pre + ".downsample.0" in layers and self.kind != "basic":
+                layers = [n for n in layers if n != pre + ".downsample.0"]   # the shortcut of the same block does not see t1 / t2
+        names = []
+        for n in layers:
+            names += self.layers[n].grad_names()
+        return names
+
     def set_flat_grads(self, bucket_bytes=32 << 20, tail_bytes=6 << 20):
         """Turn the persistent flat gradient buffer on (bucket_bytes: all-reduce bucket size; None turns it off).
         tail_bytes: the LAST bucket is final only when the backward ends, so its all-reduce is fully exposed -- it is cut down

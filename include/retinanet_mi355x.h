@@ -276,6 +276,20 @@ typedef struct rn_conv_desc {
 #define RN_FP32_DEFAULT RN_FP32_SPLIT
 int rn_get_fp32_mfma(void);
 int rn_set_fp32_mfma(int mode);
+/* Process-wide run-time options (0 / 1); initial value from the environment variable named, else the default.
+ *   RN_OPT_SPLITK         (RN_SPLITK, default 1)  rn_conv_splitk_workspace_bytes may choose the split-K form.  Off, a
+ *                         convolution's result does not depend on how many images share the launch: every output element
+ *                         is one K loop in a fixed order (the batch-invariance the batch-8 parity test relies on).
+ *   RN_OPT_DETERMINISTIC  (RN_DETERMINISTIC, default 0)  weight gradients are reduced in a fixed order: every K slice of
+ *                         rn_conv_wgrad* stores its partial tile in a slab of the workspace and an ordered pass adds the
+ *                         slabs (and the column sums) -- two runs give bit-identical gradients, as the reference's CPU path
+ *                         does; costs the slab traffic (rn_conv_wgrad_det_workspace_bytes).  Off: fp32 atomics, fastest,
+ *                         last bits depend on arrival order. */
+#define RN_OPT_SPLITK 0
+#define RN_OPT_DETERMINISTIC 1
+#define RN_OPT_COUNT 2
+int rn_get_option(int option);
+int rn_set_option(int option, int value);
 /* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (192; environment RN_FP32_SPLIT_MIN_K);
  * shorter reductions are memory-bound and keep the fp32 MFMA kernel.  (A pre-split weight operand, w_format 1, is always
  * taken by the split kernels: prepare it for the long reductions only.) */
@@ -331,6 +345,16 @@ int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *co
 int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                           int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
+/* The same reduction in a FIXED order (RN_OPT_DETERMINISTIC; the host logic selects it when the option is on): every K slice
+ * stores its partial result into its own slab of `workspace` (plain stores) and one ordered pass adds slabs 0, 1, 2 ... and the
+ * slices' column sums into dw / colsum: bit-identical from run to run, as the reference's CPU autograd is.  Costs one write and
+ * one read of slices x the result size (measured per training step: DESIGN.md 4.2). */
+int64_t rn_conv_wgrad_det_workspace_bytes(int ldy, int nbatch, int64_t dw_bstride, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
+                                          int Cout, int kh, int kw);
+int rn_conv_wgrad_batched_det(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
+                              int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
+                              int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
+                              void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------- bf16 convolution engine -----------------
  * The reduced-precision form of rn_conv_igemm / rn_conv_wgrad for BASELINE configs[2] (bf16 MFMA,

@@ -13,9 +13,11 @@ ResNet-18, batch 2, ONE flipped mask in 17 920 (regressionModel.conv3 at the P4 
 ResNet-18 moves the 8 tensors below it by 2e-4 .. 1.3e-3; one at 8e-8 in layer4.0 of ResNet-101, 3x4 pixels there at the
 golden's size, moves the 189 tensors below it by ~8e-4 and layer4.0.bn1.bias by 4.8e-3).  So: at least FLIP_FREE of
 the compared tensors must meet the tight bound and every tensor the loose one (GRAD_L2_FLIP / GRAD_MAX) -- a systematic
-error 10x the measured one fails the first -- OR the test finds the flipped element itself (the zero pattern of the saved
-activations differs between the two product modes of the kernels, relu_flips()) and every tensor meets the bounds a flip
-can reach at these sizes (FLIPPED_L2 / FLIPPED_MAX).  The kernels themselves are held to 1e-4 .. 2e-5 against fp64 in
+error 10x the measured one fails the first -- OR the test LOCATES the flipped element(s): every ReLU output of this GPU run
+is compared, element by element, with the oracle's CPU run (located_flips: Engine.relu_outputs vs oracle.model's taps); at
+most MAX_FLIPS elements may differ, only the parameters inside their backward cone (Engine.backward_cone: the producing
+layer and what the backward pass runs after it along the data-gradient path) may use the bounds a flip can reach at these
+sizes (FLIPPED_L2 / FLIPPED_MAX), and EVERY tensor outside the cone must meet the tight bound.  The kernels themselves are held to 1e-4 .. 2e-5 against fp64 in
 every mode by tests/test_gpu_conv.py, where no ReLU intervenes.
 At the full benchmark size (test_cfg2_full_size_against_oracle: 1e8 activations, hundreds of such flips, accumulating
 towards the stem) heads and FPN stay at <= 1.1e-5 and the backbone reaches 1e-4 .. 6e-4 with EITHER kernel family, so
@@ -82,7 +84,7 @@ def grad_close(got, want, name, test, l2_tol=GRAD_L2_FLIP, max_tol=GRAD_MAX):
         assert l2 <= l2_tol and mx <= max_tol, "%s [%s]: L2-rel %.3e, max-rel %.3e" % (name, test, l2, mx)
 
 
-FLIP_FREE = 0.8                                                # share of the tensors that must meet the tight bounds
+FLIP_FREE = 0.9                                                # share of the tensors that must meet the tight bounds
 
 
 def most_within(test, tol, frac=FLIP_FREE):
@@ -130,36 +132,58 @@ def mfma(request, dev):
 
 
 FLIPPED_L2, FLIPPED_MAX = 1e-2, 5e-2                           # reach of one flipped mask at the goldens' sizes (see the module docstring)
+MAX_FLIPS = 4                                                  # more activations than this on the wrong side of zero is not rounding
 
 
-def _activation_patterns(net, img):
-    from retinanet_mi355x import conv
-    pats = {}
+def located_flips(net, img, sd, arch):
+    """{activation name: number of elements} whose sign differs between THIS GPU run (current product mode and kernel family)
+    and the oracle's CPU run of the same network: every ReLU output of the forward pass, compared element by element
+    (Engine.relu_outputs vs oracle.model's taps)."""
+    from oracle import model as omodel
+    taps = {}
+    with torch.no_grad():
+        omodel.forward_heads(img.cpu(), sd, arch, taps=taps)
+    eng = net._engine
+    with torch.no_grad():
+        S = eng.forward(net._tensor_dict(), img, save=True)[2]
+    got = eng.relu_outputs(S)
+    assert sorted(got) == sorted(taps), sorted(set(got) ^ set(taps))
+    flips = {}
+    for name, t in got.items():
+        want = taps[name] > 0                                  # NCHW on the CPU
+        have = (t > 0).permute(0, 3, 1, 2).cpu()
+        assert have.shape == want.shape, (name, have.shape, want.shape)
+        n = int((have != want).sum())
+        if n:
+            flips[name] = n
+    return flips
 
-    def walk(o, path):
-        if isinstance(o, torch.Tensor):
-            if o.dtype == torch.float32 and o.numel() > 0 and "wino_v" not in path:
-                pats[path] = o > 0
-        elif isinstance(o, dict):
-            for k, v in o.items():
-                walk(v, "%s/%s" % (path, k))
-        elif isinstance(o, (list, tuple)):
-            for i, v in enumerate(o):
-                walk(v, "%s/%d" % (path, i))
-    walk(net._engine.forward(net._tensor_dict(), img, save=True)[2], "S")
-    return pats
 
-
-def relu_flips(net, img):
-    """Elements of the saved forward activations that are zero in exactly one of the two product modes."""
-    from retinanet_mi355x import conv
-    before = conv.get_fp32_mfma()
-    pats = []
-    for m in conv.FP32_MFMA_MODES:
-        conv.set_fp32_mfma(m)
-        pats.append(_activation_patterns(net, img))
-    conv.set_fp32_mfma(before)
-    return sum(int((pats[0][k] != pats[1][k]).sum()) for k in pats[0] if k in pats[1] and pats[0][k].shape == pats[1][k].shape)
+def check_gradients(net, img, sd, arch, mode, test, errs, norm_err):
+    """The two-level rule of the module docstring.  errs / norm_err: {parameter: (L2, max)} / {parameter: relative norm error}."""
+    worst = max(errs, key=lambda n: errs[n][0])
+    tight = sum(e[0] <= GRAD_L2[mode] for e in errs.values()) >= FLIP_FREE * len(errs) and \
+        sum(e <= NORM_TOL[mode] for e in norm_err.values()) >= FLIP_FREE * len(norm_err)
+    loose = all(e[0] <= GRAD_L2_FLIP and e[1] <= GRAD_MAX for e in errs.values()) and all(e <= GRAD_L2_FLIP for e in norm_err.values())
+    if tight and loose:
+        return
+    # Outside the bounds: the ONLY accepted cause is an activation on the other side of zero than in the CPU run.  Find it
+    # (layer, pyramid level), take the parameters its mask can reach (Engine.backward_cone) -- those may move by what one flipped
+    # mask moves at these sizes -- and hold EVERY other tensor to the tight bound.
+    flips = located_flips(net, img, sd, arch)
+    STATS[test]["flips"] = flips
+    assert flips, "%s: worst %s %s and every ReLU output has the sign pattern of the CPU run" % (test, worst, errs[worst])
+    assert sum(flips.values()) <= MAX_FLIPS, "%s: %s" % (test, flips)
+    cone = set()
+    for act in flips:
+        cone.update(net._engine.backward_cone(act))
+    outside = {n: e for n, e in errs.items() if n not in cone}
+    for n, e in outside.items():
+        assert e[0] <= GRAD_L2[mode], "%s: %s %s is outside the cone of %s and outside the tight bound" % (test, n, e, flips)
+    for n, e in norm_err.items():
+        assert e <= (FLIPPED_L2 if n in cone else 10 * NORM_TOL[mode]), "%s: norm of %s off by %.2e (flips %s)" % (test, n, e, flips)
+    for n, e in errs.items():
+        assert e[0] <= FLIPPED_L2 and e[1] <= FLIPPED_MAX, "%s: %s %s inside the cone of %s" % (test, n, e, flips)
 
 
 @pytest.mark.parametrize("mode", ["wino", "direct"])
@@ -167,7 +191,7 @@ def relu_flips(net, img):
 def test_directional_train_losses_and_gradients(dev, golden, arch, mode, mfma):
     """Losses within 1e-4; parameter gradients by the two-level rule of the module docstring."""
     z = golden(gc.MODEL_CASES[arch][0])
-    net, img, ann, _ = _build(arch, True, dev, wino=(mode == "wino"))
+    net, img, ann, sd = _build(arch, True, dev, wino=(mode == "wino"))
     net.train()
     net.freeze_bn()
     cls_l, reg_l, vp_l = net([img, ann])
@@ -191,16 +215,7 @@ def test_directional_train_losses_and_gradients(dev, golden, arch, mode, mfma):
     assert len(errs) > 30
     if MEASURE_ONLY:
         return
-    worst = max(errs, key=lambda n: errs[n][0])
-    tight = sum(e[0] <= GRAD_L2[mode] for e in errs.values()) >= FLIP_FREE * len(errs) and \
-        sum(e <= NORM_TOL[mode] for e in norm_err.values()) >= FLIP_FREE * len(norm_err)
-    loose = all(e[0] <= GRAD_L2_FLIP and e[1] <= GRAD_MAX for e in errs.values()) and all(e <= GRAD_L2_FLIP for e in norm_err.values())
-    if tight and loose:
-        return
-    flips = relu_flips(net, img)
-    assert flips > 0, "%s: worst %s %s and no ReLU mask differs between the product modes" % (test, worst, errs[worst])
-    assert all(e[0] <= FLIPPED_L2 and e[1] <= FLIPPED_MAX for e in errs.values()) and all(e <= FLIPPED_L2 for e in norm_err.values()), \
-        "%s: %d flipped mask(s), worst %s %s" % (test, flips, worst, errs[worst])
+    check_gradients(net, img, sd, arch, mode, test, errs, norm_err)
 
 
 def test_flat2d_train_and_eval(dev, golden):
@@ -338,6 +353,73 @@ def test_fused_clip_adam_matches_torch(dev):
             assert float((p.grad - q.grad).abs().max()) <= 1e-6 * float(q.grad.abs().max()) + 1e-12   # clipped grads written back
 
 
+def test_clip_adam_hyperparameters_live_on_the_device(dev):
+    """ClipAdam keeps lr / max_norm / betas / eps / grad_scale in device memory (rn_opt_clip_adam_hp): a scheduler's new lr
+    reaches a REPLAYED hipGraph (sync_hyperparameters outside the graph), a change inside a capture raises instead of being
+    frozen in silently, grad_scale = 1/world equals pre-scaled gradients, and state_dict / load_state_dict carry the step
+    number and both moments (a resumed run keeps Adam's bias correction)."""
+    from retinanet_mi355x import optim
+    torch.manual_seed(1)
+    shapes = [(300, 7), (64,), (5000,)]
+    grads = [torch.randn(s, device=dev) * 0.01 for s in shapes]
+
+    def params():
+        torch.manual_seed(2)
+        return [torch.nn.Parameter(torch.randn(s, device=dev) * 0.1) for s in shapes]
+    # (a) lr change between two replays of a captured step
+    pa, pb = params(), params()
+    ref = torch.optim.Adam(pb, lr=1e-3)
+    mine = optim.ClipAdam(pa, lr=1e-3, max_norm=0.0)
+    for p, q, g in zip(pa, pb, grads):
+        p.grad, q.grad = g.clone(), g.clone()
+    mine.step(); ref.step()                                    # eager warm-up: pointer table
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        mine.step()
+    graph.replay(); ref.step()
+    graph.replay(); ref.step()                                 # (capture itself executes nothing)
+    mine.param_groups[0]["lr"] = ref.param_groups[0]["lr"] = 1e-4
+    assert mine.sync_hyperparameters()
+    graph.replay(); ref.step()
+    for p, q in zip(pa, pb):
+        assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()), "the new lr did not reach the replayed graph"
+    mine.param_groups[0]["lr"] = 5e-5
+    g2, side, msg = torch.cuda.CUDAGraph(), torch.cuda.Stream(), ""
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g2.capture_begin()
+        try:
+            mine.step()                                        # raises before anything is launched into the capture
+        except RuntimeError as e:
+            msg = str(e)
+        finally:
+            g2.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    assert "inside a graph capture" in msg
+    # (b) grad_scale: a gradient SUM over 4 ranks with grad_scale 1/4 == averaged gradients
+    pa, pb = params(), params()
+    one = optim.ClipAdam(pa, lr=1e-3, max_norm=0.1)
+    two = optim.ClipAdam(pb, lr=1e-3, max_norm=0.1, grad_scale=0.25)
+    for p, q, g in zip(pa, pb, grads):
+        p.grad, q.grad = g.clone(), 4.0 * g
+    n1, n2 = float(one.step()), float(two.step())
+    assert abs(n1 - n2) <= 1e-6 * n1
+    for p, q in zip(pa, pb):
+        assert float((p - q).abs().max()) <= 1e-6 * float(q.abs().max())
+    # (c) state_dict round trip: resumed optimizer continues bit for bit
+    sd = one.state_dict()
+    assert sd["step"] == 1 and len(sd["m"]) == len(shapes)
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    three = optim.ClipAdam(pc, lr=7e-3, max_norm=0.5)
+    three.load_state_dict(sd)
+    for p, q, g in zip(pa, pc, grads):
+        p.grad, q.grad = g.clone(), g.clone()
+    one.step(); three.step()
+    assert int(three.step_dev) == 2
+    for p, q in zip(pa, pc):
+        assert torch.equal(p.detach(), q.detach())
+
+
 def test_cfg1_resnet18_2d_512(dev):
     """BASELINE configs[0]: ResNet-18 2D RetinaNet, 512x512 random tensors, 10 random GT boxes, batch 2,
     forward + FocalLoss -- against the oracle on CPU with the same weights."""
@@ -425,24 +507,53 @@ def test_data_parallel_is_refused_clearly(dev):
         dp(torch.cat([img, img]))
 
 
-def test_deferred_label_check(dev):
-    """A training batch without any label: the reference raises inside FocalLoss (D/losses.py:362).  The model's hot path
-    reports it one call late by default (no host sync per step), immediately with RN_EAGER_LABEL_CHECK=1."""
+def test_label_check_is_eager_and_the_reference_loop_skips_the_iteration(dev):
+    """A training batch without any label: the reference raises INSIDE FocalLoss (D/losses.py:362), so its trainer's
+    try / except (train_detector_3D_angle.py:367-408) never reaches backward / clip / step for that iteration.  Same here by
+    default: one reference-style iteration on an all-empty batch leaves every parameter untouched and the loss history clean."""
+    from retinanet_mi355x import ops
+    net, img, ann, _ = _build("resnet18", True, dev)
+    net.train()
+    net.freeze_bn()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    empty = torch.full_like(ann, -1.0)
+    loss_hist = []
+    try:                                                      # the reference's iteration, line for line in spirit (:367-408)
+        opt.zero_grad()
+        cls_l, reg_l, vp_l = net([img, empty])
+        loss = cls_l.mean() + reg_l.mean() + vp_l.mean()
+        if not bool(loss == 0):
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 0.1)
+            opt.step()
+            loss_hist.append(float(loss))
+    except Exception as e:
+        assert "non-empty TensorList" in str(e)
+    assert not loss_hist
+    for n, p in net.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    net([img, ann])                                           # the next (good) batch is not discarded
+    ops.flush_label_checks()
+
+
+def test_deferred_label_check_is_opt_in(dev):
+    """RN_DEFERRED_LABEL_CHECK=1 (bench.py, captured-graph loops): no host sync per step; the error arrives one call late."""
     from retinanet_mi355x import ops
     net, img, ann, _ = _build("resnet18", True, dev)
     net.train()
     empty = torch.full_like(ann, -1.0)
-    out = net([img, empty])
-    assert torch.isnan(out[2]).all()                          # vp loss 0/0 over zero labelled images
-    with pytest.raises(RuntimeError, match="non-empty TensorList"):
-        ops.flush_label_checks()
-    os.environ["RN_EAGER_LABEL_CHECK"] = "1"
+    os.environ["RN_DEFERRED_LABEL_CHECK"] = "1"
     try:
+        out = net([img, empty])
+        assert torch.isnan(out[2]).all()                      # vp loss 0/0 over zero labelled images
         with pytest.raises(RuntimeError, match="non-empty TensorList"):
-            net([img, empty])
+            ops.flush_label_checks()
     finally:
-        del os.environ["RN_EAGER_LABEL_CHECK"]
-    net([img, ann])                                           # and a good batch goes through
+        del os.environ["RN_DEFERRED_LABEL_CHECK"]
+    with pytest.raises(RuntimeError, match="non-empty TensorList"):
+        net([img, empty])                                     # default: raised by this very forward
+    net([img, ann])
     ops.flush_label_checks()
 
 
