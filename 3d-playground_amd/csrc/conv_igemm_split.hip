@@ -43,6 +43,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_groupe
     conv_igemm_tile<WM, WN, true, BK, false, false, SPLIT>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
+// SPLIT 3 (conv_igemm_tile.h: the activation operand split once per workgroup into bf16 planes in LDS) for the 128 x 128 tile
+// when the weights come pre-split and a K-step lies inside one filter tap; RN_SPLIT_A_ONCE=0 keeps the SPLIT 2 kernels (A/B).
+static bool split_a_once(const rn_conv_desc *d) {
+    static const int on = [] { const char *e = getenv("RN_SPLIT_A_ONCE"); return e ? atoi(e) : 1; }();
+    return on && d->w_format == 1 && (d->Cin % 16) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24;
+}
+
 // variant: the instance conv_igemm.hip's launcher chose -- 0 raw GEMM, 1 input ReLU, 2 / 3 narrow dense / general,
 // 4 / 5 wide dense / general.  d->w_format 1: w is the pre-split form (rn_split_weights).
 int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, const float *x, const float *w, float *y,
@@ -51,7 +58,8 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
     const dim3 grid(tiles), block(256);
 #define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW)                                                                                              \
     do {                                                                                                                                \
-        if (d->w_format == 1) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 2>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2); \
+        if (WM == 2 && split_a_once(d)) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, (WM == 2 ? 3 : 2)>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2); \
+        else if (d->w_format == 1) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 2>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 1>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);                 \
     } while (0)
     switch (variant) {
@@ -71,7 +79,8 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
 int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_group *g, const float *w, const float *scale,
                                   const float *shift, hipStream_t s) {
     const bool pre = g->d[0].w_format == 1;
-    if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    if (!narrow && split_a_once(&g->d[0])) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 3>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+    else if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);

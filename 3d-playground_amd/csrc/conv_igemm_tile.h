@@ -92,6 +92,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   BK = 32 (128-byte rows): swz = (r & 7) ^ ((r >> 3) & 7);   BK = 16 (64-byte rows): swz = (r >> 2) & 3.
 // Checked against the servicing groups of ds_read_b128 (4 x 16 lanes: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the
 // same + 32): within a group the 16 lanes hit 16 distinct 16-byte bank groups.
+// The compiler sinks most of a K-step's MFMAs below the s_waitcnt vmcnt(0) + s_barrier that end the step (they only use
+// registers), so the wait for the NEXT step's loads came ~200 cycles after their issue instead of a whole MFMA phase later:
+// every wave stalled on memory once per K-step.  A scheduling barrier pins the MFMA phase in front of the wait.
+#ifndef RN_PIN_MFMA
+#define RN_PIN_MFMA 1
+#endif
+// RN_SGB 1: sched_group_barrier pattern that spreads the SPLIT 3 form's vector work between its MFMAs.  Measured equal or slightly
+// slower than the compiler's own order (profiles/r03_split_a_once_ab.txt: 181.8 against 186.1 TF on 3x3 256->256): the K-step's
+// parts -- MFMAs, loads, vector + LDS work -- ADD UP on this chip whatever their order inside a wave (r03_split_knockout.txt).
+#ifndef RN_SGB
+#define RN_SGB 0
+#endif
+#ifndef RN_KO
+#define RN_KO 0
+#endif
+#if RN_PIN_MFMA
+#define RN_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RN_PIN() do {} while (0)
+#endif
+
 template <int BK>
 __device__ __forceinline__ int lds_swz(int row) {
     return BK == 32 ? ((row & 7) ^ ((row >> 3) & 7)) : ((row >> 2) & 3);
@@ -116,10 +137,15 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
     constexpr int RPI = 64 / CPK;                          // rows one wave instruction fills
     constexpr int SUB = BK / 16;                           // split forms: 16-wide MFMA steps per staged K-step
-    constexpr int BPL = BN * 8;                            // SPLIT 2: floats' worth of one bf16 plane of the B tile (BN rows x 32 bytes)
-    constexpr int NBI = SUB * 3 * BN / 32;                 // SPLIT 2: wave instructions that fill the planes: (sub-step, plane, 32 rows)
-    constexpr int IA = BM / RPI / 4, IB = SPLIT == 2 ? (NBI + 3) / 4 : BN / RPI / 4;    // instructions per wave per K-step and operand
-    constexpr int STEP = SPLIT == 2 ? BM * BK + SUB * 3 * BPL : (BM + BN) * BK;   // floats per buffer: A rows, then B rows (planes)
+    constexpr int BPL = BN * 8;                            // SPLIT 2 / 3: floats' worth of one bf16 plane of the B tile (BN rows x 32 bytes)
+    constexpr int APL = BM * 8;                            // SPLIT 3: the same for the A tile
+    constexpr int NBI = SUB * 3 * BN / 32;                 // SPLIT 2 / 3: wave instructions that fill the B planes: (sub-step, plane, 32 rows)
+    constexpr bool PB = SPLIT >= 2;                        // B arrives pre-split
+    constexpr int IA = SPLIT == 3 ? 1 : BM / RPI / 4, IB = PB ? (NBI + 3) / 4 : BN / RPI / 4;    // instructions per wave per K-step and operand (SPLIT 3: A rows per THREAD)
+    constexpr int BOFF = SPLIT == 3 ? 3 * APL : BM * BK;   // floats: where the B part of a buffer starts
+    constexpr int STEP = SPLIT == 3 ? 3 * (APL + BPL) : (SPLIT == 2 ? BM * BK + SUB * 3 * BPL : (BM + BN) * BK);   // floats per buffer: A rows (planes), then B rows (planes)
+    constexpr int UPT = BM * 2 / 256;                      // SPLIT 3: (row, 8-value half) units of the A tile per thread
+    static_assert(SPLIT != 3 || (BK == 16 && UPT == 1), "SPLIT 3: 16-wide K-steps, 128-row tiles");
     constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
 #ifndef RN_SPLIT_NBUF
 #define RN_SPLIT_NBUF 2
@@ -156,7 +182,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     const v4i32 rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride,
                                  (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
     // per-image weights (w_batch_stride, in elements): a batch of GEMMs.  The pre-split form has 6 bytes per element.
-    const v4i32 rs_b = SPLIT == 2
+    const v4i32 rs_b = PB
         ? make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * 6, (unsigned)((int64_t)d.Cout * Kpad * 6))
         : make_rsrc(w + (int64_t)n_first * d.w_batch_stride, (unsigned)((int64_t)d.Cout * Kpad * 4));
 
@@ -168,8 +194,9 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     const int rel0 = m0 - n_first * HoWo;
 #pragma unroll
     for (int j = 0; j < IA; ++j) {
-        const int row = (wave * IA + j) * RPI + rsub;
-        a_c[j] = 4 * (pos ^ lds_swz<BK>(row));
+        // SPLIT 3: thread t owns (row t >> 1, values 8 * (t & 1) .. + 7 of the K-step) of the A tile: one MFMA operand chunk
+        const int row = SPLIT == 3 ? tid >> 1 : (wave * IA + j) * RPI + rsub;
+        a_c[j] = SPLIT == 3 ? 8 * (tid & 1) : 4 * (pos ^ lds_swz<BK>(row));
         if ((int64_t)m0 + row < M) {
             const unsigned rel = (unsigned)(rel0 + row);
             const unsigned n = rel / (unsigned)HoWo;
@@ -188,7 +215,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     unsigned b_voff[IB];                                   // fixed for the whole kernel; the K-step advance is scalar
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
-        if constexpr (SPLIT == 2) {
+        if constexpr (PB) {
             // instruction q fills 32 rows of one plane: lane -> (row, position), fetches chunk position ^ ((row >> 4) & 1)
             const int q = wave * IB + j, sub = q / (3 * BN / 32), plane = (q / (BN / 32)) % 3, row = (q % (BN / 32)) * 32 + (lane >> 1);
             const int n = n0 + row;
@@ -222,12 +249,13 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         const unsigned B = lds0 + (unsigned)((buf * STEP + BM * BK + (wave_u * IB) * RPI * BK) * 4);
 #pragma unroll
         for (int j = 0; j < IB; ++j) {
-            if constexpr (SPLIT == 2) {
-                if (wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BM * BK) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * SUB * 96));
+            if constexpr (PB) {
+                if (4 * IB <= NBI || wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BOFF) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * SUB * 96));
             } else {
                 dma16(rs_b, B + j * (RPI * BK * 4), b_voff[j], (unsigned)(ks * BK * 4));
             }
         }
+        if constexpr (SPLIT == 3) return;                   // the A operand goes through registers: load_a / split_a below
         if (fast) {
             if (f_c == 0 || f_new) {                       // new tap (wave-uniform)
                 f_new = false;
@@ -263,6 +291,62 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         }
     };
 
+    // ---- SPLIT 3: the A operand is split ONCE per workgroup.  Each thread loads its 8 consecutive values of one row into
+    // registers (two 16-byte buffer loads; the range check is the zero-fill, as for the direct-to-LDS loads), two K-steps
+    // ahead of the MFMAs that consume them; one step ahead it splits them (mfma_split.h) and stores the three bf16 terms as
+    // ready MFMA operand chunks into the buffer's A planes -- the image the pre-split weights have: plane [BM rows][32 bytes],
+    // chunk position 2 * row + (half ^ ((row >> 4) & 1)).  The MFMA phase then only reads operands: half the vector ALU work
+    // of splitting per wave (the two waves that share a row block each split it in the SPLIT 1 / 2 forms).  Fast path only
+    // (Cin a multiple of 16: the launcher sends the other layers to SPLIT 2).
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v ar[2], arn[2];                                   // two register sets, used in turn (the K loop is unrolled by two)
+    // (the compiler's buffer-load builtin wants its own resource type: same base, range and dword 3 as rs_a)
+    const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + (int64_t)n_first * d.x_batch_stride), (short)0,
+        (int)(unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4), 0x00020000);
+    // Branch-free, and without multiplications (the compiler wraps anything expensive behind a select into a branch, and the K
+    // loop's body must stay ONE basic block for the vector work to be spread between the MFMAs): with div_shift == 0 (the
+    // launcher's condition for this form, with kh * kw <= 24) the byte offset of tap (r, s) is a per-thread base plus a
+    // scalar, and whether the tap falls inside the image is one bit of a per-thread mask.  Steps past the last tap find a
+    // zero bit and load zeros.
+    unsigned a_mask = 0;
+    for (int r = 0, t = 0; r < d.kh; ++r)
+        for (int s_ = 0; s_ < d.kw; ++s_, ++t) {
+            const int ih = a_h[0] + r * d.b, iw = a_w[0] + s_ * d.b;
+            a_mask |= (unsigned)(((ih | iw) >= 0) & (ih < d.Hi) & (iw < d.Wi)) << t;
+        }
+    const int a_base = a_img[0] + ((a_h[0] * d.Wi + a_w[0]) * d.Cin + a_c[0]) * 4;
+    auto load_a = [&](f32x4v (&ar)[2]) {
+        const int t = f_r * d.kw + f_s;                                         // scalar
+        const int delta = (f_r * d.Wi + f_s) * d.b * d.Cin * 4;
+        // valid = all ones if bit t of the mask is set (t <= 31: kh * kw <= 24 and at most two steps past the end), else zero;
+        // plain bit arithmetic -- behind a select the compiler moves even this one addition into a branch
+        const unsigned valid = 0u - ((a_mask >> (t & 31)) & 1u);
+        const unsigned v = ((unsigned)(a_base + delta) & valid) | (0x80000000u & ~valid);
+        ar[0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a3, (int)v, f_c * 4, 0));
+        ar[1] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a3, (int)(v + 16u), f_c * 4, 0));
+        f_c += BK;
+        const bool wrap = f_c >= d.Cin;                     // scalar selects, no branch
+        f_c = wrap ? 0 : f_c;
+        f_s += wrap ? 1 : 0;
+        const bool wrap_s = f_s == d.kw;
+        f_s = wrap_s ? 0 : f_s;
+        f_r += wrap_s ? 1 : 0;
+    };
+    const int a_wr = 4 * (2 * (tid >> 1) + ((tid & 1) ^ ((tid >> 5) & 1)));   // floats: this thread's chunk within a plane ((row >> 4) & 1 = (tid >> 5) & 1)
+    auto split_a = [&](int buf, const f32x4v (&ar)[2]) {
+        float av[8] = {ar[0][0], ar[0][1], ar[0][2], ar[0][3], ar[1][0], ar[1][1], ar[1][2], ar[1][3]};
+        if (RELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+        }
+        const Split8 sp = split8(av);
+        float *P = lds + buf * STEP + a_wr;
+        *reinterpret_cast<bf16x8 *>(P) = sp.h;
+        *reinterpret_cast<bf16x8 *>(P + APL) = sp.m;
+        *reinterpret_cast<bf16x8 *>(P + 2 * APL) = sp.l;
+    };
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -284,11 +368,12 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             fa[t][st] = ra * BK + 4 * (ch ^ lds_swz<BK>(ra));
             fb[t][st] = BM * BK + rb * BK + 4 * (ch ^ lds_swz<BK>(rb));
         }
-    int fbs[2];                                             // SPLIT 2: plane 0 of this lane's B operand of tile t (floats)
+    int fbs[2], fas[2];                                     // SPLIT 2 / 3: plane 0 of this lane's B (SPLIT 3: and A) operand of tile t (floats)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int rb = wn * 64 + t * 32 + (lane & 31);
-        fbs[t] = BM * BK + 4 * (2 * rb + ((lane >> 5) ^ ((rb >> 4) & 1)));
+        const int rb = wn * 64 + t * 32 + (lane & 31), ra = wm * 64 + t * 32 + (lane & 31);
+        fbs[t] = BOFF + 4 * (2 * rb + ((lane >> 5) ^ ((rb >> 4) & 1)));
+        fas[t] = 4 * (2 * ra + ((lane >> 5) ^ ((ra >> 4) & 1)));
     }
     auto multiply = [&](int buf) {
         const float *S = lds + buf * STEP;
@@ -298,14 +383,21 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                 Split8 sa[2], sb[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub + 1]);
-                    float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-                    if (RELU) {                             // input ReLU, on the fragments
+                    if constexpr (SPLIT == 3) {
+                        const float *Ap = S + fas[t];
+                        sa[t].h = *reinterpret_cast<const bf16x8 *>(Ap);
+                        sa[t].m = *reinterpret_cast<const bf16x8 *>(Ap + APL);
+                        sa[t].l = *reinterpret_cast<const bf16x8 *>(Ap + 2 * APL);
+                    } else {
+                        const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub + 1]);
+                        float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                        if (RELU) {                             // input ReLU, on the fragments
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                            for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                        }
+                        sa[t] = split8(av);
                     }
-                    sa[t] = split8(av);
-                    if constexpr (SPLIT == 2) {
+                    if constexpr (PB) {
                         const float *Bp = S + fbs[t] + sub * 3 * BPL;
                         sb[t].h = *reinterpret_cast<const bf16x8 *>(Bp);
                         sb[t].m = *reinterpret_cast<const bf16x8 *>(Bp + BPL);
@@ -355,23 +447,86 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // 2 buffers, 4 per CU 112.0 -- residency beats prefetch distance, most of all on the small-K layers.
     constexpr int NLD = IA + IB;                           // loads one wave issues per K-step
     // (SPLIT 2 with a 64-wide B tile: the last wave has no B plane to fill, its newest step is IA loads)
-    const bool b_loader = SPLIT != 2 || (wave_u + 1) * IB <= NBI;
-    static_assert(SPLIT != 2 || NBI % IB == 0, "a wave fills IB plane blocks or none");
+    const bool b_loader = !PB || (wave_u + 1) * IB <= NBI;
+    static_assert(!PB || NBI % IB == 0, "a wave fills IB plane blocks or none");
     auto wait_but_newest = [&](bool newest_in_flight) {
         if (NBUF > 2 && newest_in_flight) {
             if (b_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA) : "memory");
         } else rn_wait_dma();
     };
-    if (nks > 0) dma_step(0, 0);
-    if (NBUF > 2 && nks > 1) dma_step(1, 1);
-    wait_but_newest(nks > 1);
-    __syncthreads();
+    if constexpr (SPLIT == 3) {
+        static_assert(SPLIT != 3 || NBUF == 2, "SPLIT 3: two buffers");
+        load_a(ar); dma_step(0, 0); split_a(0, ar);         // (the compiler waits for the registers it loaded)
+        load_a(ar);                                         // step 1 stays in registers until iteration 0 splits it
+        rn_wait_dma();
+        __syncthreads();
+        // One K-step: `cur` holds the A values of step ks + 1 (loaded one iteration ago), `nxt` receives step ks + 2.
+        // Unconditional (one basic block): past the last step the loads return zeros / stale weights into a buffer nobody reads,
+        // and every one of them has landed (vmcnt(0) below) before the epilogue reuses the LDS.
+        auto k_step = [&](int ks, int rb, f32x4v (&cur)[2], f32x4v (&nxt)[2]) {
+            // the compiler's wait for `cur` HERE, where it is free (the step ended with vmcnt(0)): placed after the loads below
+            // it would be a vmcnt(0) that also covers them -- the compiler does not see the direct-to-LDS loads
+            asm volatile("" : "+v"(cur[0]), "+v"(cur[1]));
+#if !(RN_KO & 1)                                            // knock-outs (timing only, wrong results): 1 no B loads, 2 no A loads, 4 one MFMA of six
+            dma_step(ks + 1, rb ^ 1);                       // B planes of step ks + 1; buffer rb ^ 1 was released by the last barrier
+#endif
+#if !(RN_KO & 2)
+            load_a(nxt);                                    // A values of step ks + 2: a whole MFMA phase to arrive
+#endif
+            // This step's operands FIRST: the compiler cannot tell the two buffers apart, so every LDS read that follows the
+            // plane stores in program order waits for them -- and they wait for the whole split.
+            Split8 sa[2], sb[2];
+            {
+                const float *S = lds + rb * STEP;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float *Ap = S + fas[t], *Bp = S + fbs[t];
+                    sa[t].h = *reinterpret_cast<const bf16x8 *>(Ap);
+                    sa[t].m = *reinterpret_cast<const bf16x8 *>(Ap + APL);
+                    sa[t].l = *reinterpret_cast<const bf16x8 *>(Ap + 2 * APL);
+                    sb[t].h = *reinterpret_cast<const bf16x8 *>(Bp);
+                    sb[t].m = *reinterpret_cast<const bf16x8 *>(Bp + BPL);
+                    sb[t].l = *reinterpret_cast<const bf16x8 *>(Bp + 2 * BPL);
+                }
+            }
+            split_a(rb ^ 1, cur);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+#if RN_SGB
+            // Spread the split's vector work and the plane stores between the 24 MFMAs (32 cycles each, of which 24 are free
+            // issue slots): left alone the compiler puts all of it in front of the first MFMA.
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);            // A registers of step ks + 2
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);           // this step's operands
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);            // A planes of step ks + 1
+            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+#endif
+            RN_PIN();
+            rn_wait_dma();                                  // B planes of step ks + 1 landed, A registers of step ks + 2 arrived
+            __syncthreads();                                // (and the A planes' ds_writes: the barrier waits for lgkmcnt)
+        };
+        for (int ks = 0; ks < nks; ks += 2) {
+            k_step(ks, 0, ar, arn);
+            if (ks + 1 < nks) k_step(ks + 1, 1, arn, ar);
+        }
+    }
+    if (SPLIT != 3 && nks > 0) dma_step(0, 0);
+    if (SPLIT != 3 && NBUF > 2 && nks > 1) dma_step(1, 1);
+    if (SPLIT != 3) { wait_but_newest(nks > 1); __syncthreads(); }
     int rb = 0, wb = NBUF - 1;                              // buffer read by this step / filled for step ks + NBUF-1
-    for (int ks = 0; ks < nks; ++ks) {
+    for (int ks = 0; SPLIT != 3 && ks < nks; ++ks) {
         const bool more = ks + (NBUF - 1) < nks;
         if (more) dma_step(ks + (NBUF - 1), wb);
         multiply(rb);
+        RN_PIN();
         wait_but_newest(more);                              // the next step has landed (this wave's part) ...
         __syncthreads();                                    // ... and everybody's; buffer rb is free
         rb = rb == NBUF - 1 ? 0 : rb + 1;

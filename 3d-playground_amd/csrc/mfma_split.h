@@ -32,12 +32,12 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsi
     h = __builtin_bit_cast(unsigned, hp);
     // (the empty asm pins the PACKED value: without it the compiler derives h << 16 from a second, single-value conversion of
     // x0 -- seen in the weight-gradient kernel: 64 conversions per K-step instead of 32)
-    asm volatile("" : "+v"(h));
+    asm("" : "+v"(h));
     const float r0 = x0 - __builtin_bit_cast(float, h << 16);
     const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
     const bf16x2 mp = {(__bf16)r0, (__bf16)r1};
     m = __builtin_bit_cast(unsigned, mp);
-    asm volatile("" : "+v"(m));
+    asm("" : "+v"(m));
     const float s0 = r0 - __builtin_bit_cast(float, m << 16);
     const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
     // the last residual has at most 8 significant bits (x has 24, h and m took 8 each): its bf16 is its upper half, one
@@ -81,7 +81,7 @@ __device__ __forceinline__ void split_store_chunk(const float *__restrict__ src,
 }
 
 // acc += a * b for one 32x32 tile and 16 values of k: the six products, smallest first.
-#if defined(RN_SPLIT_ABL) && RN_SPLIT_ABL == 2                 // knock-out (timing only, wrong results): one MFMA of the six
+#if (defined(RN_SPLIT_ABL) && RN_SPLIT_ABL == 2) || (defined(RN_KO) && (RN_KO & 4))                 // knock-out (timing only, wrong results): one MFMA of the six
 #define RN_SPLIT_MFMA(ACC, A, B)                                                          \
     do {                                                                                  \
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).l, (B).h, ACC, 0, 0, 0);        \
