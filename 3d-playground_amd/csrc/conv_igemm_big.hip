@@ -1,0 +1,366 @@
+// Split-operand implicit GEMM, big tile: ONE wave per SIMD, each wave a (32*TMW) x (32*TNW) block of the output.
+//
+// STATUS: correct (tests/test_gpu_conv_big.py), NOT faster than the 128 x 128 kernels, therefore OFF unless RN_BIG_TILE=1.
+// Measured on the same GPU (profiles/r03_big_tile.txt): 3x3 256->256 at 135x240x8 fprop 1.66 ms against 1.64, the Winograd
+// GEMM of a tower layer 0.657 against 0.598 ms, 1x1 512->2048 0.238 against 0.189 ms.  Its knock-outs say why the reasoning
+// below did not carry: with one wave per SIMD nothing covers the latency of the wave's own LDS operand reads, barrier and
+// waits -- the kernel with NO loads, NO split arithmetic and one MFMA of six still takes 0.89 ms of the 1.66 (0.55 of 1.64
+// for the small tile).  Kept as the record of the experiment and as a second implementation the parity tests cross-check.
+//
+// Why: timing the 128 x 128 split kernels with pieces knocked out (profiles/r03_split_knockout.txt) showed that the three parts
+// of a K-step -- MFMAs, global loads, vector + LDS work -- ADD UP on this chip, with three workgroups per CU and whatever the
+// instruction order inside a wave: 3x3 256->256 at 135x240x8 takes 1.70 ms = 0.62 (everything but loads and 5/6 of the MFMAs)
+// + 0.51 (loads) + 0.56 (5/6 of the MFMAs).  So the lever is not overlap but the amount of non-MFMA work per MFMA, and that is
+// set by the block a wave owns: every operand fragment a wave reads (and every byte the workgroup stages) feeds TNW (TMW)
+// products instead of 2.  Per 16-wide K-step and wave:
+//                          64 x 64 per wave (conv_igemm_tile.h, SPLIT 3)      128 x 128 per wave (this file, TMW = TNW = 4)
+//   MFMAs                  24                                                 96
+//   global loads           3 direct-to-LDS + 2 to registers                   6 + 4             (0.21 -> 0.10 per MFMA)
+//   LDS operand reads      12 ds_read_b128                                    24                (0.50 -> 0.25)
+//   vector instructions    ~55 (split of 8 values + addresses)                ~100              (2.3  -> 1.0)
+// The price is registers -- 256 accumulators + 96 operand registers per lane: one workgroup of four waves per CU (the unified
+// 512-entry file) -- and the grain of the grid: 256 x 256 output tiles, so it is used where a launch still has >= 200 of them.
+//
+// Data path (the SPLIT 3 form of conv_igemm_tile.h, which has the details): weights arrive pre-split (rn_split_weights: three
+// bf16 planes, staged by direct-to-LDS loads, the range check as zero-fill); a thread loads 8 * UPT consecutive values of one
+// activation row into registers two K-steps ahead, splits them one step ahead and stores them as ready MFMA operand chunks into
+// the A planes; the MFMA phase only reads operands.  Two LDS buffers of 3 * (BM + BN) * 32 bytes, one barrier per K-step, the
+// loop body one basic block (branch-free addressing from a per-thread tap mask).  Conditions (the launcher's): pre-split
+// weights, Cin a multiple of 16, div_shift 0, kh * kw <= 24, Cout a multiple of 4, no input ReLU.
+#include "conv_igemm_tile.h"
+
+template <int TMW, int TNW, bool GENERAL, bool RAW>
+__device__ __forceinline__ void conv_big_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
+                                              float *__restrict__ y, const float *__restrict__ scale,
+                                              const float *__restrict__ shift, const float *__restrict__ add,
+                                              const float *__restrict__ mask, const float *__restrict__ add2, const int tile) {
+    constexpr int BK = 16;
+    constexpr int BM = 64 * TMW, BN = 64 * TNW;            // 2 x 2 waves
+    constexpr int APL = BM * 8, BPL = BN * 8;              // floats' worth of one bf16 plane: rows x 32 bytes
+    constexpr int STEP = 3 * (APL + BPL);                  // floats per buffer: A planes h, m, l, then B planes
+    constexpr int BOFF = 3 * APL;
+    constexpr int UPT = BM / 128;                          // 8-value units of an A row per thread (1: two threads per row, 2: one)
+    constexpr int NBI = 3 * BN / 32, IB = NBI / 4;         // direct-to-LDS instructions that fill the B planes, per wave
+    constexpr int LDT = BN + 4;
+    constexpr int RP = 64;                                 // epilogue: tile rows per pass through LDS
+    constexpr int EP = BM / RP;
+    static_assert(UPT == 1 || UPT == 2, "BM = 128 or 256");
+    static_assert(2 * STEP >= RP * LDT && NBI % 4 == 0, "tile shape");
+    __shared__ float lds[2 * STEP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ntn = (d.Cout + BN - 1) / BN;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int64_t M = (int64_t)d.N * HoWo;
+    const int K = d.kh * d.kw * d.Cin;
+    const int Kpad = (K + 31) / 32 * 32;
+    const int nks = Kpad / BK;
+
+    // ---- buffer descriptors: activations from the first image the tile touches, the pre-split weights whole (+ per-image offset)
+    const int n_first = (int)(m0 / HoWo);
+    const int64_t x_floats = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + (int64_t)n_first * d.x_batch_stride), (short)0,
+        (int)(unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4), 0x00020000);
+    const v4i32 rs_b = make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * 6,
+                                 (unsigned)((int64_t)d.Cout * Kpad * 6));
+
+    // ---- this thread's activation row: origin, tap mask, base offset (conv_igemm_tile.h, SPLIT 3)
+    const int row = UPT == 1 ? tid >> 1 : tid;
+    const int a_c = UPT == 1 ? 8 * (tid & 1) : 0;
+    int a_h = -(1 << 28), a_w = 0, a_img = 0;
+    if ((int64_t)m0 + row < M) {
+        const unsigned rel = (unsigned)(m0 - n_first * HoWo + row);
+        const unsigned n = rel / (unsigned)HoWo;
+        const unsigned rem = rel - n * (unsigned)HoWo;
+        const unsigned oh = rem / (unsigned)d.Wo, ow = rem - oh * (unsigned)d.Wo;
+        a_img = (int)((int64_t)n * d.x_batch_stride * 4);
+        a_h = (int)oh * d.a + d.p;
+        a_w = (int)ow * d.a + d.p_w;
+    }
+    unsigned a_mask = 0;
+    for (int r = 0, t = 0; r < d.kh; ++r)
+        for (int s_ = 0; s_ < d.kw; ++s_, ++t) {
+            const int ih = a_h + r * d.b, iw = a_w + s_ * d.b;
+            a_mask |= (unsigned)(((ih | iw) >= 0) & (ih < d.Hi) & (iw < d.Wi)) << t;
+        }
+    const int a_base = a_img + ((a_h * d.Wi + a_w) * d.Cin + a_c) * 4;
+    int f_r = 0, f_s = 0, f_c = 0;                         // tap and channel offset of the next step to load
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    struct ARegs { f32x4v v[2 * UPT]; };
+    auto load_a = [&](ARegs &ar) {
+        const int t = f_r * d.kw + f_s;
+        const int delta = (f_r * d.Wi + f_s) * d.b * d.Cin * 4;
+        const unsigned valid = 0u - ((a_mask >> (t & 31)) & 1u);
+        const unsigned v = ((unsigned)(a_base + delta) & valid) | (0x80000000u & ~valid);
+#pragma unroll
+        for (int q = 0; q < 2 * UPT; ++q)
+            ar.v[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)(v + 16u * q), f_c * 4, 0));
+        f_c += BK;
+        const bool wrap = f_c >= d.Cin;
+        f_c = wrap ? 0 : f_c;
+        f_s += wrap ? 1 : 0;
+        const bool wrap_s = f_s == d.kw;
+        f_s = wrap_s ? 0 : f_s;
+        f_r += wrap_s ? 1 : 0;
+    };
+    // chunk position of (row, half hf) within a plane: 2 * row + (hf ^ ((row >> 4) & 1)), in floats
+    const int a_wr0 = 4 * (2 * row + ((UPT == 1 ? (tid & 1) : 0) ^ ((row >> 4) & 1)));
+    const int a_wr1 = 4 * (2 * row + (1 ^ ((row >> 4) & 1)));                         // UPT 2: the second half
+    auto split_a = [&](int buf, const ARegs &ar) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            const float av[8] = {ar.v[2 * u][0], ar.v[2 * u][1], ar.v[2 * u][2], ar.v[2 * u][3],
+                                 ar.v[2 * u + 1][0], ar.v[2 * u + 1][1], ar.v[2 * u + 1][2], ar.v[2 * u + 1][3]};
+            const Split8 sp = split8(av);
+            float *P = lds + buf * STEP + (u == 0 ? a_wr0 : a_wr1);
+            *reinterpret_cast<bf16x8 *>(P) = sp.h;
+            *reinterpret_cast<bf16x8 *>(P + APL) = sp.m;
+            *reinterpret_cast<bf16x8 *>(P + 2 * APL) = sp.l;
+        }
+    };
+
+    // ---- weight planes: instruction q of the workgroup fills 32 rows of one plane (lane -> row, 16-byte position)
+    unsigned b_voff[IB];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int q = wave * IB + j, plane = q / (BN / 32), brow = (q % (BN / 32)) * 32 + (lane >> 1);
+        const int n = n0 + brow;
+        b_voff[j] = n < d.Cout ? (unsigned)(n * Kpad * 6 + plane * 32 + (((lane & 1) ^ ((brow >> 4) & 1)) << 4)) : 0x80000000u;
+    }
+    const unsigned lds0 = lds_addr(lds);
+    auto dma_b = [&](int ks, int buf) {
+#pragma unroll
+        for (int j = 0; j < IB; ++j)
+            dma16(rs_b, lds0 + (unsigned)((buf * STEP + BOFF) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 96));
+    };
+
+    f32x16 acc[TMW][TNW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int fas[TMW], fbs[TNW];                                 // plane 0 of this lane's operand of 32-row block t (floats)
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) {
+        const int ra = wm * 32 * TMW + t * 32 + (lane & 31);
+        fas[t] = 4 * (2 * ra + ((lane >> 5) ^ ((ra >> 4) & 1)));
+    }
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+        const int rb = wn * 32 * TNW + t * 32 + (lane & 31);
+        fbs[t] = BOFF + 4 * (2 * rb + ((lane >> 5) ^ ((rb >> 4) & 1)));
+    }
+
+    // ---- K loop (see conv_igemm_tile.h, SPLIT 3, for why every piece sits where it sits)
+    ARegs ar, arn;
+    load_a(ar); dma_b(0, 0); split_a(0, ar);
+    load_a(ar);
+    rn_wait_dma();
+    __syncthreads();
+    auto k_step = [&](int ks, int rb, ARegs &cur, ARegs &nxt) {
+#pragma unroll
+        for (int q = 0; q < 2 * UPT; ++q) asm volatile("" : "+v"(cur.v[q]));   // the compiler's wait for `cur` here, where it is free
+#if !(RN_KO & 1)                                            // knock-outs (timing only): 1 no B loads, 2 no A loads, 4 one MFMA of six, 8 no split arithmetic
+        dma_b(ks + 1, rb ^ 1);
+#endif
+#if !(RN_KO & 2)
+        load_a(nxt);
+#endif
+        Split8 sa[TMW], sb[TNW];
+        const float *S = lds + rb * STEP;
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) {
+            const float *Ap = S + fas[t];
+            sa[t].h = *reinterpret_cast<const bf16x8 *>(Ap);
+            sa[t].m = *reinterpret_cast<const bf16x8 *>(Ap + APL);
+            sa[t].l = *reinterpret_cast<const bf16x8 *>(Ap + 2 * APL);
+        }
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) {
+            const float *Bp = S + fbs[t];
+            sb[t].h = *reinterpret_cast<const bf16x8 *>(Bp);
+            sb[t].m = *reinterpret_cast<const bf16x8 *>(Bp + BPL);
+            sb[t].l = *reinterpret_cast<const bf16x8 *>(Bp + 2 * BPL);
+        }
+        split_a(rb ^ 1, cur);
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TNW; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+        RN_PIN();
+        rn_wait_dma();
+        __syncthreads();
+    };
+    for (int ks = 0; ks < nks; ks += 2) {
+        k_step(ks, 0, ar, arn);
+        if (ks + 1 < nks) k_step(ks + 1, 1, arn, ar);
+    }
+
+    // ---- plain GEMM (the Winograd stage): straight from the accumulators, two full 128-byte row segments per instruction
+    if constexpr (RAW) {
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TNW; ++tn) {
+                const int col = n0 + wn * 32 * TNW + tn * 32 + (lane & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t m = (int64_t)m0 + wm * 32 * TMW + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < M && col < d.Cout) y[m * d.Cout + col] = acc[tm][tn][e];
+                }
+            }
+        return;
+    }
+
+    // ---- epilogue through LDS, RP rows per pass (conv_igemm_tile.h: same arithmetic, same macros)
+    float *T = lds;
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;
+    const int c4 = tid % CPR;
+    const int col = n0 + 4 * c4;
+    const bool col_ok = col < d.Cout;
+    const bool vec = true;                                   // the launcher sends Cout % 4 == 0 only
+    const int ncol = 4;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (col_ok && scale != nullptr) sc[j] = scale[col + j];
+        if (col_ok && shift != nullptr) sh[j] = shift[col + j];
+    }
+#pragma unroll
+    for (int pass = 0; pass < EP; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm) {
+            const int rblk = wm * 32 * TMW + tm * 32;        // first tile row of this 32-row block (wave-uniform)
+            if (rblk / RP == pass) {
+#pragma unroll
+                for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(rblk - pass * RP + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 32 * TNW + tn * 32 + (lane & 31)] = acc[tm][tn][e];
+            }
+        }
+        __syncthreads();
+        constexpr int NIT = RP / RPP, G = NIT % 4 == 0 ? 4 : (NIT % 2 == 0 ? 2 : 1);
+        if (col_ok) {
+#pragma unroll 1
+            for (int g = 0; g < NIT; g += G) {
+                int64_t off_[G];
+                float4 mk_[G], ad_[G];
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int64_t mr = (int64_t)m0 + pass * RP + tid / CPR + (g + i) * RPP;
+                    const int64_t m = mr < M ? mr : M - 1;
+                    RN_EPI_ADDR(GENERAL)
+                    off_[i] = off;
+                    mk_[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    ad_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d.mask_mode != 0) mk_[i] = *reinterpret_cast<const float4 *>(mask + off);
+                    if (d.add_mode != 0) ad_[i] = *reinterpret_cast<const float4 *>(add + aoff);
+                    (void)a2off;
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int r = tid / CPR + (g + i) * RPP;
+                    const int64_t m = (int64_t)m0 + pass * RP + r;
+                    if (m < M) {
+                        const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                        const int64_t off = off_[i];
+                        float mk[4] = {mk_[i].x, mk_[i].y, mk_[i].z, mk_[i].w}, ad[4] = {ad_[i].x, ad_[i].y, ad_[i].z, ad_[i].w};
+                        if (d.add2_mode == 3) {
+                            int64_t a2;
+                            { RN_EPI_ADDR(GENERAL) a2 = a2off; (void)aoff; (void)off; }
+                            if (a2 >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
+                        }
+                        RN_EPI_FINISH()
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int TMW, int TNW, bool GENERAL, bool RAW>
+__global__ __launch_bounds__(256, 1) void conv_igemm_big_kernel(const rn_conv_desc d, const float *__restrict__ x,
+                                                                const float *__restrict__ w, float *__restrict__ y,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                const float *__restrict__ add, const float *__restrict__ mask,
+                                                                const float *__restrict__ add2) {
+    conv_big_tile<TMW, TNW, GENERAL, RAW>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+template <int TMW, int TNW>
+__global__ __launch_bounds__(256, 1) void conv_igemm_big_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
+                                                                        const float *__restrict__ scale,
+                                                                        const float *__restrict__ shift) {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    rn_conv_desc d = g.d[0];
+    const float *x = g.x[0], *add = g.add[0], *mask = g.mask[0];
+    float *y = g.y[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
+    conv_big_tile<TMW, TNW, true, false>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+}
+
+// Which problems take the big tile: RN_BIG_TILE=0 turns it off (A/B); min_tiles = launches with fewer 256 x 256 tiles leave
+// CUs idle (one workgroup per CU) and keep the 128 x 128 kernels.
+// (read at every launch, not cached: the parity tests force the big tile onto small problems at run time)
+static int big_tile_mode() {
+    const char *e = getenv("RN_BIG_TILE");
+    return e ? atoi(e) : 0;
+}
+static int big_min_tiles() {
+    const char *e = getenv("RN_BIG_TILE_MIN");
+    return e ? atoi(e) : 200;
+}
+static bool big_ok(const rn_conv_desc *d) {
+    return big_tile_mode() && d->w_format == 1 && (d->Cin % 16) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
+           (d->Cout % 4) == 0 && d->Cout >= 192 && !d->in_relu;
+}
+static int64_t big_tiles(const rn_conv_desc *d) {
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    return ((M + 255) / 256) * ((d->Cout + 255) / 256);
+}
+
+// -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 4 dense, 5 general.
+bool rn_igemm_big_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
+                         const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc) {
+    if (!big_ok(d) || (variant != 0 && variant != 4 && variant != 5)) return false;
+    const int64_t tiles = big_tiles(d);
+    if (tiles < big_min_tiles() || tiles > 0x7fffffff) return false;
+    const dim3 grid((unsigned)tiles), block(256);
+    if (variant == 0) hipLaunchKernelGGL((conv_igemm_big_kernel<4, 4, false, true>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else if (variant == 4) hipLaunchKernelGGL((conv_igemm_big_kernel<4, 4, false, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else hipLaunchKernelGGL((conv_igemm_big_kernel<4, 4, true, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    const hipError_t e = hipGetLastError();
+    *rc = e == hipSuccess ? RN_OK : (int)e;
+    return true;
+}
+
+bool rn_igemm_big_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc) {
+    for (int i = 0; i < g->n; ++i)
+        if (!big_ok(&g->d[i])) return false;
+    rn_conv_group gb = *g;                                  // the caller's tile table counts 128 x 128 tiles: recount
+    int64_t total = 0;
+    for (int i = 0; i < g->n; ++i) {
+        total += big_tiles(&g->d[i]);
+        gb.tile_end[i] = (int)total;
+    }
+    for (int i = g->n; i < RN_MAX_GROUP; ++i) gb.tile_end[i] = (int)total;
+    if (total < big_min_tiles() || total > 0x7fffffff) return false;
+    hipLaunchKernelGGL((conv_igemm_big_grouped_kernel<4, 4>), dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
+    const hipError_t e = hipGetLastError();
+    *rc = e == hipSuccess ? RN_OK : (int)e;
+    return true;
+}

@@ -50,11 +50,20 @@ static bool split_a_once(const rn_conv_desc *d) {
     return on && d->w_format == 1 && (d->Cin % 16) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24;
 }
 
+// conv_igemm_big.hip: 256 x 256 tiles, one wave per SIMD (returns false when the problem does not qualify)
+bool rn_igemm_big_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
+                         const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc);
+bool rn_igemm_big_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc);
+
 // variant: the instance conv_igemm.hip's launcher chose -- 0 raw GEMM, 1 input ReLU, 2 / 3 narrow dense / general,
 // 4 / 5 wide dense / general.  d->w_format 1: w is the pre-split form (rn_split_weights).
 int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, const float *x, const float *w, float *y,
                           const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
                           hipStream_t s) {
+    {
+        int rc = RN_OK;
+        if (rn_igemm_big_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
+    }
     const dim3 grid(tiles), block(256);
 #define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW)                                                                                              \
     do {                                                                                                                                \
@@ -79,6 +88,10 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
 int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_group *g, const float *w, const float *scale,
                                   const float *shift, hipStream_t s) {
     const bool pre = g->d[0].w_format == 1;
+    if (!narrow) {
+        int rc = RN_OK;
+        if (rn_igemm_big_grouped_launch(g, w, scale, shift, s, &rc)) return rc;
+    }
     if (!narrow && split_a_once(&g->d[0])) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 3>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);

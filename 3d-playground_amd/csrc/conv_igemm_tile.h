@@ -10,10 +10,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
 
 // Epilogue of one 16-byte chunk (4 output channels of one output pixel m): v = scale*t + shift; [mask before add];
 // v += add (+ add2); act; [mask after]; store through the output map.  Three stages, expanded in place by the tile

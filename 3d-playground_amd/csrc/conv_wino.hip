@@ -88,7 +88,10 @@ __device__ __forceinline__ int wino_locate(const WinoTable &g, int64_t gt, int64
 
 __global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *__restrict__ V, int C, int64_t t0, int64_t Tpad) {
     const int cq = C >> 2;
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // 6x6 patches of neighbouring tiles overlap by two pixels: every input pixel is read by 2.25 tiles.  With the plain id the
+    // tiles of one image row are spread over all eight XCDs and each L2 fetched its own copy of the shared pixels (PMC: 2.06x
+    // the input from HBM); one contiguous band of tiles per XCD keeps the re-reads in that L2.
+    const int64_t id = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int64_t gt = id / cq;
     if (gt >= g.tile_end[g.n - 1]) return;
     const int c4 = (int)(id - gt * cq) * 4;

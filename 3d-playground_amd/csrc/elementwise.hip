@@ -263,7 +263,8 @@ extern "C" int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int 
 // ------------------------------------------------------------------------------------------------ max-pool 3x3 s2 p1
 __global__ void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, uchar4 *__restrict__ arg, int H, int W,
                                    int C4, int Ho, int Wo, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*Ho*Wo*C4
+    // (3x3 / stride 2 windows overlap: one contiguous band of output rows per XCD, so the shared input rows meet in one L2)
+    const int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;       // over N*Ho*Wo*C4
     if (i >= total) return;
     const int c = (int)(i % C4);
     int64_t t = i / C4;
@@ -308,7 +309,7 @@ extern "C" int rn_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int N, 
 // recorded first maximum is this element.
 __global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ dy, const uchar4 *__restrict__ arg,
                                    float4 *__restrict__ dx, int H, int W, int C4, int Ho, int Wo, int relu_mask, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*H*W*C4
+    const int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;       // over N*H*W*C4 (band per XCD, as above)
     if (i >= total) return;
     const int c = (int)(i % C4);
     int64_t t = i / C4;

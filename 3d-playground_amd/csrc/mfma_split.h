@@ -47,7 +47,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsi
 
 __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
     u32x4 hh, mm, ll;
-#if defined(RN_SPLIT_ABL) && RN_SPLIT_ABL == 1                 // knock-out (timing only, wrong results): no vector ALU work
+#if (defined(RN_SPLIT_ABL) && RN_SPLIT_ABL == 1) || (defined(RN_KO) && (RN_KO & 8))                 // knock-out (timing only, wrong results): no vector ALU work
     Split8 k;
     k.h = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]), __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])});
     k.m = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, x[4]), __builtin_bit_cast(unsigned, x[5]), __builtin_bit_cast(unsigned, x[6]), __builtin_bit_cast(unsigned, x[7])});
