@@ -300,6 +300,66 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoTable g, float *
     }
 }
 
+// Both transforms of an output gradient in ONE pass over it: V = B^T dy B (the data gradient's input transform: 6x6 patches with
+// their halo) and Z = A dy A^T (the weight gradient's: the patch's inner 4x4).  The backward of a Winograd layer needs both and
+// read dy twice; the patch a thread has loaded for V holds the pixels of Z.
+__global__ __launch_bounds__(256) void wino_in_both_kernel(const WinoTable g, float *__restrict__ V, float *__restrict__ Z, int C,
+                                                           int64_t t0, int64_t Tpad) {
+    const int cq = C >> 2;
+    const int64_t id = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int64_t gt = id / cq;
+    if (gt >= g.tile_end[g.n - 1]) return;
+    const int c4 = (int)(id - gt * cq) * 4;
+    int64_t tile;
+    const int q = wino_locate(g, gt, tile);
+    const float *x = g.src[0];
+    WINO_SELECT(q, g, pr, x = g.src[i_];)
+    const int H = pr.H, W = pr.W, TW = pr.TW;
+    const int n = (int)(tile / (pr.TH * TW));
+    const int r = (int)(tile - (int64_t)n * pr.TH * TW);
+    const int th = r / TW, tw = r - th * TW;
+    const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
+    const float *xb = x + (int64_t)n * H * W * C + c4;
+    float4 t[6][6];                                           // t[i][j] = (B^T d)[i][j]
+    float4 tz[6][4];                                          // tz[a][j] = (A dy)[a][j], dy = the patch's rows / columns 1..4
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float4 d[6], o[6];
+        const int w = w0 + j;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int h = h0 + i;
+            const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            d[i] = ok ? *reinterpret_cast<const float4 *>(xb + ((int64_t)h * W + w) * C) : f4(0.f);
+        }
+        bt6(d, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+        if (j >= 1 && j <= 4) {
+            float4 oz[6];
+            a6(d + 1, oz);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) tz[a][j - 1] = oz[a];
+        }
+    }
+    float *zb = Z + (t0 + gt) * C + c4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float4 o[6];
+        a6(tz[a], o);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) st_stream(zb + (int64_t)(a * 6 + b) * Tpad * C, o[b]);
+    }
+    float *vb = V + (t0 + gt) * C + c4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float4 o[6];
+        bt6(t[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) st_stream(vb + (int64_t)(i * 6 + j) * Tpad * C, o[j]);
+    }
+}
+
 // dw[co][(r*3 + s)*Cin + ci] += (G^T dU G)[r][s],  dU [36][Cout][Ku] (Ku = Cin rounded up to 32)
 __global__ void wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, int Cout, int Cin, int Ku, int Kpad) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -355,6 +415,19 @@ extern "C" int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int6
     const dim3 grid(rn_blocks(t.tile_end[t.n - 1] * (C >> 2), 256));
     if (dy_form) hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad);
     else hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+extern "C" int rn_wino_input_both_group(const rn_wino_group *g, float *V, float *Z, int C, int64_t tile_offset, int64_t Tpad, void *stream) {
+    WinoTable t;
+    const int rc = wino_table(g, t);
+    if (rc) return rc;
+    if (!V || !Z || C <= 0 || (C & 3) || tile_offset < 0 || tile_offset + t.tile_end[t.n - 1] > Tpad) return RN_EINVAL;
+    for (int i = 0; i < t.n; ++i)
+        if (!t.src[i]) return RN_EINVAL;
+    hipLaunchKernelGGL(wino_in_both_kernel, dim3(rn_blocks(t.tile_end[t.n - 1] * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, t,
+                       V, Z, C, tile_offset, Tpad);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -111,6 +111,7 @@ SIGNATURES.update({
     "rn_unpack_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "rn_prep_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "rn_wino_input_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
+    "rn_wino_input_both_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "rn_wino_output_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -241,7 +241,7 @@ def _wino_workspace(device, floats_v, floats_m):
 
 
 def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
-                    flops=0.0, keep_v=False, y_batch_stride=0, V_in=None):
+                    flops=0.0, keep_v=False, y_batch_stride=0, V_in=None, V_ready=None):
     """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
     [36, Cout, Kpad]: one grouped input transform into V, ONE batched GEMM launch, one grouped output transform with
     the epilogue (outs: dense tensors, or slices with y_batch_stride).  Returns the outputs (and, with keep_v, the
@@ -256,7 +256,12 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     V, M = _wino_workspace(dev, 0 if keep_v else 36 * Tpad * C, 36 * Tpad * cout)
     shapes = tuple(tuple(x.shape) for x in xs)
     reuse = keep_v and V_in is not None and V_in[1] == shapes and V_in[0].numel() == 36 * Tpad * C   # (V, shapes) of the same inputs
-    if reuse:
+    # V_ready: (V, shapes) of exactly these inputs computed a moment ago by wino_wgrad_group(fuse_dgrad_input=True) -- the
+    # output gradient's two transforms in one pass -- so this call (the data gradient) starts at the GEMM
+    ready = not keep_v and V_ready is not None and V_ready[1] == shapes and V_ready[0].numel() >= 36 * Tpad * C
+    if ready:
+        V, reuse = V_ready[0], True
+    elif reuse:
         V = V_in[0]
     elif keep_v:                                     # the caller keeps B^T d B of the inputs for the weight gradient
         V = torch.empty(36 * Tpad * C, dtype=torch.float32, device=dev)
@@ -287,7 +292,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     return (outs, (V, tuple(tuple(x.shape) for x in xs))) if keep_v else outs   # V + the shapes it belongs to
 
 
-def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None):
+def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_input=False):
     """Weight gradient of a 3x3 / stride 1 / padding 1 convolution over several problems (gs[i] = dY [N,H,W,Cout],
     xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum."""
     lib = _hip.load()
@@ -305,7 +310,19 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None):
     assert all(g.shape[:3] == x.shape[:3] and g.is_contiguous() and x.is_contiguous() for g, x in zip(gs, xs))
     if not have_v:
         _wino_transform_in(xs, V, C, Tpad, 0)
-    _wino_transform_in(gs, Z, cout, Tpad, 1)
+    v_dy = None
+    if fuse_dgrad_input and have_v and len(gs) <= _hip.RN_MAX_GROUP:
+        # The data gradient of the same layer follows and needs B^T dy B of the same gs: both transforms in ONE pass over dy
+        # (rn_wino_input_both_group).  B^T dy B goes to the V half of the workspace (idle here: the forward's V was kept), and
+        # the (tensor, shapes) pair goes back to the caller for wino_conv_group(V_ready=...).
+        Vd, Z = _wino_workspace(dev, 36 * Tpad * cout, 36 * Tpad * cout)
+        g = _wino_group(gs, srcs=gs)
+        nb = 4.0 * (sum(t.numel() for t in gs) + 2 * 36 * T * cout)
+        _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_both_group(
+            ctypes.byref(g), Vd.data_ptr(), Z.data_ptr(), cout, 0, Tpad, _hip.stream())), "rn_wino_input_both_group")
+        v_dy = (Vd, tuple(tuple(t.shape) for t in gs))
+    else:
+        _wino_transform_in(gs, Z, cout, Tpad, 1)
     ku = (C + 31) // 32 * 32
     if dU is None or tuple(dU.shape) != (36, cout, ku):      # dU: a ZEROED [36, cout, ku] accumulator of the caller (used once)
         dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
@@ -314,7 +331,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None):
         (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0)))
     _hip.check(rc, "rn_conv_wgrad_batched")
     _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
-    return dw
+    return v_dy if fuse_dgrad_input else dw
 
 
 def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):

@@ -24,6 +24,11 @@ import torch
 from . import _hip, arch, conv as cv, ops
 
 
+# The two input-side transforms of an output gradient (for the weight gradient and for the data gradient of a Winograd layer) in
+# one pass over it; RN_WINO_FUSE_DY=0 keeps the two separate launches (A/B).
+FUSE_DY = os.environ.get("RN_WINO_FUSE_DY", "1") != "0"
+
+
 class Layer:
     """One convolution with its fused batch-norm / bias, the per-step packed weights and gradient accumulators."""
 
@@ -51,6 +56,7 @@ class Layer:
         self.uf = self.ud = None
         self.wf16 = self.wd16 = None               # bf16 copies of the packed weights (bf16 mode)
         self.saved_v = None                        # Winograd input transform of the forward, kept for the weight gradient
+        self.dy_v = None                           # B^T dy B of the step's output gradient, left by the weight gradient for the data gradient
 
     # ---- per-step preparation
     def prepare(self, P, cache):
@@ -196,7 +202,8 @@ class Layer:
             return outs
         if (wino or self.wino_active) and self.wino_ok and all(g.shape[3] == s.cout for g in gs):
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
-            return cv.wino_conv_group(gs, self.wino_weights(1), adds=adds, masks=masks, mask_mode=2, flops=fl)
+            ready, self.dy_v = getattr(self, "dy_v", None), None
+            return cv.wino_conv_group(gs, self.wino_weights(1), adds=adds, masks=masks, mask_mode=2, flops=fl, V_ready=ready)
         probs, outs, fl = [], [], 0.0
         for i, g in enumerate(gs):
             N = g.shape[0]
@@ -228,7 +235,8 @@ class Layer:
             return
         if self.wino_active and not in_relu and g.shape[3] == s.cout and g.is_contiguous() and x.is_contiguous():
             du, self.du = getattr(self, "du", None), None          # the zeroed slot is good for one accumulation
-            cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v, dU=du)
+            # (the data gradient of this layer follows: its input transform of g rides along -- bwd_data picks it up)
+            self.dy_v = cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY)
             self.saved_v = None
             return
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
@@ -243,7 +251,7 @@ class Layer:
                 self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
             du, self.du = getattr(self, "du", None), None
-            cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v, dU=du)
+            self.dy_v = cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY)
             self.saved_v = None
             return
         for g, x in zip(gs, xs):
@@ -259,8 +267,9 @@ class Layer:
                 return cv.dgrad_s2_classes_bf16(g, self.dgrad_weights16(), in_hw, s.cin, s.k, s.pad, **kw)
             return cv.dgrad_any_bf16(g, self.dgrad_weights16(), in_hw, s.cin, s.k, s.stride, s.pad, **kw)
         if self.wino_active and add2 is None and g.shape[3] == s.cout and g.is_contiguous():
+            ready, self.dy_v = getattr(self, "dy_v", None), None
             return cv.wino_conv_group([g], self.wino_weights(1), adds=None if add is None else [add],
-                                      masks=None if mask is None else [mask], mask_mode=mask_mode)[0]
+                                      masks=None if mask is None else [mask], mask_mode=mask_mode, V_ready=ready)[0]
         kw = dict(add=add, add_mode=1 if add is not None else 0, mask=mask, mask_mode=mask_mode,
                   flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
         if s.stride == 2 and s.k > 1:
@@ -301,7 +310,7 @@ class Layer:
             out[s.bn + ".bias"] = dbeta
         elif s.bias:
             out[s.name + ".bias"] = dbeta
-        self.dw = self.cs = self.wd = self.uf = self.ud = self.saved_v = None
+        self.dw = self.cs = self.wd = self.uf = self.ud = self.saved_v = self.dy_v = None
         return out
 
 
@@ -646,7 +655,7 @@ class Engine:
                                   torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks))
         _hip.check(_hip.load().rn_unpack_batched(hit[1].data_ptr(), hit[2].data_ptr(), hit[3], _hip.stream()), "rn_unpack_batched")
         for L in layers:
-            L.dw = L.cs = L.wd = L.uf = L.ud = L.saved_v = None
+            L.dw = L.cs = L.wd = L.uf = L.ud = L.saved_v = L.dy_v = None
 
     def _zero_grad_accumulators(self, device):
         """Weight-gradient and column-sum accumulators of every layer -- and the Winograd-domain accumulators dU of the layers that
@@ -768,7 +777,7 @@ class Engine:
         grads = {}
         self._zero_grad_accumulators(dreg.device)
         for L in Ls.values():
-            L.saved_v = None
+            L.saved_v = L.dy_v = None
         for n, v in S.pop("wino_v", {}).items():          # this call's Winograd input transforms (see forward)
             Ls[n].saved_v = v
 

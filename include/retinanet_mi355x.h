@@ -417,6 +417,9 @@ typedef struct rn_wino_group {
     const float *mask[RN_MAX_GROUP];
 } rn_wino_group;
 int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form, void *stream);
+/* Both input-side transforms of an output gradient in one pass over it: V = B^T dy B (rn_wino_input_group, dy_form 0: what the
+ * data gradient's GEMM reads) and Z = A dy A^T (dy_form 1: what the weight gradient's reads). */
+int rn_wino_input_both_group(const rn_wino_group *g, float *V, float *Z, int C, int64_t tile_offset, int64_t Tpad, void *stream);
 int rn_wino_output_group(const rn_wino_group *g, const float *M, int Cout, int64_t tile_offset, int64_t Tpad,
                          const float *scale, const float *shift, int mask_mode, int act, int64_t y_batch_stride, void *stream);
 int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);

@@ -518,3 +518,36 @@ def test_wide_dynamic_range_elementwise(cv, dev):
     for got, ref in ((nchw(y), y_ref), (nchw(dx), dx_ref), (dwu.view(cout, cin), dw_ref)):
         rel = ((got.cpu().double() - ref).abs() / ref.abs()).max()
         assert float(rel) <= 1e-5, float(rel)
+
+
+def test_split_mode_corners_that_differ_from_ieee_fp32(dev):
+    """RN_FP32_SPLIT (the library default) is not IEEE in three corners, documented in include/retinanet_mi355x.h, DESIGN.md 4.6
+    and INTEGRATION.md; this pins them so a change is noticed:
+      * an infinite operand gives NaN (inf - bf16(inf) in the residual), where the fp32 MFMA gives inf;
+      * a finite operand above the largest bf16 (3.3895e38) rounds its leading term to inf and gives NaN as well;
+      * operands below the bf16 NORMAL range lose their residual terms (flushed by the matrix core): the product is the
+        leading term's, i.e. correct to 2^-8 relative instead of 2^-24 -- on values below 1e-37.
+    Everything finite and normal is covered by the other tests of this module at 1e-5 relative."""
+    from retinanet_mi355x import conv
+    before = conv.get_fp32_mfma(), conv.PRESPLIT
+    cin, cout, N, H, W = 256, 128, 1, 8, 16               # K = 256 >= rn_fp32_split_min_k: the split kernels take it
+    w = torch.full((cout, cin, 1, 1), 0.5)
+    try:
+        out = {}
+        for mode in ("native", "split"):
+            conv.set_fp32_mfma(mode)
+            conv.PRESPLIT = True
+            wp = conv.pack_weights(w.to(dev), 0)
+            for name, val in (("inf", float("inf")), ("huge", 3.4e38), ("tiny", 3e-39)):
+                x = torch.ones(N, H, W, cin) * (1e-39 if name == "tiny" else 1.0)
+                x[0, 2, 3, 5] = val
+                out[mode, name] = conv.fprop(x.to(dev), wp, cout, 1, 1, 0).cpu()
+        assert torch.isinf(out["native", "inf"][0, 2, 3]).all() and torch.isfinite(out["native", "inf"][0, 2, 4]).all()
+        assert torch.isnan(out["split", "inf"][0, 2, 3]).all() and torch.isfinite(out["split", "inf"][0, 2, 4]).all()
+        assert torch.isnan(out["split", "huge"][0, 2, 3]).all()                        # native: 0.5 * 3.4e38 + 127.5, finite
+        assert torch.isfinite(out["native", "huge"][0, 2, 3]).all()
+        t_n, t_s = out["native", "tiny"], out["split", "tiny"]
+        assert torch.isfinite(t_s).all() and float((t_n - t_s).abs().max()) <= 2.0 ** -7 * float(t_n.abs().max()) + 1e-44
+    finally:
+        conv.set_fp32_mfma(before[0])
+        conv.PRESPLIT = before[1]
