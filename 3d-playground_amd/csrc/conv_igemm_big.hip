@@ -27,29 +27,32 @@
 // the A planes; the MFMA phase only reads operands.  Two LDS buffers of 3 * (BM + BN) * 32 bytes, one barrier per K-step, the
 // loop body one basic block (branch-free addressing from a per-thread tap mask).  Conditions (the launcher's): pre-split
 // weights, Cin a multiple of 16, div_shift 0, kh * kw <= 24, Cout a multiple of 4, no input ReLU.
+#include <type_traits>
+
 #include "conv_igemm_tile.h"
 
-template <int TMW, int TNW, bool GENERAL, bool RAW>
+template <int WGM, int WGN, int TMW, int TNW, bool GENERAL, bool RAW, int NBUF = 2>
 __device__ __forceinline__ void conv_big_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
                                               float *__restrict__ y, const float *__restrict__ scale,
                                               const float *__restrict__ shift, const float *__restrict__ add,
                                               const float *__restrict__ mask, const float *__restrict__ add2, const int tile) {
     constexpr int BK = 16;
-    constexpr int BM = 64 * TMW, BN = 64 * TNW;            // 2 x 2 waves
+    constexpr int NT = 64 * WGM * WGN;                     // threads: WGM x WGN waves
+    constexpr int BM = 32 * TMW * WGM, BN = 32 * TNW * WGN;
     constexpr int APL = BM * 8, BPL = BN * 8;              // floats' worth of one bf16 plane: rows x 32 bytes
     constexpr int STEP = 3 * (APL + BPL);                  // floats per buffer: A planes h, m, l, then B planes
     constexpr int BOFF = 3 * APL;
-    constexpr int UPT = BM / 128;                          // 8-value units of an A row per thread (1: two threads per row, 2: one)
-    constexpr int NBI = 3 * BN / 32, IB = NBI / 4;         // direct-to-LDS instructions that fill the B planes, per wave
+    constexpr int UPT = 2 * BM / NT;                       // 8-value units of an A row per thread (1: two threads per row, 2: one)
+    constexpr int NBI = 3 * BN / 32, IB = NBI / (WGM * WGN);   // direct-to-LDS instructions that fill the B planes, per wave
     constexpr int LDT = BN + 4;
     constexpr int RP = 64;                                 // epilogue: tile rows per pass through LDS
     constexpr int EP = BM / RP;
-    static_assert(UPT == 1 || UPT == 2, "BM = 128 or 256");
-    static_assert(2 * STEP >= RP * LDT && NBI % 4 == 0, "tile shape");
-    __shared__ float lds[2 * STEP];
+    static_assert(UPT == 1 || UPT == 2, "one or two threads per activation row");
+    static_assert(NBUF * STEP >= RP * LDT && NBI % (WGM * WGN) == 0 && (NBUF == 2 || NBUF == 3), "tile shape");
+    __shared__ float lds[NBUF * STEP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int ntn = (d.Cout + BN - 1) / BN;
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -157,8 +160,97 @@ __device__ __forceinline__ void conv_big_tile(const rn_conv_desc &d, const float
         fbs[t] = BOFF + 4 * (2 * rb + ((lane >> 5) ^ ((rb >> 4) & 1)));
     }
 
-    // ---- K loop (see conv_igemm_tile.h, SPLIT 3, for why every piece sits where it sits)
+    // ---- K loop, three LDS buffers: every load stays in flight ACROSS the barrier that ends the step it was issued in.
+    // With two buffers the step ends in s_waitcnt vmcnt(0): whatever of its loads has not landed by then stalls the wave,
+    // and all waves of a workgroup issue their loads together and wait together.  Here the loads are inline assembly (the
+    // compiler does not see them, so it inserts no waits of its own), issued in a fixed order -- the A values of step ks + 2
+    // (registers), then the weight planes of step ks + 2 (direct to LDS, buffer (ks + 2) % 3) -- and waited for by COUNT:
+    //   top of step ks:   vmcnt(IB)           the A registers of step ks + 1 are there (its planes may still be in flight)
+    //   end of step ks:   vmcnt(NA + IB)      the weight planes of step ks + 1 have landed; this step's loads stay in flight
+    // then the barrier.  Buffer use: step ks reads buffer ks % 3; the A planes of step ks + 1 are written (split) into buffer
+    // (ks + 1) % 3, last read in step ks - 2; the planes of step ks + 2 go where step ks - 1 read, released by its barrier.
+    if constexpr (NBUF == 3) {
+        constexpr int NA = 2 * UPT;
+        const v4i32 rs_av = make_rsrc(x + (int64_t)n_first * d.x_batch_stride,
+                                      (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
+        auto load_a_asm = [&](ARegs &r) {
+            const int t = f_r * d.kw + f_s;
+            const int delta = (f_r * d.Wi + f_s) * d.b * d.Cin * 4;
+            const unsigned valid = 0u - ((a_mask >> (t & 31)) & 1u);
+            const unsigned v = ((unsigned)(a_base + delta) & valid) | (0x80000000u & ~valid);
+            const unsigned so = (unsigned)(f_c * 4);
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r.v[0]) : "v"(v), "s"(rs_av), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(r.v[1]) : "v"(v), "s"(rs_av), "s"(so) : "memory");
+            if constexpr (UPT == 2) {
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:32" : "=v"(r.v[2 * UPT - 2]) : "v"(v), "s"(rs_av), "s"(so) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:48" : "=v"(r.v[2 * UPT - 1]) : "v"(v), "s"(rs_av), "s"(so) : "memory");
+            }
+            f_c += BK;
+            const bool wrap = f_c >= d.Cin;
+            f_c = wrap ? 0 : f_c;
+            f_s += wrap ? 1 : 0;
+            const bool wrap_s = f_s == d.kw;
+            f_s = wrap_s ? 0 : f_s;
+            f_r += wrap_s ? 1 : 0;
+        };
+        // wait until at most N loads are outstanding, and tie the registers to the wait so that no use is scheduled before it
+        auto wait_regs = [&](ARegs &r, auto n_tag) {
+            constexpr int N = decltype(n_tag)::value;
+            if constexpr (UPT == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2 * UPT - 2]), "+v"(r.v[2 * UPT - 1]) : "n"(N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.v[0]), "+v"(r.v[1]) : "n"(N) : "memory");
+        };
+        ARegs ra, rn;
+        load_a_asm(ra);                                     // A(0)
+        dma_b(0, 0);                                        // B(0)
+        load_a_asm(rn);                                     // A(1)
+        dma_b(1, 1);                                        // B(1)
+        wait_regs(ra, std::integral_constant<int, IB + NA + IB>{});    // A(0) arrived
+        split_a(0, ra);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + IB) : "memory");   // B(0) landed; A(1), B(1) in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int b0 = 0, b1 = 1, b2 = 2;                         // buffers of steps ks, ks + 1, ks + 2
+        auto k_step3 = [&](int ks, ARegs &cur, ARegs &nxt) {
+            wait_regs(cur, std::integral_constant<int, IB>{});         // A(ks + 1) arrived
+            load_a_asm(nxt);                                // A(ks + 2)
+            dma_b(ks + 2, b2);                              // B(ks + 2)
+            Split8 sa[TMW], sb[TNW];
+            const float *S = lds + b0 * STEP;
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                const float *Ap = S + fas[t];
+                sa[t].h = *reinterpret_cast<const bf16x8 *>(Ap);
+                sa[t].m = *reinterpret_cast<const bf16x8 *>(Ap + APL);
+                sa[t].l = *reinterpret_cast<const bf16x8 *>(Ap + 2 * APL);
+            }
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) {
+                const float *Bp = S + fbs[t];
+                sb[t].h = *reinterpret_cast<const bf16x8 *>(Bp);
+                sb[t].m = *reinterpret_cast<const bf16x8 *>(Bp + BPL);
+                sb[t].l = *reinterpret_cast<const bf16x8 *>(Bp + 2 * BPL);
+            }
+            split_a(b1, cur);
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TNW; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+            RN_PIN();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + IB) : "memory");   // B(ks + 1) landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the A planes of step ks + 1 are written
+            __builtin_amdgcn_s_barrier();
+            const int t_ = b0; b0 = b1; b1 = b2; b2 = t_;
+        };
+        for (int ks = 0; ks < nks; ks += 2) {
+            k_step3(ks, rn, ra);
+            if (ks + 1 < nks) k_step3(ks + 1, ra, rn);
+        }
+        rn_wait_dma();                                      // the loads past the last step, before the epilogue reuses the LDS
+        __syncthreads();
+    }
+    // ---- K loop, two buffers (see conv_igemm_tile.h, SPLIT 3, for why every piece sits where it sits)
     ARegs ar, arn;
+    if constexpr (NBUF == 2) {
     load_a(ar); dma_b(0, 0); split_a(0, ar);
     load_a(ar);
     rn_wait_dma();
@@ -201,6 +293,7 @@ __device__ __forceinline__ void conv_big_tile(const rn_conv_desc &d, const float
         k_step(ks, 0, ar, arn);
         if (ks + 1 < nks) k_step(ks + 1, 1, arn, ar);
     }
+    }
 
     // ---- plain GEMM (the Winograd stage): straight from the accumulators, two full 128-byte row segments per instruction
     if constexpr (RAW) {
@@ -220,7 +313,7 @@ __device__ __forceinline__ void conv_big_tile(const rn_conv_desc &d, const float
 
     // ---- epilogue through LDS, RP rows per pass (conv_igemm_tile.h: same arithmetic, same macros)
     float *T = lds;
-    constexpr int CPR = BN / 4, RPP = 256 / CPR;
+    constexpr int CPR = BN / 4, RPP = NT / CPR;
     const int c4 = tid % CPR;
     const int col = n0 + 4 * c4;
     const bool col_ok = col < d.Cout;
@@ -286,17 +379,17 @@ __device__ __forceinline__ void conv_big_tile(const rn_conv_desc &d, const float
     }
 }
 
-template <int TMW, int TNW, bool GENERAL, bool RAW>
-__global__ __launch_bounds__(256, 1) void conv_igemm_big_kernel(const rn_conv_desc d, const float *__restrict__ x,
+template <int WGM, int WGN, int TMW, int TNW, bool GENERAL, bool RAW, int NBUF = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_big_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                                 const float *__restrict__ w, float *__restrict__ y,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 const float *__restrict__ add, const float *__restrict__ mask,
                                                                 const float *__restrict__ add2) {
-    conv_big_tile<TMW, TNW, GENERAL, RAW>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_big_tile<WGM, WGN, TMW, TNW, GENERAL, RAW, NBUF>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-template <int TMW, int TNW>
-__global__ __launch_bounds__(256, 1) void conv_igemm_big_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
+template <int WGM, int WGN, int TMW, int TNW, int NBUF = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_big_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
                                                                         const float *__restrict__ scale,
                                                                         const float *__restrict__ shift) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -310,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_big_grouped_kernel(const rn
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_big_tile<TMW, TNW, true, false>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_big_tile<WGM, WGN, TMW, TNW, true, false, NBUF>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // Which problems take the big tile: RN_BIG_TILE=0 turns it off (A/B); min_tiles = launches with fewer 256 x 256 tiles leave
@@ -339,10 +432,23 @@ bool rn_igemm_big_launch(int variant, const rn_conv_desc *d, const float *x, con
     if (!big_ok(d) || (variant != 0 && variant != 4 && variant != 5)) return false;
     const int64_t tiles = big_tiles(d);
     if (tiles < big_min_tiles() || tiles > 0x7fffffff) return false;
-    const dim3 grid((unsigned)tiles), block(256);
-    if (variant == 0) hipLaunchKernelGGL((conv_igemm_big_kernel<4, 4, false, true>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else if (variant == 4) hipLaunchKernelGGL((conv_igemm_big_kernel<4, 4, false, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else hipLaunchKernelGGL((conv_igemm_big_kernel<4, 4, true, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    const dim3 grid((unsigned)tiles);
+    if (big_tile_mode() == 3) {                             // eight waves, three LDS buffers, loads in flight across the barrier
+        const dim3 block(512);
+        if (variant == 0) hipLaunchKernelGGL((conv_igemm_big_kernel<2, 4, 4, 2, false, true, 3>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else if (variant == 4) hipLaunchKernelGGL((conv_igemm_big_kernel<2, 4, 4, 2, false, false, 3>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else hipLaunchKernelGGL((conv_igemm_big_kernel<2, 4, 4, 2, true, false, 3>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    } else if (big_tile_mode() == 2) {                      // eight waves (two per SIMD), 128 x 64 per wave
+        const dim3 block(512);
+        if (variant == 0) hipLaunchKernelGGL((conv_igemm_big_kernel<2, 4, 4, 2, false, true>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else if (variant == 4) hipLaunchKernelGGL((conv_igemm_big_kernel<2, 4, 4, 2, false, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else hipLaunchKernelGGL((conv_igemm_big_kernel<2, 4, 4, 2, true, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    } else {                                                // four waves (one per SIMD), 128 x 128 per wave
+        const dim3 block(256);
+        if (variant == 0) hipLaunchKernelGGL((conv_igemm_big_kernel<2, 2, 4, 4, false, true>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else if (variant == 4) hipLaunchKernelGGL((conv_igemm_big_kernel<2, 2, 4, 4, false, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else hipLaunchKernelGGL((conv_igemm_big_kernel<2, 2, 4, 4, true, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    }
     const hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? RN_OK : (int)e;
     return true;
@@ -359,7 +465,9 @@ bool rn_igemm_big_grouped_launch(const rn_conv_group *g, const float *w, const f
     }
     for (int i = g->n; i < RN_MAX_GROUP; ++i) gb.tile_end[i] = (int)total;
     if (total < big_min_tiles() || total > 0x7fffffff) return false;
-    hipLaunchKernelGGL((conv_igemm_big_grouped_kernel<4, 4>), dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
+    if (big_tile_mode() == 3) hipLaunchKernelGGL((conv_igemm_big_grouped_kernel<2, 4, 4, 2, 3>), dim3((unsigned)total), dim3(512), 0, s, gb, w, scale, shift);
+    else if (big_tile_mode() == 2) hipLaunchKernelGGL((conv_igemm_big_grouped_kernel<2, 4, 4, 2>), dim3((unsigned)total), dim3(512), 0, s, gb, w, scale, shift);
+    else hipLaunchKernelGGL((conv_igemm_big_grouped_kernel<2, 2, 4, 4>), dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
     const hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? RN_OK : (int)e;
     return true;

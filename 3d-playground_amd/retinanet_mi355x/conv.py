@@ -76,9 +76,14 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
         _hip.check(rc, "rn_conv_igemm_splitk")
         return y
     wptr, d.w_format = _w_operand(w_packed)
+    nb = 0.0
+    if prof.ACTIVE is not None:            # algorithmic bytes: every operand once (the split kernels read weights as 6-byte terms)
+        out_el = N * Ho * Wo * Cout
+        nb = 4.0 * (x.numel() + out_el * (1 + (add is not None) + (mask is not None))) + (6.0 if d.w_format else 4.0) * w_packed.numel() \
+            + (4.0 * add2.numel() if add2 is not None else 0.0)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm(
         ctypes.byref(d), x.data_ptr(), wptr, y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
-        _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), _hip.stream()))
+        _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), _hip.stream()), nb)
     _hip.check(rc, "rn_conv_igemm")
     return y
 
@@ -356,8 +361,15 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
     kind = "conv_igemm_4x1" if problems[0]["geom"][2] <= 64 else "conv_igemm_2x2"
     if prof.BY_SHAPE:
         kind += " grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh)
+    nb = 0.0
+    if prof.ACTIVE is not None:
+        nb = (6.0 if wfmt else 4.0) * w_packed.numel()
+        for pr in problems:
+            dd = pr["geom"]
+            out_el = pr["x"].shape[0] * dd[0] * dd[1] * dd[2]
+            nb += 4.0 * (pr["x"].numel() + out_el * (1 + (pr.get("add") is not None) + (pr.get("mask") is not None)))
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_grouped(
-        ctypes.byref(g), wptr, _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
+        ctypes.byref(g), wptr, _hip.ptr(scale), _hip.ptr(shift), _hip.stream()), nb)
     _hip.check(rc, "rn_conv_igemm_grouped")
 
 

@@ -275,7 +275,9 @@ def pmc_traffic(kind):
                                  "conv_igemm_split_grouped_kernel<2, 2"),
               "conv_igemm_4x1": ("conv_igemm_kernel<4, 1", "conv_igemm_grouped_kernel<4, 1", "conv_igemm_split_kernel<4, 1",
                                  "conv_igemm_split_grouped_kernel<4, 1"),
-              "conv_wgrad": ("conv_wgrad_kernel",)}.get(kind)
+              "conv_wgrad": ("conv_wgrad_kernel",),
+              "wino_input": ("wino_in_kernel", "wino_in_both_kernel", "wino_dy_kernel"),
+              "wino_output": ("wino_out_kernel",)}.get(kind)
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if prefix is None or not os.path.exists(path):
         return None
@@ -504,7 +506,10 @@ def main():
                     gbs = a["work_total"] / (a["ms_total"] * 1e-3) / 1e9 if a["ms_total"] > 0 else 0.0
                     kernels[kind] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                      "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": a["launches"] // args.steps,
-                                     "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
+                                     "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4),
+                                     "algorithmic_bytes": int(a["work_total"] / max(a["launches"], 1)), "traffic": pmc_traffic(kind)}
+                    if kernels[kind]["traffic"]:
+                        kernels[kind]["traffic_over_algorithmic"] = round(kernels[kind]["traffic"] / kernels[kind]["algorithmic_bytes"], 3)
                     continue
                 tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12 if a["ms_total"] > 0 else 0.0
                 peak = PEAK_BF16_MFMA_TF if kind.endswith("_bf16") else conv_peak
@@ -519,6 +524,13 @@ def main():
             r = dict(kernels[dom])
             r["kernel"] = dom
             r["traffic"] = pmc_traffic(dom)
+            # ALGORITHMIC bytes per launch of the same family (every operand once), so that the line itself shows the ratio:
+            # traffic well above it = re-reads
+            a = summ[dom]
+            if a.get("bytes_total"):
+                r["algorithmic_bytes"] = int(a["bytes_total"] / max(a["launches"], 1))
+                if r["traffic"]:
+                    r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
             line["roofline"] = r
             kernels.update(loss_kernel_roofline(dev, B, H, W))
             # north_star target "MFMA roofline on the ResNet-50-FPN forward": conv kernels of forward-only passes, with the

@@ -13,14 +13,17 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def cv(dev):
+@pytest.fixture(scope="module", params=["1", "2", "3"])
+def cv(dev, request):
+    """RN_BIG_TILE=1: four waves of 128 x 128; =2: eight waves (two per SIMD) of 128 x 64; =3: the same with three LDS buffers and
+    counted waits (loads in flight across the barrier)."""
     from retinanet_mi355x import conv
     before = conv.get_fp32_mfma(), conv.PRESPLIT, os.environ.get("RN_BIG_TILE_MIN"), os.environ.get("RN_BIG_TILE")
     conv.set_fp32_mfma("split")
     conv.PRESPLIT = True
     os.environ["RN_BIG_TILE_MIN"] = "1"
-    os.environ["RN_BIG_TILE"] = "1"
+    os.environ["RN_BIG_TILE"] = request.param
+    conv._big_mode = request.param
     yield conv
     conv.set_fp32_mfma(before[0])
     conv.PRESPLIT = before[1]
@@ -54,7 +57,7 @@ def _both_kernels(cv, fn):
     try:
         b = fn()
     finally:
-        os.environ["RN_BIG_TILE"] = "1"
+        os.environ["RN_BIG_TILE"] = cv._big_mode
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     return a
 

@@ -136,7 +136,25 @@ def main():
         s, c, b = net(frames)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / 10
-    print("%-42s %7.2f ms per frame      %6.1f frames/s  (%d detections kept)" % ("single frame, per-class NMS", dt * 1e3, 1 / dt, s.numel()))
+    print("%-42s %7.2f ms per frame      %6.1f frames/s  (%d detections kept)" % ("single frame, per-class NMS (noise frame: stress)", dt * 1e3, 1 / dt, s.numel()))
+    # The same path on a frame a detector would see: a flat road with a few dozen vehicle-sized bright rectangles.  Random weights
+    # then score the anchors around the rectangles apart from the background, the 10 000 candidates per class crowd there and
+    # NMS leaves what a real frame leaves -- hundreds, not the ~25 000 survivors of pure noise (which time the NMS, not the path).
+    gen = torch.Generator().manual_seed(11)
+    scene = torch.full((1, 3, H, W), -1.0)
+    for _ in range(40):
+        h_, w_ = int(torch.randint(40, 140, (1,), generator=gen)), int(torch.randint(60, 220, (1,), generator=gen))
+        y0, x0 = int(torch.randint(300, H - h_, (1,), generator=gen)), int(torch.randint(0, W - w_, (1,), generator=gen))
+        scene[0, :, y0:y0 + h_, x0:x0 + w_] = torch.rand(3, 1, 1, generator=gen) * 2.0 + 0.5
+    scene = scene.to(dev)
+    net(scene)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(10):
+        s, c, b = net(scene)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 10
+    print("%-42s %7.2f ms per frame      %6.1f frames/s  (%d detections kept)" % ("single frame, per-class NMS (40-vehicle scene)", dt * 1e3, 1 / dt, s.numel()))
 
 
 if __name__ == "__main__":
