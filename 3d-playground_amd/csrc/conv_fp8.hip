@@ -1,0 +1,389 @@
+// fp8 (OCP e4m3fn) implicit-GEMM convolution, forward / inference form -- BASELINE configs[4] ("fp8 weights / activations on the
+// CDNA4 fp8 MFMA"), first cut: the fprop of every convolution of the detector behind the fp32 stem (D/model.py:59-205,
+// D/utils.py:12-80; network of configs[4]: D/model.py:434-443) with its fused frozen batch-norm / bias / residual / ReLU /
+// sigmoid / FPN upsample-add epilogue.  No backward pass, no weight gradient: training stays fp32 / bf16.
+//
+// Arithmetic: v_mfma_scale_f32_32x32x64_f8f6f4 with both operands e4m3 and every block scale 2^0 -- the scaled form is the one
+// that runs at the fp8 rate (twice the bf16 MFMA per clock; the non-scaled fp8 MFMA runs at the bf16 rate:
+// MI355X_MICROARCH.md, Matrix cores); fp32 accumulation.  Quantisation is by real-valued scales applied in the epilogue, where
+// they cost nothing: weights per OUTPUT CHANNEL (w_q = fp8(w / sw[c]), sw[c] = max|w[c]| / 448, rn_fp8_quantize_rows),
+// activations per TENSOR (x_q = fp8(x / sx), sx calibrated by the host logic against the bf16 / fp32 path):
+//     y = act( acc * (sx * sw[c] * bn_scale[c]) + shift[c] + add_q * s_add ),   stored as fp8(y / sy) or as fp32.
+// The caller folds sx * sw[c] * bn_scale[c] into `scale`.
+//
+// Tile / staging: the bf16 kernel's (conv_bf16.hip) BYTE for byte -- a staged row is 64 bytes of K (64 fp8 instead of 32 bf16),
+// direct-to-LDS buffer loads, out-of-range offsets as zero padding, the XOR swizzle on the load's source and on the fragment read.
+// One 32x32x64 operand = this lane's 32 consecutive K values of row lane & 31 (K half lane >> 5): two ds_read_b128.  Per 64-byte
+// K-step a wave issues 8 reads against 4 MFMAs of 64 cycles: twice the FLOPs of the bf16 kernel on the same staged bytes.
+//
+// Roofline: MFMA by FLOPs (~5 PF dense fp8); in practice staging bandwidth, like the bf16 kernel.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define F8_BK 64                 // K elements per step = 64 bytes per staged row
+#define F8_MAX 448.0f            // largest finite e4m3fn
+
+__device__ __forceinline__ int f8_swz(int row) { return (row >> 2) & 3; }
+
+// two floats -> two e4m3 in the low / high half of a dword (round to nearest even, saturating by the clamp in front)
+__device__ __forceinline__ float f8_clamp(float a) { return fminf(fmaxf(a, -F8_MAX), F8_MAX); }
+__device__ __forceinline__ int f8_pack4(float a, float b, float c, float d) {
+    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(a), f8_clamp(b), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(c), f8_clamp(d), lo, true);
+}
+
+// ---------------------------------------------------------------------------------------------- quantisation
+// dst[i] = fp8(src[i] * inv_scale): activations entering the fp8 part of the network (per-tensor scale).
+__global__ void fp8_quantize_kernel(const float *__restrict__ src, int *__restrict__ dst, int64_t n4, float inv_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4 *>(src)[i];
+    dst[i] = f8_pack4(v.x * inv_scale, v.y * inv_scale, v.z * inv_scale, v.w * inv_scale);
+}
+extern "C" int rn_fp8_quantize(const float *src, void *dst, int64_t n, float inv_scale, void *stream) {
+    if (n <= 0 || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 3)) return RN_EINVAL;
+    hipLaunchKernelGGL(fp8_quantize_kernel, dim3(rn_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<int *>(dst), n / 4, inv_scale);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+__global__ void fp8_dequantize_kernel(const int *__restrict__ src, float *__restrict__ dst, int64_t n4, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int q = src[i];
+    reinterpret_cast<float4 *>(dst)[i] = make_float4(__builtin_amdgcn_cvt_f32_fp8(q, 0) * scale, __builtin_amdgcn_cvt_f32_fp8(q, 1) * scale,
+                                                     __builtin_amdgcn_cvt_f32_fp8(q, 2) * scale, __builtin_amdgcn_cvt_f32_fp8(q, 3) * scale);
+}
+extern "C" int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float scale, void *stream) {
+    if (n <= 0 || (n & 3) || ((uintptr_t)src & 3) || ((uintptr_t)dst & 15)) return RN_EINVAL;
+    hipLaunchKernelGGL(fp8_dequantize_kernel, dim3(rn_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const int *>(src), dst, n / 4, scale);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// Packed fp32 weight rows [rows][Kpad] (rn_pack_weights) -> fp8 rows [rows][Kpad64] (Kpad rounded up to 64: a K-step reads 64
+// bytes of a row) with one scale per row: row_scale[r] = max|row| / 448 (1 for an all-zero row), dst = fp8(src / row_scale[r]).
+// One workgroup per row.
+__global__ __launch_bounds__(256) void fp8_quantize_rows_kernel(const float *__restrict__ src, unsigned char *__restrict__ dst,
+                                                                float *__restrict__ row_scale, int Kpad, int Kpad64) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const float *s = src + (int64_t)r * Kpad;
+    float m = 0.f;
+    for (int k = threadIdx.x; k < Kpad; k += 256) m = fmaxf(m, fabsf(s[k]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = m > 0.f ? m / F8_MAX : 1.f;
+    if (threadIdx.x == 0) row_scale[r] = sc;
+    const float inv = 1.f / sc;
+    int *d = reinterpret_cast<int *>(dst + (int64_t)r * Kpad64);
+    for (int k4 = threadIdx.x; k4 < Kpad64 / 4; k4 += 256) {
+        const int k = 4 * k4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (k + j < Kpad) ? s[k + j] * inv : 0.f;
+        d[k4] = f8_pack4(v[0], v[1], v[2], v[3]);
+    }
+}
+extern "C" int rn_fp8_quantize_rows(const float *w_packed, void *w_q, float *row_scale, int64_t rows, int Kpad, void *stream) {
+    if (rows <= 0 || Kpad <= 0 || (Kpad & 3) || ((uintptr_t)w_q & 15)) return RN_EINVAL;
+    hipLaunchKernelGGL(fp8_quantize_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, w_packed,
+                       reinterpret_cast<unsigned char *>(w_q), row_scale, Kpad, (Kpad + 63) / 64 * 64);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- implicit GEMM
+struct Fp8Args {
+    float add_scale;             // the addend's per-tensor scale (its values are fp8)
+    float out_inv_scale;         // 1 / the result's per-tensor scale (fp8 result), unused for an fp32 result
+};
+
+// 128 x 128 output tile by 2 x 2 waves, each a 64 x 64 sub-tile = 2 x 2 accumulators of the 32x32x64 MFMA.
+template <bool YF32>
+__global__ __launch_bounds__(256, 3) void conv_igemm_fp8_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
+                                                                const unsigned char *__restrict__ w, void *__restrict__ yv,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                const unsigned char *__restrict__ add, const Fp8Args fa_) {
+    constexpr int BM = 128, BN = 128, NW = 4;
+    constexpr int RF = 16;                                   // 4-byte words per staged row: 64 bytes
+    constexpr int RPI = 16;                                  // rows one wave instruction fills (1 KiB / 64 B)
+    constexpr int IA = BM / RPI / NW, IB = BN / RPI / NW;    // DMA instructions per wave per K-step and operand
+    constexpr int STEP = (BM + BN) * RF;                     // words per buffer: A rows, then B rows
+    constexpr int LDT = BN + 4;
+    constexpr int RP = 64;
+    constexpr int NBUF = 3;
+    constexpr int LDSF = NBUF * STEP > RP * LDT ? NBUF * STEP : RP * LDT;
+    __shared__ float lds[LDSF];
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ntn = (d.Cout + BN - 1) / BN;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int64_t M = (int64_t)d.N * HoWo;
+    const int K = d.kh * d.kw * d.Cin;
+    const int Kpad = (K + 63) / 64 * 64;                     // fp8 weight rows: zero-padded to a multiple of 64 (rn_fp8_quantize_rows)
+    const int nks = Kpad / F8_BK;
+    const int dmask = (1 << d.div_shift) - 1;
+
+    const int n_first = (int)(m0 / HoWo);
+    const int64_t x_elems = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
+    const v4i32 rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride, (unsigned)(x_elems > 0x7FFFFFFF ? 0x7FFFFFFF : x_elems));
+    const v4i32 rs_b = make_rsrc(w, (unsigned)((int64_t)d.Cout * Kpad));
+
+    // staging geometry: instruction j of this wave fills rows (wave*I + j)*16 .. +15; the lane fills 16-byte position pos of row
+    // rsub, i.e. fetches logical chunk pos ^ swz(row) = 16 elements of K
+    const int pos = lane & 3, rsub = lane >> 2;
+    int a_h[IA], a_w[IA], a_img[IA], a_c[IA];
+    unsigned a_voff[IA];
+    const int rel0 = m0 - n_first * HoWo;
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+        const int row = (wave * IA + j) * RPI + rsub;
+        a_c[j] = 16 * (pos ^ f8_swz(row));
+        if ((int64_t)m0 + row < M) {
+            const unsigned rel = (unsigned)(rel0 + row);
+            const unsigned n = rel / (unsigned)HoWo;
+            const unsigned rem = rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)d.Wo, ow = rem - oh * (unsigned)d.Wo;
+            a_img[j] = (int)((int64_t)n * d.x_batch_stride);
+            a_h[j] = (int)oh * d.a + d.p;
+            a_w[j] = (int)ow * d.a + d.p_w;
+        } else {
+            a_img[j] = 0;
+            a_h[j] = -(1 << 28);
+            a_w[j] = 0;
+        }
+        a_voff[j] = 0x80000000u;
+    }
+    unsigned b_voff[IB];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int row = (wave * IB + j) * RPI + rsub;
+        const int n = n0 + row;
+        b_voff[j] = n < d.Cout ? (unsigned)(n * Kpad + 16 * (pos ^ f8_swz(row))) : 0x80000000u;
+    }
+    const bool fast = (d.Cin % F8_BK) == 0;                  // a K-step lies inside one filter tap
+    int f_r = 0, f_s = 0, f_c = 0;
+    const unsigned lds0 = lds_addr(lds);
+    auto dma_step = [&](int ks, int buf) {
+        const unsigned A = lds0 + (unsigned)((buf * STEP + (wave_u * IA) * RPI * RF) * 4);
+        const unsigned B = lds0 + (unsigned)((buf * STEP + BM * RF + (wave_u * IB) * RPI * RF) * 4);
+#pragma unroll
+        for (int j = 0; j < IB; ++j) dma16(rs_b, B + j * (RPI * RF * 4), b_voff[j], (unsigned)(ks * F8_BK));
+        if (fast) {
+            if (f_c == 0) {
+                const bool tap_ok = f_r < d.kh;
+                const int hoff = f_r * d.b, woff = f_s * d.b;
+#pragma unroll
+                for (int j = 0; j < IA; ++j) {
+                    const int nh = a_h[j] + hoff, nw = a_w[j] + woff;
+                    const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+                    const bool ok = tap_ok & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
+                    a_voff[j] = ok ? (unsigned)(a_img[j] + (ih * d.Wi + iw) * d.Cin + a_c[j]) : 0x80000000u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < IA; ++j) dma16(rs_a, A + j * (RPI * RF * 4), a_voff[j], (unsigned)f_c);
+            f_c += F8_BK;
+            if (f_c >= d.Cin) { f_c = 0; if (++f_s == d.kw) { f_s = 0; ++f_r; } }
+        } else {
+#pragma unroll
+            for (int j = 0; j < IA; ++j) {                   // Cin % 16 == 0: a 16-byte chunk stays inside one tap
+                const int k = ks * F8_BK + a_c[j];
+                const int tap = k / d.Cin;
+                const int c0 = k - tap * d.Cin;
+                const int r = tap / d.kw, s_ = tap - r * d.kw;
+                const int nh = a_h[j] + r * d.b, nw = a_w[j] + s_ * d.b;
+                const int ih = nh >> d.div_shift, iw = nw >> d.div_shift;
+                const bool ok = (r < d.kh) & ((nh | nw) >= 0) & (((nh | nw) & dmask) == 0) & (ih < d.Hi) & (iw < d.Wi);
+                dma16(rs_a, A + j * (RPI * RF * 4), ok ? (unsigned)(a_img[j] + (ih * d.Wi + iw) * d.Cin + c0) : 0x80000000u, 0u);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // fragment addresses (words within a buffer): row = lane & 31 of each 32-row MFMA tile, logical chunks 2h and 2h + 1 (h = lane >> 5:
+    // this lane's 32 consecutive K values), at their swizzled positions
+    int fa[2][2], fb[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+            const int ch = 2 * (lane >> 5) + c;
+            fa[t][c] = ra * RF + 4 * (ch ^ f8_swz(ra));
+            fb[t][c] = BM * RF + rb * RF + 4 * (ch ^ f8_swz(rb));
+        }
+    const int one = 0x7F7F7F7F;                              // E8M0 block scales: 2^0 in every byte
+    auto multiply = [&](int buf) {
+        const float *S = lds + buf * STEP;
+        i32x8 a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const i32x4 a0 = *reinterpret_cast<const i32x4 *>(S + fa[t][0]), a1 = *reinterpret_cast<const i32x4 *>(S + fa[t][1]);
+            const i32x4 b0 = *reinterpret_cast<const i32x4 *>(S + fb[t][0]), b1 = *reinterpret_cast<const i32x4 *>(S + fb[t][1]);
+            a[t] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            b[t] = i32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[tm], b[tn], acc[tm][tn], 0, 0, 0, one, 0, one);
+    };
+
+    // K loop over a ring of three LDS buffers, counted waits (conv_bf16.hip: same structure)
+    constexpr int NLD = IA + IB;
+    auto wait_keep = [&](int steps_in_flight) {
+        if (steps_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    };
+    const int pre = nks < NBUF - 1 ? nks : NBUF - 1;
+    for (int s_ = 0; s_ < pre; ++s_) dma_step(s_, s_);
+    wait_keep(pre - 1);
+    __syncthreads();
+    int rb = 0, wb = NBUF - 1;
+    for (int ks = 0; ks < nks; ++ks) {
+        if (ks + NBUF - 1 < nks) dma_step(ks + NBUF - 1, wb);
+        multiply(rb);
+        const int later = nks - 2 - ks;
+        wait_keep(later < NBUF - 2 ? later : NBUF - 2);
+        __syncthreads();
+        rb = rb == NBUF - 1 ? 0 : rb + 1;
+        wb = wb == NBUF - 1 ? 0 : wb + 1;
+    }
+    rn_wait_dma();
+
+    // ---- epilogue through LDS (two passes of 64 rows): a lane owns CH consecutive channels of one output pixel: 16 for an fp8
+    // result (16-byte stores, 16-byte addend loads), 4 for an fp32 result
+    float *T = lds;
+    constexpr int CH = YF32 ? 4 : 16;
+    constexpr int CPR = BN / CH, RPP = 256 / CPR;
+    const int cc = tid % CPR;
+    const int col = n0 + CH * cc;
+    const bool col_ok = col < d.Cout;
+    unsigned char *yq = reinterpret_cast<unsigned char *>(yv);
+    float *yf = reinterpret_cast<float *>(yv);
+#pragma unroll 1
+    for (int pass = 0; pass < BM / RP; ++pass) {
+        if (pass) __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * LDT + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][e];
+        }
+        __syncthreads();
+        if (!col_ok) continue;
+#pragma unroll 1
+        for (int r = tid / CPR; r < RP; r += RPP) {
+            const int64_t m = (int64_t)m0 + pass * RP + r;
+            if (m >= M) break;
+            const unsigned mu = (unsigned)m;
+            const int n = (int)(mu / (unsigned)HoWo);
+            const int rem = (int)(mu - (unsigned)n * (unsigned)HoWo);
+            const int oh = (int)((unsigned)rem / (unsigned)d.Wo), ow = rem - oh * d.Wo;
+            const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
+            const int64_t pix = (int64_t)ph * d.Wy + pw;
+            const int64_t off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
+            int64_t aoff = -1;
+            if (d.add_mode == 1) aoff = (int64_t)n * d.add_batch_stride + pix * d.Cout + col;
+            else if (d.add_mode == 2) aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col;
+            float v[CH];
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + CH * cc + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            int aq[CH / 4];
+            if (aoff >= 0) {
+#pragma unroll
+                for (int q = 0; q < CH / 4; ++q) aq[q] = reinterpret_cast<const int *>(add + aoff)[q];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float sc = scale != nullptr ? scale[col + j] : 1.f, sh = shift != nullptr ? shift[col + j] : 0.f;
+                float u = v[j] * sc + sh;
+                if (aoff >= 0) {
+                    const int word = aq[j >> 2];
+                    const float a = (j & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8(word, 0) : (j & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8(word, 1)
+                                  : (j & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8(word, 2) : __builtin_amdgcn_cvt_f32_fp8(word, 3);
+                    u += a * fa_.add_scale;
+                }
+                if (d.act == 1) u = fmaxf(u, 0.f);
+                else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
+                v[j] = u;
+            }
+            if constexpr (YF32) {
+                *reinterpret_cast<float4 *>(yf + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const float is = fa_.out_inv_scale;
+                i32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = f8_pack4(v[4 * q] * is, v[4 * q + 1] * is, v[4 * q + 2] * is, v[4 * q + 3] * is);
+                *reinterpret_cast<i32x4 *>(yq + off) = o;
+            }
+        }
+    }
+}
+
+static int check_desc_fp8(const rn_conv_desc *d, int y_is_f32) {
+    if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
+    if (d->Cin < 16 || (d->Cin & 15) || (d->Cout & (y_is_f32 ? 3 : 15)) || d->w_format != 0) return RN_EINVAL;
+    if ((int64_t)d->Hi * d->Wi * d->Cin > 0x7fffffffLL) return RN_EINVAL;
+    const int64_t HoWo = (int64_t)d->Ho * d->Wo, span = 127 / HoWo + 2;
+    if (d->x_batch_stride < 0 || (span - 1) * d->x_batch_stride + (int64_t)d->Hi * d->Wi * d->Cin > 0x7fffffffLL) return RN_EINVAL;
+    const int64_t Kpad = ((int64_t)d->kh * d->kw * d->Cin + 63) / 64 * 64;
+    if (d->Cout * Kpad > 0x7fffffffLL || (int64_t)d->N * HoWo > 0x7fffffffLL) return RN_EINVAL;
+    if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
+    if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
+    if (d->mask_mode != 0 || d->in_relu || d->add2_mode != 0 || d->w_batch_stride != 0) return RN_EINVAL;   // forward form only
+    if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0) return RN_EINVAL;
+    if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
+    if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
+    if (!y_is_f32 && ((d->y_batch_stride & 15) || (d->add_batch_stride & 3))) return RN_EINVAL;
+    return RN_OK;
+}
+
+extern "C" int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, void *y, int y_is_f32, const float *scale,
+                                 const float *shift, const void *add_q, float add_scale, float out_inv_scale, void *stream) {
+    const int rc = check_desc_fp8(d, y_is_f32);
+    if (rc) return rc;
+    if ((d->add_mode != 0) != (add_q != nullptr)) return RN_EINVAL;
+    if (((uintptr_t)x_q & 15) || ((uintptr_t)w_q & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add_q & 3)) return RN_EINVAL;
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (tiles > 0x7fffffff) return RN_EINVAL;
+    Fp8Args a;
+    a.add_scale = add_scale;
+    a.out_inv_scale = out_inv_scale;
+    const dim3 grid((unsigned)tiles), block(256);
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(x_q), *wb = reinterpret_cast<const unsigned char *>(w_q);
+    const unsigned char *ab = reinterpret_cast<const unsigned char *>(add_q);
+    if (y_is_f32) hipLaunchKernelGGL((conv_igemm_fp8_kernel<true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, a);
+    else hipLaunchKernelGGL((conv_igemm_fp8_kernel<false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -707,3 +707,54 @@ def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16_grouped(
         ctypes.byref(g), w_packed.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm_bf16_grouped")
+
+
+# ---------------------------------------------------------------------------------------------- fp8 forward (BASELINE configs[4])
+FP8_MAX = 448.0                                  # largest finite e4m3fn
+
+
+def fp8_quantize(t, scale):
+    """fp32 device tensor -> e4m3 bytes (uint8 tensor of the same shape) with ONE scale: q = fp8(t / scale), saturating.
+    The scale rides on the result as ``._rn_scale`` (x ~= q * scale)."""
+    t = _hip.f32c(t)
+    _hip.need_gpu(t)
+    out = torch.empty(t.shape, dtype=torch.uint8, device=t.device)
+    _hip.check(_hip.load().rn_fp8_quantize(t.data_ptr(), out.data_ptr(), t.numel(), 1.0 / float(scale), _hip.stream()), "rn_fp8_quantize")
+    out._rn_scale = float(scale)
+    return out
+
+
+def fp8_dequantize(q, scale=None):
+    scale = q._rn_scale if scale is None else scale
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    _hip.check(_hip.load().rn_fp8_dequantize(q.data_ptr(), out.data_ptr(), q.numel(), float(scale), _hip.stream()), "rn_fp8_dequantize")
+    return out
+
+
+def fp8_quantize_weights(w_packed):
+    """Packed fp32 weight rows [rows][Kpad] -> (e4m3 rows [rows][round64(Kpad)], per-row scale [rows] = max|row| / 448)."""
+    rows, kp = w_packed.shape
+    kp64 = (kp + 63) // 64 * 64
+    wq = torch.empty((rows, kp64), dtype=torch.uint8, device=w_packed.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=w_packed.device)
+    _hip.check(_hip.load().rn_fp8_quantize_rows(w_packed.data_ptr(), wq.data_ptr(), sc.data_ptr(), rows, kp, _hip.stream()), "rn_fp8_quantize_rows")
+    return wq, sc
+
+
+def conv_igemm_fp8(xq, wq, y, geom, scale, shift=None, add=None, add_mode=0, add_hw=(0, 0), act=ACT_NONE, y_batch_stride=None,
+                   out_scale=1.0, flops=0.0):
+    """rn_conv_igemm_fp8: xq [N,Hi,Wi,Cin] e4m3 (uint8), wq from fp8_quantize_weights, y uint8 (e4m3, scale out_scale) or fp32;
+    scale [Cout] = x_scale * weight row scale * folded batch-norm scale; add: e4m3 with ``._rn_scale``; geom as conv_igemm."""
+    lib = _hip.load()
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and y.dtype in (torch.uint8, torch.float32)
+    d = _make_desc(xq, geom, act, add_mode, add_hw, 0, False, None, y_batch_stride, None, None)
+    kind = "conv_igemm_fp8"
+    if prof.BY_SHAPE:
+        kind += " %dx%dx%d %d->%d k%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh)
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_fp8(
+        ctypes.byref(d), xq.data_ptr(), wq.data_ptr(), y.data_ptr(), int(y.dtype == torch.float32), _hip.ptr(scale), _hip.ptr(shift),
+        _hip.ptr(add), float(add._rn_scale) if add is not None else 1.0, 1.0 / float(out_scale), _hip.stream()))
+    _hip.check(rc, "rn_conv_igemm_fp8")
+    if y.dtype == torch.uint8:
+        y._rn_scale = float(out_scale)
+    return y

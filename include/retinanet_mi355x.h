@@ -376,6 +376,23 @@ int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int
  * tile_end[i] = running sum of ceil(N*Ho*Wo / rows) * ceil(Cout / cols).  (tile_end is ignored on input by this query;
  * d[], the pointers and n must be filled.) */
 int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32);
+/* ---------------------------------------------------------------- fp8 forward (BASELINE configs[4], first cut) -----------
+ * The convolutions of the detector's forward pass with e4m3fn (OCP) weights and activations on v_mfma_scale_f32_32x32x64_f8f6f4
+ * (all block scales 2^0; fp32 accumulation): every nn.Conv2d behind the fp32 stem with its fused batch-norm / bias / residual /
+ * ReLU / sigmoid / FPN upsample-add epilogue (D/model.py:59-205, D/utils.py:12-80).  Inference only: no data or weight gradient.
+ *   rn_fp8_quantize / _dequantize   fp32 <-> e4m3 with one scale per tensor: q = fp8(x * inv_scale) (saturating at +-448), x = q * scale;
+ *   rn_fp8_quantize_rows            packed fp32 weight rows [rows][Kpad] -> e4m3 rows [rows][round64(Kpad)] + row_scale[rows]
+ *                                   (= max|row| / 448): the per-output-channel weight scale;
+ *   rn_conv_igemm_fp8               rn_conv_desc geometry as rn_conv_igemm (no mask, no input ReLU, no add2, Cin % 16 == 0):
+ *                                   y = act(acc * scale[c] + shift[c] + add_q * add_scale), the caller folding
+ *                                   x_scale * row_scale[c] * bn_scale[c] into scale[c]; stored as e4m3(y * out_inv_scale)
+ *                                   (Cout % 16 == 0) or as fp32 (y_is_f32: head outputs). */
+int rn_fp8_quantize(const float *src, void *dst, int64_t n, float inv_scale, void *stream);
+int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float scale, void *stream);
+int rn_fp8_quantize_rows(const float *w_packed, void *w_q, float *row_scale, int64_t rows, int Kpad, void *stream);
+int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, void *y, int y_is_f32, const float *scale,
+                      const float *shift, const void *add_q, float add_scale, float out_inv_scale, void *stream);
+
 /* dw[co][r][s][ci] (fp32, packed [Cout][Kpad] like rn_conv_wgrad, atomically accumulated) from bf16 dy [N,Ho,Wo,ldy>=Cout]
  * and bf16 x [N,Hi,Wi,Cin]; colsum (may be NULL) += column sums of dy.  Cin % 8 == 0, ldy % 8 == 0. */
 int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi, int Cin,
