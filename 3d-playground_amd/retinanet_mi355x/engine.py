@@ -32,9 +32,12 @@ FUSE_DY = os.environ.get("RN_WINO_FUSE_DY", "1") != "0"
 class Layer:
     """One convolution with its fused batch-norm / bias, the per-step packed weights and gradient accumulators."""
 
-    def __init__(self, spec, kw_pad=None, cin_pad=None, bf16=False):
+    def __init__(self, spec, kw_pad=None, cin_pad=None, bf16=False, fp8=False):
         self.spec = spec
         self.bf16 = bf16                               # bf16 activations / packed weights, fp32 accumulation (conv_bf16.hip)
+        self.fp8 = fp8                                 # e4m3 activations / weights, forward only (conv_fp8.hip); see Engine
+        self.out_scale = 1.0                           # fp8: per-tensor scale of this layer's output (Engine.calibration)
+        self.calib = None                              # a dict while Engine.calibrate() records output magnitudes
         self.kw_pad = spec.k if kw_pad is None else kw_pad
         self.cin_pad = spec.cin if cin_pad is None else cin_pad
         # channel count of a padded head-output gradient = K of its data gradient: 16-byte chunks must not straddle taps
@@ -78,6 +81,11 @@ class Layer:
         self.uf = self.ud = None
         self.wd16 = None
         self.wf16 = cache.get(("wf16", s.name), w, lambda: cv.to_bf16(self.wf)) if self.bf16 else None
+        if self.fp8:                                   # e4m3 rows + per-output-channel scale, times the folded batch-norm scale
+            self.wq, sw = cache.get(("wq", s.name), w, lambda: cv.fp8_quantize_weights(self.wf))
+            self.wscale = cache.get(("wqs", s.name), (w,) + ((P[s.bn + ".weight"], P[s.bn + ".running_var"]) if s.bn else ()),
+                                    lambda: (sw * self.scale) if self.scale is not None else sw)
+            self._fp8_scales = {}
 
     def adopt(self, P, cache, wf, bn, wd, wino=None, wf16=None, wd16=None):
         """Training step: take this step's packed weights / folded batch norm from the engine's batched preparation
@@ -132,6 +140,9 @@ class Layer:
         s = self.spec
         N, Hi, Wi, _ = x.shape
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
+        if self.fp8:
+            assert not in_relu, "fp8: the caller applies the input ReLU"
+            return self._fwd_fp8(x, (Ho, Wo), act, add, add_mode, add_hw, out, y_batch_stride)
         if self.bf16:
             assert not in_relu, "bf16: the caller applies the input ReLU (cv.relu_bf16)"
             if out is None:
@@ -149,13 +160,40 @@ class Layer:
         cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
                       shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
                       y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo))
+        self._tap(out if y_batch_stride is None else None)
         return out
+
+    def _tap(self, out):
+        """Calibration of the fp8 path (Engine.calibrate): remember the largest magnitude this layer's output has taken."""
+        if self.calib is not None and out is not None:
+            self.calib[self.spec.name] = max(self.calib.get(self.spec.name, 0.0), float(out.abs().max()))
+
+    def _fwd_fp8(self, x, out_hw, act, add, add_mode, add_hw, out, y_batch_stride):
+        """One e4m3 convolution (conv_fp8.hip): x / add are uint8 tensors carrying their per-tensor scale (._rn_scale); the result
+        is e4m3 with this layer's calibrated scale, or fp32 when `out` is an fp32 destination (the head outputs)."""
+        s = self.spec
+        Ho, Wo = out_hw
+        sx = float(x._rn_scale)
+        scale = self._fp8_scales.get(sx)
+        if scale is None:                              # x_scale * weight row scale * folded batch-norm scale, per input scale seen
+            scale = self._fp8_scales[sx] = (self.wscale * sx).contiguous()
+        if out is None:
+            out = torch.empty((x.shape[0], Ho, Wo, s.cout), dtype=torch.uint8, device=x.device)
+        return cv.conv_igemm_fp8(x, self.wq, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale, shift=self.shift,
+                                 add=add, add_mode=add_mode, add_hw=add_hw, act=act, y_batch_stride=y_batch_stride,
+                                 out_scale=self.out_scale, flops=self.flops(x.shape[0], Ho, Wo))
 
     def fwd_group(self, xs, act=cv.ACT_NONE, outs=None, y_batch_stride=None, wino=False, shared_v=None):
         """Same convolution on several inputs (pyramid levels) in one launch.  outs: destination tensors/views
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only).  shared_v: the kept
         input transform of ANOTHER layer that read the same xs (both towers' conv1 read the pyramid): reused, not recomputed."""
         s = self.spec
+        if self.fp8:                                   # first cut: one launch per pyramid level
+            ys = []
+            for i, x in enumerate(xs):
+                o = None if outs is None else outs[i]
+                ys.append(self._fwd_fp8(x, (x.shape[1], x.shape[2]), act, None, 0, (0, 0), o, y_batch_stride))
+            return ys
         if self.bf16:                                  # the levels of a head layer as one grouped bf16 launch
             probs, ys, fl = [], [], 0.0
             for i, x in enumerate(xs):
@@ -183,6 +221,9 @@ class Layer:
             probs.append({"x": x, "y": y, "geom": (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
                           "y_batch_stride": y_batch_stride})
         cv.conv_igemm_grouped(probs, self.wf, scale=self.scale, shift=self.shift, act=act, flops=fl)
+        if outs is None:
+            for y in ys:
+                self._tap(y)
         return ys
 
     def bwd_data_group(self, gs, in_hws, adds=None, masks=None, wino=False):
@@ -336,10 +377,15 @@ class Engine:
     def __init__(self, arch_name, num_classes, n_reg, dtype="fp32"):
         """dtype "fp32": the reference's arithmetic (default).  "bf16" (BASELINE configs[2]): bf16 activations and packed
         weights, fp32 accumulation / epilogues / parameters / gradients / loss; the 3-channel stem stays fp32 and the
-        Winograd path is not used.  Bottleneck architectures only (resnet50 / 101 / 152)."""
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError("dtype must be 'fp32' or 'bf16'")
+        Winograd path is not used.  Bottleneck architectures only (resnet50 / 101 / 152).
+        "fp8" (BASELINE configs[4], first cut, INFERENCE ONLY): e4m3 activations (one calibrated scale per tensor: calibrate())
+        and weights (one scale per output channel) on the fp8 MFMA, fp32 accumulation and epilogues; the stem and the head
+        outputs stay fp32; no backward pass."""
+        if dtype not in ("fp32", "bf16", "fp8"):
+            raise ValueError("dtype must be 'fp32', 'bf16' or 'fp8'")
         self.bf16 = dtype == "bf16"
+        self.fp8 = dtype == "fp8"
+        self.fp8_scales = None                     # {layer name / "pool": largest magnitude seen} from calibrate()
         if self.bf16 and arch.LAYERS[arch_name][0] != "bottleneck":
             raise NotImplementedError("the bf16 schedule is built for the bottleneck networks (resnet50/101/152)")
         self.arch = arch_name
@@ -369,14 +415,14 @@ class Engine:
             if role == "stem":
                 self.layers[spec.name] = Layer(spec, kw_pad=8, cin_pad=4)
                 continue
-            self.layers[spec.name] = Layer(spec, bf16=self.bf16)
+            self.layers[spec.name] = Layer(spec, bf16=self.bf16, fp8=self.fp8)
             if cur is None or cur[0] != pre:
                 cur = (pre, {})
                 self.blocks.append(cur)
             cur[1][role] = self.layers[spec.name]
         for spec in arch.fpn_convs(arch_name) + arch.head_convs("regressionModel", n_reg) + \
                 arch.head_convs("classificationModel", num_classes):
-            self.layers[spec.name] = Layer(spec, bf16=self.bf16)
+            self.layers[spec.name] = Layer(spec, bf16=self.bf16, fp8=self.fp8)
         self.param_names = [k for k, shp in arch.state_dict_shapes(arch_name, num_classes, n_reg).items()
                             if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
 
@@ -679,6 +725,25 @@ class Engine:
             L.du = arena[o + a + b:o + a + b + c].view(36, L.spec.cout, -1) if c else None
             o += a + b + c
 
+    # ------------------------------------------------------------------------------------------- fp8 calibration
+    def calibrate(self, P, frames, margin=1.0):
+        """Per-tensor activation scales of the fp8 path from THIS engine's own fp32 / bf16 forward on `frames` ([B,3,H,W],
+        representative inputs): the largest magnitude every convolution output (and the pooled stem) takes, times margin.
+        -> dict for Engine(dtype="fp8").fp8_scales.  One host read per layer: a set-up call, not a hot path."""
+        assert not self.fp8, "calibrate with the fp32 (or bf16) engine, then hand the result to the fp8 engine"
+        rec = {}
+        for L in self.layers.values():
+            L.calib = rec
+        self.calib = rec
+        try:
+            with torch.no_grad():
+                self.forward(P, frames, save=False)
+        finally:
+            for L in self.layers.values():
+                L.calib = None
+            self.calib = None
+        return {k: v * margin for k, v in rec.items()}
+
     # ------------------------------------------------------------------------------------------- forward
     def forward(self, P, img, save, x4=None):
         """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None).  x4: the input already
@@ -688,8 +753,15 @@ class Engine:
             self._prepare_training(P)
         else:
             self._prepare(P)
+        if self.fp8:
+            if save:
+                raise RuntimeError("the fp8 engine is inference-only (no backward pass): train in fp32 / bf16")
+            if not self.fp8_scales:
+                raise RuntimeError("the fp8 engine needs activation scales: net.calibrate_fp8(frames) first")
+            for n_, L in Ls.items():
+                L.out_scale = max(self.fp8_scales.get(n_, 0.0), 1e-30) / cv.FP8_MAX
         for L in Ls.values():                              # Winograd where it pays; in inference only on request
-            L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer and not self.bf16)
+            L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer and not self.bf16 and not self.fp8)
             L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow
         if x4 is None:
             _hip.need_gpu(img)
@@ -705,6 +777,10 @@ class Engine:
             S["x4"], S["stem"], S["pool_arg"] = x4, stem, pool_arg
         else:
             x = pool(stem)
+        if getattr(self, "calib", None) is not None:
+            self.calib["pool"] = max(self.calib.get("pool", 0.0), float(x.abs().max()))
+        if self.fp8:                                        # fp8 mode: the fp32 stem + pool end here
+            x = cv.fp8_quantize(x, max(self.fp8_scales.get("pool", 0.0), 1e-30) / cv.FP8_MAX)
         if save:
             S["blocks"] = []
         feats = {}
@@ -731,7 +807,9 @@ class Engine:
         p3 = Ls["fpn.P3_2"].fwd(p3sum)
         p6 = Ls["fpn.P6"].fwd(c5)
         p6r = cv.relu_bf16(p6) if self.bf16 else None                      # fp32: the ReLU rides on the fragments (in_relu)
-        p7 = Ls["fpn.P7_2"].fwd(p6r) if self.bf16 else Ls["fpn.P7_2"].fwd(p6, in_relu=True)
+        if self.fp8:                                                       # (a 17 x 30 map: through fp32, same scale)
+            p6r = cv.fp8_quantize(torch.relu(cv.fp8_dequantize(p6)), p6._rn_scale)
+        p7 = Ls["fpn.P7_2"].fwd(p6r) if (self.bf16 or self.fp8) else Ls["fpn.P7_2"].fwd(p6, in_relu=True)
         pyramid = [p3, p4, p5, p6, p7]
         if save:
             S["fpn"] = (c3, c4, c5, p5lat, p4sum, p3sum, p6)
@@ -752,7 +830,7 @@ class Engine:
             for i in range(1, 5):                                         # one launch per tower conv, all 5 levels
                 first = Ls["regressionModel.conv1"]                       # both towers' conv1 transform the same pyramid: once
                 shared = first.saved_v if (i == 1 and prefix == "classificationModel") else None
-                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16,
+                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16 and not self.fp8,
                                                              shared_v=shared)
                 acts.append(ts)
             views, off = [], 0

@@ -267,15 +267,28 @@ class ResNet(nn.Module):
             self._engine.set_flat_grads(None)
 
     def set_compute_dtype(self, dtype):
-        """"fp32" (default: the reference's arithmetic) or "bf16" (BASELINE configs[2]): bf16 activations and packed weights
+        """"fp32" (default: the reference's arithmetic), "fp8" (inference only, after calibrate_fp8) or "bf16" (BASELINE configs[2]): bf16 activations and packed weights
         on the bf16 matrix cores, fp32 accumulation, parameters, gradients and loss.  Not the reference's numerics: expect
         ~1e-2 relative differences in losses and gradients (tests/test_gpu_model_bf16.py)."""
         old = self._engine
         eng = engine.Engine(self._arch_name, old.num_classes, old.n_reg, dtype=dtype)
         eng.set_flat_grads(old.flat_bucket_bytes)
         eng.bucket_hook = old.bucket_hook
+        eng.fp8_scales = getattr(old, "fp8_scales", None)
         self.__dict__["_engine"] = eng
         return self
+
+    def calibrate_fp8(self, frames, margin=1.0):
+        """BASELINE configs[4], first cut: run the CURRENT (fp32 or bf16) engine on representative frames [B,3,H,W], record the
+        magnitude of every activation tensor, and switch the model to the fp8 inference engine with those per-tensor scales
+        (e4m3 activations and per-output-channel-scaled e4m3 weights on the fp8 MFMA; csrc/conv_fp8.hip).  Inference only:
+        ``net.train()`` forwards raise.  ``set_compute_dtype("fp32")`` switches back (the scales are kept)."""
+        if self._engine.fp8:
+            self.set_compute_dtype("fp32")
+        scales = self._engine.calibrate(self._tensor_dict(), frames, margin)
+        self.set_compute_dtype("fp8")
+        self._engine.fp8_scales = scales
+        return scales
 
     def use_flat_gradients(self, on=True):
         """Write parameter gradients into one persistent device buffer (stable ``p.grad`` pointers from step to step,

@@ -201,6 +201,64 @@ def bf16_section(dev, args, B, H, W):
     return out
 
 
+PEAK_FP8_MFMA_TF = 5000.0         # dense fp8 MFMA (block-scaled f8f6f4 form), same guide
+
+
+def fp8_section(dev, args, B, H, W):
+    """Supplementary, NOT the headline: BASELINE configs[4]'s arithmetic, first cut (inference / forward only) -- (a) the e4m3
+    implicit-GEMM kernel (csrc/conv_fp8.hip, v_mfma_scale_f32_32x32x64_f8f6f4) on two layer shapes of the benchmark against the
+    ~5 PF dense fp8 MFMA peak and the HBM roof (algorithmic bytes: every operand once, 1 byte per element), (b) the model's forward
+    pass (eval, no post-process) with e4m3 activations / weights against the same pass in fp32, activation scales calibrated on
+    the benchmark's frames."""
+    from retinanet_mi355x import conv as cv, modules, synth
+    out = {}
+
+    def timeit(fn, iters=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    for name, cin, cout, k, hh, ww in (("conv_igemm_fp8_3x3_256", 256, 256, 3, 135, 240), ("conv_igemm_fp8_1x1_1024_256", 1024, 256, 1, 68, 120)):
+        x = torch.relu(torch.randn(B, hh, ww, cin, device=dev))
+        w = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (k * k * cin)) ** 0.5
+        xq = cv.fp8_quantize(x, float(x.max()) / cv.FP8_MAX)
+        wq, sw = cv.fp8_quantize_weights(cv.pack_weights(w, 0, presplit=False))
+        y = torch.empty(B, hh, ww, cout, dtype=torch.uint8, device=dev)
+        scale = (sw * xq._rn_scale).contiguous()
+        pad = k // 2
+        ms = timeit(lambda: cv.conv_igemm_fp8(xq, wq, y, (hh, ww, cout, k, k, 1, 1, -pad, 0), scale, act=cv.ACT_RELU, out_scale=0.05))
+        flops = 2.0 * B * hh * ww * cout * cin * k * k
+        nbytes = xq.numel() + wq.numel() + y.numel()
+        tf, gbs = flops / ms / 1e9, nbytes / ms / 1e6
+        out[name] = {"layer": "%dx%d %d->%d @%dx%d, batch %d" % (k, k, cin, cout, hh, ww, B), "bound": "mfma", "achieved": round(tf, 1),
+                     "peak": PEAK_FP8_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP8_MFMA_TF, 4), "ms": round(ms, 4),
+                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes}
+        del x, xq, wq, y
+    net = getattr(modules, args.arch)(num_classes=8)
+    net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))
+    net = net.to(dev).eval()
+    img = frames(B, H, W, 0, dev)
+    P = net._tensor_dict()
+
+    def fwd():
+        with torch.no_grad():
+            net._engine.forward(P, img, save=False)
+    ms32 = timeit(fwd, 3)
+    net.calibrate_fp8(img[:2])
+    ms8 = timeit(fwd, 3)
+    out["forward_pass"] = {"value": round(B / (ms8 * 1e-3), 1), "unit": "images/sec", "ms_per_pass": round(ms8, 2), "dtype": "fp8 (e4m3fn)",
+                           "fp32_ms_per_pass": round(ms32, 2), "speedup_over_fp32_forward": round(ms32 / ms8, 2),
+                           "note": "forward only (backbone + FPN + heads, no post-process), fp32 stem and head outputs; one launch per "
+                                   "pyramid level in the heads (no grouped fp8 launch yet); not the reference's arithmetic, not the headline"}
+    return out
+
+
 def native_section(dev, args, B, H, W):
     """Supplementary: the SAME training step with the fp32 convolutions on v_mfma_f32_32x32x2_f32 (RN_FP32_NATIVE), on this GPU
     in this run -- the reader's yardstick for the split-operand headline."""
@@ -579,6 +637,11 @@ def main():
                 line["bf16"] = bf16_section(dev, args, B, H, W)
             except Exception as e:
                 line["bf16"] = {"error": str(e)[:300]}
+            try:
+                torch.cuda.empty_cache()
+                line["fp8"] = fp8_section(dev, args, B, H, W)
+            except Exception as e:
+                line["fp8"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.arch, H, W)
