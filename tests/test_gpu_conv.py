@@ -525,8 +525,9 @@ def test_split_mode_corners_that_differ_from_ieee_fp32(dev):
     and INTEGRATION.md; this pins them so a change is noticed:
       * an infinite operand gives NaN (inf - bf16(inf) in the residual), where the fp32 MFMA gives inf;
       * a finite operand above the largest bf16 (3.3895e38) rounds its leading term to inf and gives NaN as well;
-      * operands below the bf16 NORMAL range lose their residual terms (flushed by the matrix core): the product is the
-        leading term's, i.e. correct to 2^-8 relative instead of 2^-24 -- on values below 1e-37.
+      * operands below the bf16 NORMAL range (|x| < 1.18e-38) lose their residual terms (flushed by the matrix core) and keep only
+        a subnormal bf16 leading term: the result is correct to a few per cent instead of 2^-24 -- on values below 1e-37
+        (measured here: 1.0e-2 relative with operands of 1e-39).
     Everything finite and normal is covered by the other tests of this module at 1e-5 relative."""
     from retinanet_mi355x import conv
     before = conv.get_fp32_mfma(), conv.PRESPLIT
@@ -547,7 +548,7 @@ def test_split_mode_corners_that_differ_from_ieee_fp32(dev):
         assert torch.isnan(out["split", "huge"][0, 2, 3]).all()                        # native: 0.5 * 3.4e38 + 127.5, finite
         assert torch.isfinite(out["native", "huge"][0, 2, 3]).all()
         t_n, t_s = out["native", "tiny"], out["split", "tiny"]
-        assert torch.isfinite(t_s).all() and float((t_n - t_s).abs().max()) <= 2.0 ** -7 * float(t_n.abs().max()) + 1e-44
+        assert torch.isfinite(t_s).all() and float((t_n - t_s).abs().max()) <= 2.0 ** -4 * float(t_n.abs().max()) + 1e-44
     finally:
         conv.set_fp32_mfma(before[0])
         conv.PRESPLIT = before[1]
