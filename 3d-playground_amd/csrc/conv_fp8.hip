@@ -110,10 +110,10 @@ struct Fp8Args {
 
 // 128 x 128 output tile by 2 x 2 waves, each a 64 x 64 sub-tile = 2 x 2 accumulators of the 32x32x64 MFMA.
 template <bool YF32>
-__global__ __launch_bounds__(256, 3) void conv_igemm_fp8_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
-                                                                const unsigned char *__restrict__ w, void *__restrict__ yv,
-                                                                const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                const unsigned char *__restrict__ add, const Fp8Args fa_) {
+__device__ __forceinline__ void conv_igemm_fp8_tile(const rn_conv_desc &d, const unsigned char *__restrict__ x,
+                                                    const unsigned char *__restrict__ w, void *__restrict__ yv,
+                                                    const float *__restrict__ scale, const float *__restrict__ shift,
+                                                    const unsigned char *__restrict__ add, const Fp8Args fa_, const int tile) {
     constexpr int BM = 128, BN = 128, NW = 4;
     constexpr int RF = 16;                                   // 4-byte words per staged row: 64 bytes
     constexpr int RPI = 16;                                  // rows one wave instruction fills (1 KiB / 64 B)
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_fp8_kernel(const rn_conv_de
     constexpr int LDSF = NBUF * STEP > RP * LDT ? NBUF * STEP : RP * LDT;
     __shared__ float lds[LDSF];
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -349,6 +348,35 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_fp8_kernel(const rn_conv_de
     }
 }
 
+template <bool YF32>
+__global__ __launch_bounds__(256, 3) void conv_igemm_fp8_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
+                                                                const unsigned char *__restrict__ w, void *__restrict__ yv,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                const unsigned char *__restrict__ add, const Fp8Args fa_) {
+    conv_igemm_fp8_tile<YF32>(d, x, w, yv, scale, shift, add, fa_, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch (rn_conv_igemm_grouped's form): the pyramid levels of a head layer, same weights and scalars, as ONE grid.
+// The group's pointers are e4m3 bytes behind the float-typed fields of rn_conv_group.
+template <bool YF32>
+__global__ __launch_bounds__(256, 3) void conv_igemm_fp8_grouped_kernel(const rn_conv_group g, const unsigned char *__restrict__ w,
+                                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                        const Fp8Args fa_) {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    rn_conv_desc d = g.d[0];
+    const float *x = g.x[0], *add = g.add[0];
+    float *y = g.y[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; first = g.tile_end[i - 1]; }
+    conv_igemm_fp8_tile<YF32>(d, reinterpret_cast<const unsigned char *>(x), w, y, scale, shift,
+                              reinterpret_cast<const unsigned char *>(add), fa_, tile - first);
+}
+
 static int check_desc_fp8(const rn_conv_desc *d, int y_is_f32) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 16 || (d->Cin & 15) || (d->Cout & (y_is_f32 ? 3 : 15)) || d->w_format != 0) return RN_EINVAL;
@@ -384,6 +412,35 @@ extern "C" int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const v
     const unsigned char *ab = reinterpret_cast<const unsigned char *>(add_q);
     if (y_is_f32) hipLaunchKernelGGL((conv_igemm_fp8_kernel<true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, a);
     else hipLaunchKernelGGL((conv_igemm_fp8_kernel<false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// One launch for up to RN_MAX_GROUP problems that share weights, scales and activation (tile_end[i] = running sum of
+// ceil(N*Ho*Wo / 128) * ceil(Cout / 128)); x / y / add of the group are e4m3 (y: or fp32) behind the float-typed fields.
+extern "C" int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q, int y_is_f32, const float *scale, const float *shift,
+                                         float add_scale, float out_inv_scale, void *stream) {
+    if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_q & 15)) return RN_EINVAL;
+    const rn_conv_desc &d0 = g->d[0];
+    int prev = 0;
+    for (int i = 0; i < g->n; ++i) {
+        const rn_conv_desc &d = g->d[i];
+        const int rc = check_desc_fp8(&d, y_is_f32);
+        if (rc) return rc;
+        if (d.Cin != d0.Cin || d.Cout != d0.Cout || d.kh != d0.kh || d.kw != d0.kw || d.act != d0.act) return RN_EINVAL;
+        if ((d.add_mode != 0) != (g->add[i] != nullptr)) return RN_EINVAL;
+        if (((uintptr_t)g->x[i] & 15) || ((uintptr_t)g->y[i] & 15) || ((uintptr_t)g->add[i] & 3)) return RN_EINVAL;
+        const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
+        const int64_t tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
+        if (g->tile_end[i] - prev != tiles) return RN_EINVAL;
+        prev = g->tile_end[i];
+    }
+    Fp8Args a;
+    a.add_scale = add_scale;
+    a.out_inv_scale = out_inv_scale;
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(w_q);
+    if (y_is_f32) hipLaunchKernelGGL((conv_igemm_fp8_grouped_kernel<true>), dim3((unsigned)prev), dim3(256), 0, (hipStream_t)stream, *g, wb, scale, shift, a);
+    else hipLaunchKernelGGL((conv_igemm_fp8_grouped_kernel<false>), dim3((unsigned)prev), dim3(256), 0, (hipStream_t)stream, *g, wb, scale, shift, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -147,6 +147,7 @@ SIGNATURES.update({
     "rn_fp8_dequantize": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "rn_fp8_quantize_rows": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "rn_conv_igemm_fp8": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp]),
+    "rn_conv_igemm_fp8_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp]),
     "rn_conv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 11 + [c_vp]),
     "rn_maxpool_fwd_bf16out": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
     "rn_maxpool_bwd_bf16in": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),

@@ -758,3 +758,29 @@ def conv_igemm_fp8(xq, wq, y, geom, scale, shift=None, add=None, add_mode=0, add
     if y.dtype == torch.uint8:
         y._rn_scale = float(out_scale)
     return y
+
+
+def conv_igemm_fp8_grouped(problems, wq, scale, shift=None, act=ACT_NONE, out_scale=1.0, flops=0.0):
+    """rn_conv_igemm_fp8_grouped: up to RN_MAX_GROUP problems (dicts with x, y, geom, optional y_batch_stride) that share the
+    e4m3 weights, the folded scale vector (so: ONE input scale for all of them) and the activation; results all e4m3 or all fp32."""
+    lib = _hip.load()
+    g = _hip.ConvGroup()
+    g.n = len(problems)
+    yf32 = problems[0]["y"].dtype == torch.float32
+    total = 0
+    for i, pr in enumerate(problems):
+        x = pr["x"]
+        assert x.dtype == torch.uint8 and (pr["y"].dtype == torch.float32) == yf32
+        d = _make_desc(x, pr["geom"], act, 0, (0, 0), 0, False, None, pr.get("y_batch_stride"), None, None)
+        g.d[i] = d
+        M = d.N * d.Ho * d.Wo
+        total += ((M + 127) // 128) * ((d.Cout + 127) // 128)
+        g.tile_end[i] = total
+        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), None, None
+    kind = "conv_igemm_fp8" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_fp8_grouped(
+        ctypes.byref(g), wq.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), 1.0, 1.0 / float(out_scale), _hip.stream()))
+    _hip.check(rc, "rn_conv_igemm_fp8_grouped")
+    if not yf32:
+        for pr in problems:
+            pr["y"]._rn_scale = float(out_scale)

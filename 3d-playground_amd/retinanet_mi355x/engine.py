@@ -188,11 +188,23 @@ class Layer:
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only).  shared_v: the kept
         input transform of ANOTHER layer that read the same xs (both towers' conv1 read the pyramid): reused, not recomputed."""
         s = self.spec
-        if self.fp8:                                   # first cut: one launch per pyramid level
-            ys = []
+        if self.fp8:                                   # the levels of a head layer as one grouped e4m3 launch
+            scales = {float(x._rn_scale) for x in xs}
+            if len(scales) > 1 or len(xs) > _hip.RN_MAX_GROUP:      # different input scales cannot share one folded scale vector
+                return [self._fwd_fp8(x, (x.shape[1], x.shape[2]), act, None, 0, (0, 0), None if outs is None else outs[i], y_batch_stride)
+                        for i, x in enumerate(xs)]
+            sx = scales.pop()
+            scale = self._fp8_scales.get(sx)
+            if scale is None:
+                scale = self._fp8_scales[sx] = (self.wscale * sx).contiguous()
+            probs, ys, fl = [], [], 0.0
             for i, x in enumerate(xs):
-                o = None if outs is None else outs[i]
-                ys.append(self._fwd_fp8(x, (x.shape[1], x.shape[2]), act, None, 0, (0, 0), o, y_batch_stride))
+                N, Hi, Wi, _ = x.shape
+                y = outs[i] if outs is not None else torch.empty((N, Hi, Wi, s.cout), dtype=torch.uint8, device=x.device)
+                ys.append(y)
+                fl += self.flops(N, Hi, Wi)
+                probs.append({"x": x, "y": y, "geom": (Hi, Wi, s.cout, s.k, self.kw_pad, 1, 1, -s.pad, 0), "y_batch_stride": y_batch_stride})
+            cv.conv_igemm_fp8_grouped(probs, self.wq, scale, shift=self.shift, act=act, out_scale=self.out_scale, flops=fl)
             return ys
         if self.bf16:                                  # the levels of a head layer as one grouped bf16 launch
             probs, ys, fl = [], [], 0.0
@@ -760,6 +772,11 @@ class Engine:
                 raise RuntimeError("the fp8 engine needs activation scales: net.calibrate_fp8(frames) first")
             for n_, L in Ls.items():
                 L.out_scale = max(self.fp8_scales.get(n_, 0.0), 1e-30) / cv.FP8_MAX
+            # the five pyramid maps share ONE scale, so that the towers' first layer takes them in one grouped launch
+            pyr = ("fpn.P3_2", "fpn.P4_2", "fpn.P5_2", "fpn.P6", "fpn.P7_2")
+            common = max(Ls[n_].out_scale for n_ in pyr)
+            for n_ in pyr:
+                Ls[n_].out_scale = common
         for L in Ls.values():                              # Winograd where it pays; in inference only on request
             L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer and not self.bf16 and not self.fp8)
             L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow

@@ -392,6 +392,10 @@ int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float scale, void 
 int rn_fp8_quantize_rows(const float *w_packed, void *w_q, float *row_scale, int64_t rows, int Kpad, void *stream);
 int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, void *y, int y_is_f32, const float *scale,
                       const float *shift, const void *add_q, float add_scale, float out_inv_scale, void *stream);
+/* The pyramid levels of a head layer as one launch (rn_conv_igemm_grouped's form; the group's x / y / add are e4m3 -- y: or fp32 --
+ * behind the float-typed fields, one input scale for the whole group folded into scale[c]). */
+int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q, int y_is_f32, const float *scale, const float *shift,
+                              float add_scale, float out_inv_scale, void *stream);
 
 /* dw[co][r][s][ci] (fp32, packed [Cout][Kpad] like rn_conv_wgrad, atomically accumulated) from bf16 dy [N,Ho,Wo,ldy>=Cout]
  * and bf16 x [N,Hi,Wi,Cin]; colsum (may be NULL) += column sums of dy.  Cin % 8 == 0, ldy % 8 == 0. */
