@@ -302,6 +302,224 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-operand form with the split done ONCE per workgroup (round 3).  In conv_wgrad_kernel<.., SPLIT = true> every wave splits the
+// fragments it reads -- both operands are activations -- so each fragment is split by the two waves that share it: 32 values per lane
+// and K-step, the largest vector load of any kernel here (knock-out: 23 % of the kernel's time, profiles/r03_big_tile.txt, K8).
+// Here a thread loads two float4 of each operand (4 channels of pixels p and p + 8 of the 16-pixel K-step) into registers two steps
+// ahead, splits them one step ahead (16 values per lane) and stores the three bf16 terms into plane images [16 pixels][128 columns]
+// (conv_wgrad_geom.h: WgradSplitGeom, the bf16 kernel's image); the MFMA phase reads ready operands through gfx950's transposing
+// LDS read (ds_read_b64_tr_b16: 8 consecutive pixels of one column per lane, two reads).  128 x 128 tile, 48 KB of LDS, three
+// workgroups per CU, same grid / K slices / atomics (or slabs) / column sums as the kernel above.
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 wgs_operand(const char *img, unsigned a0, unsigned a1) {
+    typedef __attribute__((address_space(3))) s16x4w *lp;
+    const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(__attribute__((address_space(3))) char *)(img + a0));
+    const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(__attribute__((address_space(3))) char *)(img + a1));
+    typedef short s16x8w __attribute__((ext_vector_type(8)));
+    const s16x8w v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs p) {
+    using G = WgradSplitGeom;
+    constexpr int BM = 128, BN = 128, WK = G::WK, TB = G::TB;
+    __shared__ __attribute__((aligned(16))) char lds[2][G::BUF];
+    __shared__ int2 pixtab[2][TB * WK];                      // (byte offset of input pixel (ih0, iw0), ih0 | iw0 << 16): 53 KB in all = 3 per CU
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int slice, tile;
+    if (p.xcd_map) {
+        const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+        slice = (wi / p.tiles) * 8 + xcd;
+        tile = wi % p.tiles;
+    } else {
+        slice = blockIdx.x / p.tiles;
+        tile = blockIdx.x % p.tiles;
+    }
+    if (slice >= p.splits) return;
+    const int batch = tile / p.tiles_per_batch;
+    tile -= batch * p.tiles_per_batch;
+    const float *dy_b = p.dy + (int64_t)batch * p.dy_bstride;
+    const float *x_b = p.x + (int64_t)batch * p.x_bstride;
+    float *dw_b = p.dw + (int64_t)batch * p.dw_bstride;
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int64_t kbeg = (int64_t)slice * p.per_split;
+    const int64_t kend = (kbeg + p.per_split < p.pixels) ? kbeg + p.per_split : p.pixels;
+    const int nks = (int)((kend - kbeg + WK - 1) / WK);
+    if (nks <= 0) return;
+    const int HoWo = p.Ho * p.Wo;
+    const int n_first = (int)(kbeg / HoWo);
+    const int rel0 = (int)(kbeg - (int64_t)n_first * HoWo);
+    const int64_t img = (int64_t)p.Hi * p.Wi * p.Cin;
+    int64_t xbytes = ((int64_t)p.N - n_first) * img * 4;
+    if (xbytes > 0x7FFFFFFF) xbytes = 0x7FFFFFFF;
+    // buffer descriptors: dY = this K slice only (pixels past kend read as zero); X from the first image the slice touches
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy_b + kbeg * p.ldy), (short)0,
+                                                                          (int)(unsigned)((kend - kbeg) * p.ldy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x_b + (int64_t)n_first * img), (short)0,
+                                                                          (int)(unsigned)xbytes, 0x00020000);
+    // this thread: 4-channel chunk c of pixels px0 and px0 + 8 of every K-step, for both operands
+    const int c = G::chunk(tid), px0 = G::pixel(tid, 0);
+    const bool a_col_ok = (m0 + 4 * c) < p.ldy;
+    const unsigned a_voff = a_col_ok ? (unsigned)((px0 * p.ldy + m0 + 4 * c) * 4) : 0x80000000u;
+    const unsigned a_half = (unsigned)(8 * p.ldy * 4);       // bytes from pixel p to pixel p + 8 (scalar)
+    const int jcol = n0 + 4 * c;                             // X: the chunk fixes (tap, first input channel)
+    const int tap = jcol / p.Cin;
+    const int ci0 = jcol - tap * p.Cin;
+    const int fr = tap / p.kw, fs = tap - fr * p.kw;
+    const int fr_t = jcol < p.Kflat ? fr : (1 << 24);        // a column past the matrix fails every row test
+    const int tap_off = ((fr * p.Wi + fs) * p.Cin + ci0) * 4;
+    const unsigned wr0 = (unsigned)G::wr_addr(tid, 0), wr1 = (unsigned)G::wr_addr(tid, 1);
+
+    auto fill_batch = [&](int j) {
+        const int rel = rel0 + j * (TB * WK) + tid;
+        int2 e = make_int2(0, 0x8000);                       // past the slice: ih0 = -32768 fails the row test (also with fr_t added)
+        if (kbeg + (int64_t)j * (TB * WK) + tid < kend) {
+            const unsigned n = (unsigned)rel / (unsigned)HoWo;
+            const unsigned rem = (unsigned)rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)p.Wo, ow = rem - oh * (unsigned)p.Wo;
+            const int ih0 = (int)oh * p.stride - p.pad, iw0 = (int)ow * p.stride - p.pad;      // both fit 16 bits (launcher)
+            e = make_int2((((int)n * p.Hi + ih0) * p.Wi + iw0) * p.Cin * 4, (ih0 & 0xffff) | (iw0 << 16));
+        }
+        pixtab[j & 1][tid] = e;
+    };
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    struct Regs { f32x4v a[2], b[2]; };
+    // loads of K-step ks (all four; offsets of the X half from the pixel table, the dY half from a scalar advance)
+    auto load_step = [&](int ks, Regs &r) {
+        const int2 *tab = pixtab[(ks / TB) & 1];
+        const unsigned so = (unsigned)ks * (unsigned)(WK * 4) * (unsigned)p.ldy;
+        r.a[0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)a_voff, (int)so, 0));
+        r.a[1] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)a_voff, (int)(so + a_half), 0));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int2 e = tab[G::tab_index(ks, tid, h)];
+            const int ih0 = (int)(short)(e.y & 0xffff), iw0 = e.y >> 16;
+            const unsigned ok = (((unsigned)(ih0 + fr_t) < (unsigned)p.Hi) & ((unsigned)(iw0 + fs) < (unsigned)p.Wi)) ? 0xFFFFFFFFu : 0u;
+            const unsigned v = ((unsigned)(e.x + tap_off) & ok) | (0x80000000u & ~ok);
+            r.b[h] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)v, 0, 0));
+        }
+    };
+    float cs4[4] = {0.f, 0.f, 0.f, 0.f};                     // column sums of this thread's 4 dY channels over its pixels
+    const bool do_cs = p.colsum != nullptr && batch == p.colsum_batch && (tile % p.tiles_n) == 0;
+    // split the registers of one K-step and store the planes of buffer `buf`
+    auto split_store = [&](int buf, const Regs &r) {
+        char *B = &lds[buf][0];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned wr = h ? wr1 : wr0;
+            float av[4] = {r.a[h][0], r.a[h][1], r.a[h][2], r.a[h][3]};
+            float bv[4] = {r.b[h][0], r.b[h][1], r.b[h][2], r.b[h][3]};
+            if (RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = fmaxf(bv[j], 0.f);
+            }
+            if (do_cs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cs4[j] += av[j];
+            }
+            unsigned ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+            split_pair(av[0], av[1], ah[0], am[0], al[0]);
+            split_pair(av[2], av[3], ah[1], am[1], al[1]);
+            split_pair(bv[0], bv[1], bh[0], bm[0], bl[0]);
+            split_pair(bv[2], bv[3], bh[1], bm[1], bl[1]);
+            *reinterpret_cast<uint2 *>(B + 0 * G::IMG + wr) = make_uint2(ah[0], ah[1]);
+            *reinterpret_cast<uint2 *>(B + 1 * G::IMG + wr) = make_uint2(am[0], am[1]);
+            *reinterpret_cast<uint2 *>(B + 2 * G::IMG + wr) = make_uint2(al[0], al[1]);
+            *reinterpret_cast<uint2 *>(B + 3 * G::IMG + wr) = make_uint2(bh[0], bh[1]);
+            *reinterpret_cast<uint2 *>(B + 4 * G::IMG + wr) = make_uint2(bm[0], bm[1]);
+            *reinterpret_cast<uint2 *>(B + 5 * G::IMG + wr) = make_uint2(bl[0], bl[1]);
+        }
+    };
+    unsigned fa[2][2], fb[2][2];                             // transposing-read addresses: [32-column sub-tile][read 0 / 1]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            fa[t][rd] = (unsigned)G::tr_addr(wm, t, rd, lane);
+            fb[t][rd] = (unsigned)(3 * G::IMG + G::tr_addr(wn, t, rd, lane));
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e_ = 0; e_ < 16; ++e_) acc[i][j][e_] = 0.f;
+
+    fill_batch(0);
+    __syncthreads();
+    Regs r0, r1;
+    load_step(0, r0);
+    split_store(0, r0);
+    load_step(1, r0);                                        // step 1 waits in registers for iteration 0
+    __syncthreads();
+    // One K-step: `cur` holds step ks + 1 (loaded an iteration ago), `nxt` receives step ks + 2 (steps past the slice load zeros:
+    // the dY descriptor ends at kend and the table marks those pixels invalid).
+    auto k_step = [&](int ks, int buf, Regs &cur, Regs &nxt) {
+        const char *S = &lds[buf][0];
+        Split8 sa[2], sb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sa[t].h = wgs_operand(S, fa[t][0], fa[t][1]);
+            sa[t].m = wgs_operand(S + G::IMG, fa[t][0], fa[t][1]);
+            sa[t].l = wgs_operand(S + 2 * G::IMG, fa[t][0], fa[t][1]);
+            sb[t].h = wgs_operand(S, fb[t][0], fb[t][1]);
+            sb[t].m = wgs_operand(S + G::IMG, fb[t][0], fb[t][1]);
+            sb[t].l = wgs_operand(S + 2 * G::IMG, fb[t][0], fb[t][1]);
+        }
+        split_store(buf ^ 1, cur);
+        load_step(ks + 2, nxt);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+        // table batch b is first read for step b * TB (loaded in iteration b * TB - 2); its slot held batch b - 2, last read in
+        // iteration (b - 1) * TB - 3: fill it in iteration (b - 1) * TB + 4
+        if ((ks % TB) == 4 && (ks / TB + 1) * TB < nks + 2) fill_batch(ks / TB + 1);
+        __syncthreads();
+    };
+    for (int ks = 0; ks < nks; ks += 2) {
+        k_step(ks, 0, r0, r1);
+        if (ks + 1 < nks) k_step(ks + 1, 1, r1, r0);
+    }
+    if (do_cs) {                                             // 8 threads hold partial sums of the same 4 channels: through LDS
+        float (*csred)[BM] = reinterpret_cast<float (*)[BM]>(&lds[0][0]);     // (the planes are done with: the loop ended in a barrier)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csred[tid >> 5][4 * c + j] = cs4[j];
+        __syncthreads();
+        if (tid < BM) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_ += csred[k][tid];
+            const int ch = m0 + tid;
+            if (ch < p.Cout) {
+                if (p.cs_slab != nullptr) p.cs_slab[(int64_t)slice * p.Cout + ch] = s_;
+                else atomicAdd(p.colsum + ch, s_);
+            }
+        }
+    }
+    float *out = dw_b;
+    if (p.slab != nullptr) out = p.slab + (int64_t)slice * p.slab_stride + (int64_t)batch * p.dw_bstride;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < p.Cout && col < p.Kflat) {
+                    if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = acc[tm][tn][e];
+                    else atomicAdd(out + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                }
+            }
+        }
+}
+
 // Deterministic form, second pass: dw[b][row][col] += slab[0] + slab[1] + ... in slice order (one thread per element, col
 // fastest: coalesced over every slab), colsum[c] likewise from the column-sum slabs.
 __global__ __launch_bounds__(256) void wgrad_combine_kernel(float *__restrict__ dw, const float *__restrict__ slab, int64_t slab_stride,
@@ -428,7 +646,13 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
         } else if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
         else hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, false, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);         \
     } while (0)
-    if (shape == 0) RN_WGRAD_LAUNCH(1, 4);
+    // RN_WGRAD_ONCE=0: the per-wave split for the 128 x 128 tile too (A/B)
+    const char *once_env = getenv("RN_WGRAD_ONCE");
+    const bool once = split && shape == 2 && (once_env ? atoi(once_env) : 1) != 0 && Hi + pad < 32000 && Wi + pad < 32000;
+    if (once) {
+        if (in_relu) hipLaunchKernelGGL((conv_wgrad_once_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_once_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else if (shape == 0) RN_WGRAD_LAUNCH(1, 4);
     else if (shape == 1) RN_WGRAD_LAUNCH(4, 1);
     else RN_WGRAD_LAUNCH(2, 2);
 #undef RN_WGRAD_LAUNCH

@@ -49,3 +49,22 @@ struct WgradBf16Geom {
         return ROWB * row + 16 * (ch ^ fx(row)) + 8 * (pp & 1);
     }
 };
+
+// fp32 split-operand kernel with the split done ONCE per workgroup (conv_wgrad.hip: conv_wgrad_once_kernel): tile 128 x 128, 16
+// pixels per K-step; every thread loads two float4 (4 channels of pixels p and p + 8) of each operand into registers, splits them
+// and stores the three bf16 terms into plane images [16 pixels][128 columns] bf16 -- WgradBf16Geom's image (256-byte rows, 16-byte
+// chunks XOR-permuted by fx(row)) cut to 16 rows, so the MFMA operands come out of the same transposing reads (tr_addr, kh = 0).
+struct WgradSplitGeom {
+    static constexpr int WK = 16, ROWB = 256, TB = 256 / WK, TAB = TB * WK;
+    static constexpr int IMG = WK * ROWB;                    // bytes of one plane image
+    static constexpr int BUF = 6 * IMG;                      // bytes of one buffer: dY planes h, m, l, then X planes h, m, l
+    static RN_HD int pixel(int tid, int half) { return (tid >> 5) + 8 * half; }          // the pixel of this thread's load `half`
+    static RN_HD int chunk(int tid) { return tid & 31; }                                 // its 4-channel chunk (columns 4c .. 4c+3)
+    // byte address (within a plane image) of the thread's 8-byte store of (pixel, columns 4c .. 4c+3)
+    static RN_HD int wr_addr(int tid, int half) {
+        const int row = pixel(tid, half), c = chunk(tid);
+        return ROWB * row + 16 * ((c >> 1) ^ WgradBf16Geom::fx(row)) + 8 * (c & 1);
+    }
+    static RN_HD int tab_index(int ks, int tid, int half) { return (ks % TB) * WK + pixel(tid, half); }
+    static RN_HD int tr_addr(int w2, int t, int rd, int lane) { return WgradBf16Geom::tr_addr(w2, t, rd, 0, lane); }
+};

@@ -93,12 +93,38 @@ static void check_bf16() {
     std::printf("ok bf16: table %d entries/half, image %d bytes\n", G::TAB, G::IMG);
 }
 
+static void check_split_once() {
+    using G = WgradSplitGeom;
+    // stores: the 256 threads x 2 halves tile a plane image exactly once, 8 bytes each, and land where the reads look for them
+    std::vector<int> cover(G::IMG, 0);
+    for (int tid = 0; tid < 256; ++tid)
+        for (int half = 0; half < 2; ++half) {
+            const int a = G::wr_addr(tid, half);
+            CHECK(a >= 0 && a + 8 <= G::IMG && (a & 7) == 0, "split-once: store at %d (thread %d half %d)", a, tid, half);
+            for (int k = 0; k < 8 && a >= 0 && a + k < G::IMG; ++k) cover[a + k]++;
+            const int row = a / G::ROWB, chunk16 = ((a % G::ROWB) / 16) ^ WgradBf16Geom::fx(row), col = 8 * chunk16 + ((a & 8) ? 4 : 0);
+            CHECK(row == G::pixel(tid, half) && col == 4 * G::chunk(tid), "split-once: thread %d half %d stores row %d col %d", tid, half, row, col);
+            const int i = G::tab_index(5, tid, half);
+            CHECK(i >= 0 && i < G::TAB && i / G::WK == 5 % G::TB && i % G::WK == G::pixel(tid, half), "split-once: table index %d", i);
+        }
+    for (int i = 0; i < G::IMG; ++i) CHECK(cover[i] == 1, "split-once: image byte %d stored %d times", i, cover[i]);
+    for (int w2 = 0; w2 < 2; ++w2)
+        for (int t = 0; t < 2; ++t)
+            for (int rd = 0; rd < 2; ++rd)
+                for (int l = 0; l < 64; ++l) {
+                    const int a = G::tr_addr(w2, t, rd, l);
+                    CHECK(a >= 0 && a + 8 <= G::IMG && (a & 7) == 0, "split-once: transposing read at %d (sub-tile %d/%d rd %d lane %d)", a, w2, t, rd, l);
+                }
+    std::printf("ok split-once: image %d bytes, buffer %d bytes\n", G::IMG, G::BUF);
+}
+
 int main() {
     check_fp32<1, 4, 16>("fp32 64x256");       // the three instances rn_conv_wgrad_batched launches (conv_wgrad.hip)
     check_fp32<4, 1, 16>("fp32 256x64");
     check_fp32<2, 2, 16>("fp32 128x128");
     check_fp32<2, 2, 32>("fp32 128x128 / 32-pixel steps");
     check_bf16();
+    check_split_once();
     if (fails) std::printf("%d violation(s)\n", fails);
     return fails ? 1 : 0;
 }
