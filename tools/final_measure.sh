@@ -6,7 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
 rm -rf "$O" && mkdir -p "$O"
-RN_TEST_MEASURE=0 timeout -k 10 900 python3 -m pytest tests -q -m gpu > "$O/gpu_tests.log" 2>&1
+RN_TEST_MEASURE=0 timeout -k 10 900 python3 -m pytest tests -q -s -m gpu > "$O/gpu_tests.log" 2>&1
 echo "tests done" && tail -1 "$O/gpu_tests.log"
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > "$O/bench.log" 2>&1
 echo "bench done"
@@ -26,5 +26,7 @@ timeout -k 10 300 python3 tools/bench_conv.py --mfma split > "$O/conv_microbench
 timeout -k 10 300 python3 tools/bench_infer.py > "$O/infer_cfg4.txt" 2>&1
 timeout -k 10 300 python3 tools/bench_infer.py --dtype bf16 >> "$O/infer_cfg4.txt" 2>&1
 RN_FP32_MFMA=native timeout -k 10 300 python3 tools/bench_infer.py >> "$O/infer_cfg4.txt" 2>&1
+RN_DETERMINISTIC=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$O/bench_deterministic.log" 2>&1
+timeout -k 10 300 python3 tools/profile_layers.py --dtype fp32 > "$O/fp32_step_by_shape.txt" 2>&1
 timeout -k 10 500 bash tools/rehearse_ddp.sh > "$O/ddp_rehearsal.txt" 2>&1
 echo "all done"
