@@ -1,7 +1,7 @@
 """The bf16 schedule of the engine (Engine(dtype="bf16"), BASELINE configs[2]) on the whole detector: same network, same
 goldens as the fp32 tests -- but NOT the same bar: bf16 activations carry 8 significant bits, so after 50 layers the losses
 agree with the reference's fp32 values to about a percent and the gradients in direction rather than digit by digit.
-Bounds below are ~3x what was measured on the MI355X (profiles/r02_bf16_model_errors.txt).  The reference itself has no
+Bounds below are ~3x what was measured on the MI355X (profiles/r03_bf16_fp8_model_errors.txt).  The reference itself has no
 bf16 mode; what is pinned here is that the bf16 schedule computes the SAME function (wiring, epilogues, strides, masks)."""
 import numpy as np
 import pytest
