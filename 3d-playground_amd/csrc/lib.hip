@@ -31,14 +31,16 @@ extern "C" int rn_set_fp32_mfma(int mode) {
     return RN_OK;
 }
 
-// Convolutions whose reduction length kh*kw*Cin is below this stay on the fp32 MFMA kernels in RN_FP32_SPLIT mode: they are
-// bound by memory and launch shape, not by the matrix cores, and the split kernels' lower residency (three workgroups per CU
-// instead of four) costs them 5-25 % (measured per layer shape: profiles/r02_fp32_split_by_shape.txt).
+// Convolutions whose reduction length kh*kw*Cin is below this stay on the fp32 MFMA kernels in RN_FP32_SPLIT mode.  Round 2: 192 --
+// the short reductions (1x1 from 64 / 128 channels) lost 5-25 % to the split kernels' lower residency (three workgroups per CU
+// instead of four; profiles/r02_fp32_split_by_shape.txt).  Round 3: 64, i.e. every layer of the detector -- with the activation operand
+// split once per workgroup (SPLIT 3) the short reductions gain too: the training step 96.1 -> 97.4 images/s
+// (RN_FP32_SPLIT_MIN_K = 192 / 128 / 64 / 192 in one call: 96.0 / 96.2 / 97.4 / 96.1; profiles/r03_split_min_k.txt).
 extern "C" int rn_fp32_split_min_k(void) {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("RN_FP32_SPLIT_MIN_K");
-        v = e ? atoi(e) : 192;
+        v = e ? atoi(e) : 64;
     }
     return v;
 }

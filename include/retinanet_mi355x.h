@@ -290,8 +290,8 @@ int rn_set_fp32_mfma(int mode);
 #define RN_OPT_COUNT 2
 int rn_get_option(int option);
 int rn_set_option(int option, int value);
-/* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (192; environment RN_FP32_SPLIT_MIN_K);
- * shorter reductions are memory-bound and keep the fp32 MFMA kernel.  (A pre-split weight operand, w_format 1, is always
+/* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (64; environment RN_FP32_SPLIT_MIN_K);
+ * shorter reductions keep the fp32 MFMA kernel.  (A pre-split weight operand, w_format 1, is always
  * taken by the split kernels: prepare it for the long reductions only.) */
 int rn_fp32_split_min_k(void);
 /* RN_FP32_SPLIT: the weights' three bf16 terms can be prepared once per optimizer step instead of in every workgroup:
