@@ -119,8 +119,8 @@ def forward_heads(img, sd, arch, taps=None):
     return reg, cls, anc
 
 
-def train_forward(img, ann, sd, arch):
-    reg, cls, anc = forward_heads(img, sd, arch)
+def train_forward(img, ann, sd, arch, taps=None):
+    reg, cls, anc = forward_heads(img, sd, arch, taps)
     if reg.shape[2] == 12:
         return olosses.focal_loss_dir(cls, reg, anc, ann)
     return olosses.focal_loss_2d(cls, reg, anc, ann)
