@@ -1,0 +1,342 @@
+// Split-operand implicit GEMM on v_mfma_f32_16x16x32_bf16: 128 x 128 output tile, four waves, each wave a 64 x 64 block as
+// 4 x 4 tiles of 16 x 16, K-step 32, two workgroups per CU.
+//
+// Why this shape of instruction and of tile: the split kernels are not short of issue slots, the CHIP IS HOLDING ITS CLOCK DOWN
+// under them.  Stamped (tools/stamp_split.py, profiles/r03_split_clock.txt): inside the K loop of the 128 x 128 kernel
+// (conv_igemm_tile.h, SPLIT 3, v_mfma_f32_32x32x16_bf16) the matrix pipe is ~77 % busy at a shader clock of 1.65-1.72 GHz, and
+// the same kernel with one workgroup per CU runs at 2.28 GHz -- which is why knocking any part out of the K-step, or adding
+// workgroups, returned so little (profiles/r03_split_knockout.txt).  What raises the clock is less energy per product
+// (cdna_hip_programming.md 5.4 rule 28; MI355X_MICROARCH.md, DVFS give-back):
+//   * the 16x16x32 shape: same cycles per FLOP, the chip holds a higher clock on it -- swapping only the instruction inside the
+//     128 x 128 kernel (wrong results, timing only) moved the loop's clock 1717 -> 1877 MHz and the launch 1.56 -> 1.45 ms;
+// A first form of this file -- 128 x 256 tiles, eight waves, 144 KB of LDS, ONE workgroup per CU: half the split arithmetic per
+// MFMA, activations read once for Cout = 256 -- gained 3 % on K = 2304 and LOST 30 % on the Winograd GEMMs (K = 256: 9.5 -> 12.4 ms
+// per step): with one workgroup per CU nothing covers a tile's prologue and epilogue.  Hence the budget here: 72 KB, two per CU.
+//
+// Data path (conv_igemm_tile.h SPLIT 3 has the reasoning for every piece): weights pre-split (rn_split_weights: records of 96
+// bytes = h, m, l of 16 values), staged by direct-to-LDS loads with the range check as zero-fill; a thread loads 8 consecutive
+// values of one activation row two K-steps ahead, splits them one step ahead and stores three 16-byte operand chunks into the A
+// planes; the MFMA phase reads operands only.  LDS planes are [rows][32 k] bf16 = 64-byte rows of four 16-byte chunks, chunk c of
+// row r stored at slot c ^ ((r >> 2) & 3): the 16 lanes of a 16x16x32 operand read (rows r .. r+15, one chunk) and the 64 lanes of
+// a plane store (16 rows x 4 chunks) both cover every bank once.
+//
+// LDS: the weight planes are double-buffered (2 x 24 KB, filled asynchronously); the activation planes are NOT (24 KB): they go
+// through registers anyway, so a K-step reads its A operands into registers, a barrier (X) says every wave has, and the planes
+// of the next step are written over them while the MFMAs run; the barrier that ends the step (Y) publishes them together with the
+// landed weight planes.  Two barriers per 32 values of k -- the 128 x 128 kernels' rate.  Conditions (the launcher's): pre-split weights, Cin a multiple of 32, div_shift 0, kh * kw <= 24, Cout a
+// multiple of 4 and > 128, no input ReLU.
+#include "conv_igemm_tile.h"
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+// acc += a * b for one 16 x 16 tile and 32 values of k: the six products, smallest first (mfma_split.h: RN_SPLIT_MFMA)
+#define RN_SPLIT_MFMA16(ACC, A, B)                                                        \
+    do {                                                                                  \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).l, (B).h, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).l, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).m, (B).m, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).m, (B).h, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).m, ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
+    } while (0)
+
+template <bool GENERAL, bool RAW>
+__device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
+                                               float *__restrict__ y, const float *__restrict__ scale,
+                                               const float *__restrict__ shift, const float *__restrict__ add,
+                                               const float *__restrict__ mask, const float *__restrict__ add2, const int tile) {
+    constexpr int BK = 32, NT = 256, BM = 128, BN = 128;
+    constexpr int BPL = BN * 16;                           // floats' worth of one bf16 plane: rows x 64 bytes
+    constexpr int BSTEP = 3 * BPL;                         // one buffer: B planes h, m, l
+    constexpr int NBI = 3 * BN / 16, IB = NBI / 4;         // direct-to-LDS instructions (16 rows x 64 bytes each) per step / per wave
+    constexpr int LDT = BN + 4;
+    static_assert(NBI % 4 == 0, "tile shape");
+    __shared__ float lds[2 * BSTEP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;              // a lane's row / column within a 16 x 16 tile, its block of 8 k values
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ntn = (d.Cout + BN - 1) / BN;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int64_t M = (int64_t)d.N * HoWo;
+    const int K = d.kh * d.kw * d.Cin;
+    const int Kpad = (K + 31) / 32 * 32;
+    const int nks = Kpad / BK;
+
+    // ---- buffer descriptors: activations from the first image the tile touches, the pre-split weights whole (+ per-image offset)
+    const int n_first = (int)(m0 / HoWo);
+    const int64_t x_floats = ((int64_t)d.N - 1 - n_first) * d.x_batch_stride + (int64_t)d.Hi * d.Wi * d.Cin;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + (int64_t)n_first * d.x_batch_stride), (short)0,
+        (int)(unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4), 0x00020000);
+    const v4i32 rs_b = make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * 6,
+                                 (unsigned)((int64_t)d.Cout * Kpad * 6));
+
+    // ---- this lane's two activation rows (tile rows 32 * wave + 16 * sm + lr): tap mask and base offset of its 8 k values
+    unsigned a_mask[2];
+    int a_base[2];
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm) {
+        const int row = 32 * wave + 16 * sm + lr;
+        int a_h = -(1 << 28), a_w = 0, a_img = 0;
+        if ((int64_t)m0 + row < M) {
+            const unsigned rel = (unsigned)(m0 - n_first * HoWo + row);
+            const unsigned n = rel / (unsigned)HoWo;
+            const unsigned rem = rel - n * (unsigned)HoWo;
+            const unsigned oh = rem / (unsigned)d.Wo, ow = rem - oh * (unsigned)d.Wo;
+            a_img = (int)((int64_t)n * d.x_batch_stride * 4);
+            a_h = (int)oh * d.a + d.p;
+            a_w = (int)ow * d.a + d.p_w;
+        }
+        unsigned mk = 0;
+        for (int r = 0, t = 0; r < d.kh; ++r)
+            for (int s_ = 0; s_ < d.kw; ++s_, ++t) {
+                const int ih = a_h + r * d.b, iw = a_w + s_ * d.b;
+                mk |= (unsigned)(((ih | iw) >= 0) & (ih < d.Hi) & (iw < d.Wi)) << t;
+            }
+        a_mask[sm] = mk;
+        a_base[sm] = a_img + ((a_h * d.Wi + a_w) * d.Cin + 8 * lg) * 4;
+    }
+    int f_r = 0, f_s = 0, f_c = 0;                         // tap and channel offset of the next step to load
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    struct ARegs { f32x4v v[4]; };
+    auto load_a = [&](ARegs &ar) {
+        const int t = f_r * d.kw + f_s;
+        const int delta = (f_r * d.Wi + f_s) * d.b * d.Cin * 4;
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const unsigned valid = 0u - ((a_mask[sm] >> (t & 31)) & 1u);
+            const unsigned v = ((unsigned)(a_base[sm] + delta) & valid) | (0x80000000u & ~valid);
+            ar.v[2 * sm] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)v, f_c * 4, 0));
+            ar.v[2 * sm + 1] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)(v + 16u), f_c * 4, 0));
+        }
+        f_c += BK;
+        const bool wrap = f_c >= d.Cin;
+        f_c = wrap ? 0 : f_c;
+        f_s += wrap ? 1 : 0;
+        const bool wrap_s = f_s == d.kw;
+        f_s = wrap_s ? 0 : f_s;
+        f_r += wrap_s ? 1 : 0;
+    };
+
+    // ---- weight planes: instruction q of the workgroup fills 16 rows of one plane; lane -> row (lane >> 2), slot (lane & 3).
+    // The slot holds chunk c = slot ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3): k values 8c .. 8c+7 of the step, i.e. bytes
+    // (c & 1) * 16 of the plane's half-record in 16-value record c >> 1.
+    unsigned b_voff[IB];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int q = wave * IB + j, plane = q / (BN / 16), brow = (q % (BN / 16)) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((lane >> 4) & 3);
+        const int n = n0 + brow;
+        b_voff[j] = n < d.Cout ? (unsigned)(n * Kpad * 6 + (c >> 1) * 96 + plane * 32 + (c & 1) * 16) : 0x80000000u;
+    }
+    const unsigned lds0 = lds_addr(lds);
+    auto dma_b = [&](int ks, int buf) {
+#pragma unroll
+        for (int j = 0; j < IB; ++j)
+            dma16(rs_b, lds0 + (unsigned)(buf * BSTEP * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 192));
+    };
+
+    f32x4a acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    // plane 0 of this lane's operand chunk of weight rows 16 * t + lr (floats, within a buffer): 16 * row + 4 * (lg ^ ((row >> 2) & 3));
+    // 16 * t does not change (row >> 2) & 3, so one address and an immediate per t
+    const int fb0 = 16 * lr + 4 * (lg ^ ((lr >> 2) & 3));
+
+    // ---- K loop.  `cur` holds the A values of step ks (loaded during step ks - 1): split into the MFMA operands, then the same
+    // registers receive step ks + 1 -- a whole MFMA phase to arrive.  Unconditional (one basic block): past the last step the loads
+    // return zeros / stale weights nobody uses, and all have landed (vmcnt(0)) before the epilogue reuses the LDS.
+    ARegs cur;
+    load_a(cur); dma_b(0, 0);
+    rn_wait_dma();
+    __syncthreads();
+    auto k_step = [&](int ks, int rb) {
+        asm volatile("" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]));   // the compiler's wait for `cur` here, where it is free
+        Split8 sa[2];
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const float av[8] = {cur.v[2 * sm][0], cur.v[2 * sm][1], cur.v[2 * sm][2], cur.v[2 * sm][3],
+                                 cur.v[2 * sm + 1][0], cur.v[2 * sm + 1][1], cur.v[2 * sm + 1][2], cur.v[2 * sm + 1][3]};
+            sa[sm] = split8(av);
+        }
+        dma_b(ks + 1, rb ^ 1);
+        load_a(cur);
+        const float *S = lds + rb * BSTEP + fb0;
+#pragma unroll
+        for (int sn = 0; sn < 8; ++sn) {
+            Split8 sb;
+            sb.h = *reinterpret_cast<const bf16x8 *>(S + 256 * sn);
+            sb.m = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + BPL);
+            sb.l = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + 2 * BPL);
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) RN_SPLIT_MFMA16(acc[sm][sn], sa[sm], sb);
+        }
+        RN_PIN();
+        rn_wait_dma();                                      // B planes of step ks + 1 landed, A registers of step ks + 1 arrived
+        __syncthreads();
+    };
+    for (int ks = 0; ks < nks; ks += 2) {
+        k_step(ks, 0);
+        if (ks + 1 < nks) k_step(ks + 1, 1);
+    }
+
+    // ---- epilogue, WAVE-PRIVATE: a wave owns tile rows 32 w .. 32 w + 31 and all 128 columns, so it transposes its accumulators
+    // through a 16-row strip of LDS of its own (the staging buffers are free after the last barrier) and nobody waits for anybody:
+    // no workgroup barrier after the K loop.  Accumulator element e of lane l is row 4 * (l >> 4) + e, column l & 15 of its
+    // 16 x 16 tile; out of the strip a lane takes float4s: 32 consecutive lanes one 512-byte row segment, so out, add and mask all
+    // move as 16-byte accesses (conv_igemm_tile.h: same arithmetic, same macros).
+    float *T = lds + wave * (16 * LDT);
+    static_assert(4 * 16 * LDT <= 2 * BSTEP, "four strips fit the staging buffers");
+    const int c4 = lane & 31;
+    const int col = n0 + 4 * c4;
+    const bool col_ok = col < d.Cout;
+    const bool vec = true;                                   // the launcher sends Cout % 4 == 0 only
+    const int ncol = 4;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!RAW && col_ok && scale != nullptr) sc[j] = scale[col + j];
+        if (!RAW && col_ok && shift != nullptr) sh[j] = shift[col + j];
+    }
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm) {
+#pragma unroll
+        for (int sn = 0; sn < 8; ++sn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(4 * lg + e) * LDT + 16 * sn + lr] = acc[sm][sn][e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is this wave's own: order within the wave is all it needs
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int NIT = 8, G = 4;                        // 16 rows, two per instruction
+        if (col_ok) {
+#pragma unroll 1
+            for (int g = 0; g < NIT; g += G) {
+                int64_t off_[G];
+                float4 mk_[G], ad_[G];
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int64_t mr = (int64_t)m0 + 32 * wave + 16 * sm + (lane >> 5) + 2 * (g + i);
+                    const int64_t m = mr < M ? mr : M - 1;
+                    RN_EPI_ADDR(GENERAL)
+                    off_[i] = off;
+                    mk_[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    ad_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!RAW && d.mask_mode != 0) mk_[i] = *reinterpret_cast<const float4 *>(mask + off);
+                    if (!RAW && d.add_mode != 0) ad_[i] = *reinterpret_cast<const float4 *>(add + aoff);
+                    (void)a2off;
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int r = (lane >> 5) + 2 * (g + i);
+                    const int64_t m = (int64_t)m0 + 32 * wave + 16 * sm + r;
+                    if (m < M) {
+                        const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                        const int64_t off = off_[i];
+                        float mk[4] = {mk_[i].x, mk_[i].y, mk_[i].z, mk_[i].w}, ad[4] = {ad_[i].x, ad_[i].y, ad_[i].z, ad_[i].w};
+                        if (!RAW && d.add2_mode == 3) {
+                            int64_t a2;
+                            { RN_EPI_ADDR(GENERAL) a2 = a2off; (void)aoff; (void)off; }
+                            if (a2 >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
+                        }
+                        if (RAW) *reinterpret_cast<float4 *>(y + off) = t;
+                        else { RN_EPI_FINISH() }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip's reads before the next half's writes
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool GENERAL, bool RAW>
+__global__ __launch_bounds__(256, 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
+                                                              const float *__restrict__ w, float *__restrict__ y,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const float *__restrict__ add, const float *__restrict__ mask,
+                                                              const float *__restrict__ add2) {
+    conv_mf16_tile<GENERAL, RAW>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+__global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
+                                                                      const float *__restrict__ scale,
+                                                                      const float *__restrict__ shift) {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    rn_conv_desc d = g.d[0];
+    const float *x = g.x[0], *add = g.add[0], *mask = g.mask[0];
+    float *y = g.y[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < RN_MAX_GROUP; ++i)
+        if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
+    conv_mf16_tile<true, false>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+}
+
+// Which problems take this kernel: RN_MF16=0 turns it off (A/B); launches with fewer than RN_MF16_MIN tiles keep the 32x32x16
+// kernels (three workgroups per CU there, two here).  (read at every launch, not cached: the parity tests force it onto small problems)
+static int mf16_on() {
+    const char *e = getenv("RN_MF16");
+    return e ? atoi(e) : 1;
+}
+static int mf16_min_tiles() {
+    const char *e = getenv("RN_MF16_MIN");
+    return e ? atoi(e) : 1;
+}
+static bool mf16_ok(const rn_conv_desc *d) {
+    return mf16_on() && d->w_format == 1 && (d->Cin % 32) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
+           (d->Cout % 4) == 0 && d->Cout > 64 && !d->in_relu;
+}
+static int64_t mf16_tiles(const rn_conv_desc *d) {
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    return ((M + 127) / 128) * ((d->Cout + 127) / 128);
+}
+
+// -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 4 dense, 5 general.
+bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
+                          const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc) {
+    if (!mf16_ok(d) || (variant != 0 && variant != 4 && variant != 5)) return false;
+    const int64_t tiles = mf16_tiles(d);
+    if (tiles < mf16_min_tiles() || tiles > 0x7fffffff) return false;
+    const dim3 grid((unsigned)tiles), block(256);
+    if (variant == 0) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, true>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else if (variant == 4) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else hipLaunchKernelGGL((conv_igemm_mf16_kernel<true, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    const hipError_t e = hipGetLastError();
+    *rc = e == hipSuccess ? RN_OK : (int)e;
+    return true;
+}
+
+bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc) {
+    for (int i = 0; i < g->n; ++i)
+        if (!mf16_ok(&g->d[i])) return false;
+    rn_conv_group gb = *g;                                  // the caller's tile table counts 128 x 128 tiles: recount
+    int64_t total = 0;
+    for (int i = 0; i < g->n; ++i) {
+        total += mf16_tiles(&g->d[i]);
+        gb.tile_end[i] = (int)total;
+    }
+    for (int i = g->n; i < RN_MAX_GROUP; ++i) gb.tile_end[i] = (int)total;
+    if (total < mf16_min_tiles() || total > 0x7fffffff) return false;
+    hipLaunchKernelGGL(conv_igemm_mf16_grouped_kernel, dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
+    const hipError_t e = hipGetLastError();
+    *rc = e == hipSuccess ? RN_OK : (int)e;
+    return true;
+}
+
+#if RN_STAMP
+// diagnostic build: read and clear this file's K-step stamps (tools/stamp_split.py --mf16)
+extern "C" int rn_debug_stamps_mf16(unsigned long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rn_stamps), sizeof(rn_stamps)) != hipSuccess) return -1;
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rn_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

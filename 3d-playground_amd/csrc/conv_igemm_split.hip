@@ -54,6 +54,16 @@ static bool split_a_once(const rn_conv_desc *d) {
 bool rn_igemm_big_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
                          const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc);
 bool rn_igemm_big_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc);
+// conv_igemm_mf16.hip: 128 x 256 tiles on v_mfma_f32_16x16x32_bf16
+bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
+                          const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc);
+bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc);
+
+static int dbg_dyn_lds(const void *fn) {                  // occupancy experiment: RN_DBG_DYN_LDS bytes of unused dynamic LDS per workgroup
+    static const int v = getenv("RN_DBG_DYN_LDS") ? atoi(getenv("RN_DBG_DYN_LDS")) : 0;
+    if (v > 16384) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+    return v;
+}
 
 // variant: the instance conv_igemm.hip's launcher chose -- 0 raw GEMM, 1 input ReLU, 2 / 3 narrow dense / general,
 // 4 / 5 wide dense / general.  d->w_format 1: w is the pre-split form (rn_split_weights).
@@ -63,11 +73,12 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
     {
         int rc = RN_OK;
         if (rn_igemm_big_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
+        if (rn_igemm_mf16_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
     }
     const dim3 grid(tiles), block(256);
 #define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW)                                                                                              \
     do {                                                                                                                                \
-        if (WM == 2 && split_a_once(d)) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, (WM == 2 ? 3 : 2)>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2); \
+        if (WM == 2 && split_a_once(d)) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, (WM == 2 ? 3 : 2)>), grid, block, dbg_dyn_lds((const void *)conv_igemm_split_kernel<WM, WN, G, R, RAW, (WM == 2 ? 3 : 2)>), s, *d, x, w, y, scale, shift, add, mask, add2); \
         else if (d->w_format == 1) hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 2>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 1>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);                 \
     } while (0)
@@ -91,6 +102,7 @@ int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_gro
     if (!narrow) {
         int rc = RN_OK;
         if (rn_igemm_big_grouped_launch(g, w, scale, shift, s, &rc)) return rc;
+        if (rn_igemm_mf16_grouped_launch(g, w, scale, shift, s, &rc)) return rc;
     }
     if (!narrow && split_a_once(&g->d[0])) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 3>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
@@ -114,3 +126,14 @@ extern "C" int rn_split_weights(const float *w_packed, void *w_split, int64_t ro
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
+
+#if RN_STAMP
+// diagnostic build: read and clear the K-step stamps (conv_igemm_tile.h)
+extern "C" int rn_debug_stamps(unsigned long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rn_stamps), sizeof(rn_stamps)) != hipSuccess) return -1;
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rn_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    return RN_OK;
+}
+#endif

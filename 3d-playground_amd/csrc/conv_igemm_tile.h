@@ -100,6 +100,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef RN_SGB
 #define RN_SGB 0
 #endif
+// Diagnostic build only (-DRN_STAMP=1, tools/stamp_split.sh): s_memtime stamps between the parts of a SPLIT 3 K-step, summed per
+// wave in scalar registers and added into rn_stamps[] once after the loop.  The stamps' fences forbid overlaps the real kernel has:
+// read the SHARES.  No product build executes a stamp.
+#ifndef RN_STAMP
+#define RN_STAMP 0
+#endif
+#if RN_STAMP
+static __device__ unsigned long long rn_stamps[16];
+#define RN_T(i)                                                                                                  \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t[i])::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define RN_T(i)
+#endif
 #ifndef RN_KO
 #define RN_KO 0
 #endif
@@ -453,6 +470,11 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     };
     if constexpr (SPLIT == 3) {
         static_assert(SPLIT != 3 || NBUF == 2, "SPLIT 3: two buffers");
+#if RN_STAMP
+        unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long st_c0, st_r0, st_c1, st_r1;       // shader clock / 100 MHz reference around the K loop: the clock the loop ran at
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0)::"memory");
+#endif
         load_a(ar); dma_step(0, 0); split_a(0, ar);         // (the compiler waits for the registers it loaded)
         load_a(ar);                                         // step 1 stays in registers until iteration 0 splits it
         rn_wait_dma();
@@ -464,12 +486,17 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             // the compiler's wait for `cur` HERE, where it is free (the step ended with vmcnt(0)): placed after the loads below
             // it would be a vmcnt(0) that also covers them -- the compiler does not see the direct-to-LDS loads
             asm volatile("" : "+v"(cur[0]), "+v"(cur[1]));
+#if RN_STAMP
+            unsigned long long st_t[7];
+#endif
+            RN_T(0);
 #if !(RN_KO & 1)                                            // knock-outs (timing only, wrong results): 1 no B loads, 2 no A loads, 4 one MFMA of six
             dma_step(ks + 1, rb ^ 1);                       // B planes of step ks + 1; buffer rb ^ 1 was released by the last barrier
 #endif
 #if !(RN_KO & 2)
             load_a(nxt);                                    // A values of step ks + 2: a whole MFMA phase to arrive
 #endif
+            RN_T(1);
             // This step's operands FIRST: the compiler cannot tell the two buffers apart, so every LDS read that follows the
             // plane stores in program order waits for them -- and they wait for the whole split.
             Split8 sa[2], sb[2];
@@ -486,11 +513,26 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                     sb[t].l = *reinterpret_cast<const bf16x8 *>(Bp + 2 * BPL);
                 }
             }
+            RN_T(2);
+#if RN_KO & 32                                              // LDS-traffic experiment (timing only): 8 more operand reads per K-step
+            u32x4 xd0, xd1;
+            {
+                const unsigned la = lds_addr(lds + rb * STEP + fas[0]);
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\tds_read_b128 %0, %2 offset:8192\n\tds_read_b128 %1, %2 offset:12288\n\t"
+                             "ds_read_b128 %0, %2 offset:16384\n\tds_read_b128 %1, %2 offset:20480\n\tds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:6144"
+                             : "=&v"(xd0), "=&v"(xd1) : "v"(la) : "memory");
+            }
+#endif
             split_a(rb ^ 1, cur);
+            RN_T(3);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+            RN_T(4);
+#if RN_KO & 32
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xd0), "+v"(xd1)::"memory");
+#endif
 #if RN_SGB
             // Spread the split's vector work and the plane stores between the 24 MFMAs (32 cycles each, of which 24 are free
             // issue slots): left alone the compiler puts all of it in front of the first MFMA.
@@ -507,12 +549,29 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #endif
             RN_PIN();
             rn_wait_dma();                                  // B planes of step ks + 1 landed, A registers of step ks + 2 arrived
+            RN_T(5);
             __syncthreads();                                // (and the A planes' ds_writes: the barrier waits for lgkmcnt)
+            RN_T(6);
+#if RN_STAMP
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st_sum[i] += st_t[i + 1] - st_t[i];
+#endif
         };
         for (int ks = 0; ks < nks; ks += 2) {
             k_step(ks, 0, ar, arn);
             if (ks + 1 < nks) k_step(ks + 1, 1, arn, ar);
         }
+#if RN_STAMP
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1)::"memory");
+        if (lane == 0) {
+            atomicAdd(&rn_stamps[10], st_c1 - st_c0);
+            atomicAdd(&rn_stamps[11], st_r1 - st_r0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) atomicAdd(&rn_stamps[i], st_sum[i]);
+            atomicAdd(&rn_stamps[8], (unsigned long long)nks);
+            atomicAdd(&rn_stamps[9], 1ull);
+        }
+#endif
     }
     if (SPLIT != 3 && nks > 0) dma_step(0, 0);
     if (SPLIT != 3 && NBUF > 2 && nks > 1) dma_step(1, 1);

@@ -87,6 +87,21 @@ __device__ __forceinline__ void split_store_chunk(const float *__restrict__ src,
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).l, (B).h, ACC, 0, 0, 0);        \
         ACC[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, (A).h)[0] ^ __builtin_bit_cast(u32x4, (A).m)[1] ^ __builtin_bit_cast(u32x4, (B).m)[2] ^ __builtin_bit_cast(u32x4, (B).l)[3]) * 1e-30f; \
     } while (0)
+#elif defined(RN_KO) && (RN_KO & 16)                  // shape experiment (timing only, wrong results): every 32x32x16 as two 16x16x32 (same pipe cycles)
+typedef float rn_f32x4 __attribute__((ext_vector_type(4)));
+#define RN_MF16(ACC, X, Y)                                                                \
+    do {                                                                                  \
+        rn_f32x4 lo_ = __builtin_shufflevector(ACC, ACC, 0, 1, 2, 3), hi_ = __builtin_shufflevector(ACC, ACC, 4, 5, 6, 7); \
+        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y, lo_, 0, 0, 0);                \
+        hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y, hi_, 0, 0, 0);                \
+        ACC[0] = lo_[0]; ACC[1] = lo_[1]; ACC[2] = lo_[2]; ACC[3] = lo_[3];               \
+        ACC[4] = hi_[0]; ACC[5] = hi_[1]; ACC[6] = hi_[2]; ACC[7] = hi_[3];               \
+    } while (0)
+#define RN_SPLIT_MFMA(ACC, A, B)                                                          \
+    do {                                                                                  \
+        RN_MF16(ACC, (A).l, (B).h); RN_MF16(ACC, (A).h, (B).l); RN_MF16(ACC, (A).m, (B).m); \
+        RN_MF16(ACC, (A).m, (B).h); RN_MF16(ACC, (A).h, (B).m); RN_MF16(ACC, (A).h, (B).h); \
+    } while (0)
 #else
 #define RN_SPLIT_MFMA(ACC, A, B)                                                          \
     do {                                                                                  \

@@ -13,21 +13,28 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["1", "2", "3"])
+ENV = ("RN_BIG_TILE_MIN", "RN_BIG_TILE", "RN_MF16", "RN_MF16_MIN")
+
+
+@pytest.fixture(scope="module", params=["1", "2", "3", "mf16"])
 def cv(dev, request):
     """RN_BIG_TILE=1: four waves of 128 x 128; =2: eight waves (two per SIMD) of 128 x 64; =3: the same with three LDS buffers and
-    counted waits (loads in flight across the barrier)."""
+    counted waits (loads in flight across the barrier).  mf16: csrc/conv_igemm_mf16.hip -- 128 x 256 tiles on
+    v_mfma_f32_16x16x32_bf16, the product default for layers with more than 128 output channels, here forced onto small shapes
+    (RN_MF16_MIN=1) and compared with the 128 x 128 kernels (RN_MF16=0)."""
     from retinanet_mi355x import conv
-    before = conv.get_fp32_mfma(), conv.PRESPLIT, os.environ.get("RN_BIG_TILE_MIN"), os.environ.get("RN_BIG_TILE")
+    before = (conv.get_fp32_mfma(), conv.PRESPLIT) + tuple(os.environ.get(k) for k in ENV)
     conv.set_fp32_mfma("split")
     conv.PRESPLIT = True
-    os.environ["RN_BIG_TILE_MIN"] = "1"
-    os.environ["RN_BIG_TILE"] = request.param
-    conv._big_mode = request.param
+    if request.param == "mf16":
+        conv._big_on = {"RN_BIG_TILE": "0", "RN_MF16": "1", "RN_MF16_MIN": "1"}
+    else:
+        conv._big_on = {"RN_BIG_TILE": request.param, "RN_BIG_TILE_MIN": "1", "RN_MF16": "0"}
+    os.environ.update(conv._big_on)
     yield conv
     conv.set_fp32_mfma(before[0])
     conv.PRESPLIT = before[1]
-    for key, val in (("RN_BIG_TILE_MIN", before[2]), ("RN_BIG_TILE", before[3])):
+    for key, val in zip(ENV, before[2:]):
         if val is None:
             os.environ.pop(key, None)
         else:
@@ -53,11 +60,11 @@ def close(got, want, tol=1e-5):
 def _both_kernels(cv, fn):
     """fn() with the big tile on, then off: the two kernels must agree with each other too (same products, other order)."""
     a = fn()
-    os.environ["RN_BIG_TILE"] = "0"
+    os.environ.update({"RN_BIG_TILE": "0", "RN_MF16": "0"})
     try:
         b = fn()
     finally:
-        os.environ["RN_BIG_TILE"] = cv._big_mode
+        os.environ.update(cv._big_on)
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     return a
 
