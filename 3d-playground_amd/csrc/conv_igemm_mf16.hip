@@ -40,17 +40,17 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
     } while (0)
 
-template <bool GENERAL, bool RAW>
+template <bool GENERAL, bool RAW, int BN>
 __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
                                                float *__restrict__ y, const float *__restrict__ scale,
                                                const float *__restrict__ shift, const float *__restrict__ add,
                                                const float *__restrict__ mask, const float *__restrict__ add2, const int tile) {
-    constexpr int BK = 32, NT = 256, BM = 128, BN = 128;
+    constexpr int BK = 32, BM = 128, NSN = BN / 16;        // BN = 128, or 64 for layers with at most 64 output channels
     constexpr int BPL = BN * 16;                           // floats' worth of one bf16 plane: rows x 64 bytes
     constexpr int BSTEP = 3 * BPL;                         // one buffer: B planes h, m, l
     constexpr int NBI = 3 * BN / 16, IB = NBI / 4;         // direct-to-LDS instructions (16 rows x 64 bytes each) per step / per wave
     constexpr int LDT = BN + 4;
-    static_assert(NBI % 4 == 0, "tile shape");
+    static_assert(NBI % 4 == 0 && (BN == 64 || BN == 128), "tile shape");
     __shared__ float lds[2 * BSTEP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,11 +138,11 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             dma16(rs_b, lds0 + (unsigned)(buf * BSTEP * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 192));
     };
 
-    f32x4a acc[2][8];
+    f32x4a acc[2][NSN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NSN; ++j) acc[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
     // plane 0 of this lane's operand chunk of weight rows 16 * t + lr (floats, within a buffer): 16 * row + 4 * (lg ^ ((row >> 2) & 3));
     // 16 * t does not change (row >> 2) & 3, so one address and an immediate per t
     const int fb0 = 16 * lr + 4 * (lg ^ ((lr >> 2) & 3));
@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         load_a(cur);
         const float *S = lds + rb * BSTEP + fb0;
 #pragma unroll
-        for (int sn = 0; sn < 8; ++sn) {
+        for (int sn = 0; sn < NSN; ++sn) {
             Split8 sb;
             sb.h = *reinterpret_cast<const bf16x8 *>(S + 256 * sn);
             sb.m = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + BPL);
@@ -187,11 +187,12 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // ---- epilogue, WAVE-PRIVATE: a wave owns tile rows 32 w .. 32 w + 31 and all 128 columns, so it transposes its accumulators
     // through a 16-row strip of LDS of its own (the staging buffers are free after the last barrier) and nobody waits for anybody:
     // no workgroup barrier after the K loop.  Accumulator element e of lane l is row 4 * (l >> 4) + e, column l & 15 of its
-    // 16 x 16 tile; out of the strip a lane takes float4s: 32 consecutive lanes one 512-byte row segment, so out, add and mask all
+    // 16 x 16 tile; out of the strip a lane takes float4s: BN / 4 consecutive lanes one whole row segment, so out, add and mask all
     // move as 16-byte accesses (conv_igemm_tile.h: same arithmetic, same macros).
     float *T = lds + wave * (16 * LDT);
     static_assert(4 * 16 * LDT <= 2 * BSTEP, "four strips fit the staging buffers");
-    const int c4 = lane & 31;
+    constexpr int CPR = BN / 4, RPI = 64 / CPR;              // 16-byte chunks per row, rows one wave instruction covers
+    const int c4 = lane % CPR;
     const int col = n0 + 4 * c4;
     const bool col_ok = col < d.Cout;
     const bool vec = true;                                   // the launcher sends Cout % 4 == 0 only
@@ -205,13 +206,13 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
 #pragma unroll
     for (int sm = 0; sm < 2; ++sm) {
 #pragma unroll
-        for (int sn = 0; sn < 8; ++sn)
+        for (int sn = 0; sn < NSN; ++sn)
 #pragma unroll
             for (int e = 0; e < 4; ++e) T[(4 * lg + e) * LDT + 16 * sn + lr] = acc[sm][sn][e];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is this wave's own: order within the wave is all it needs
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        constexpr int NIT = 8, G = 4;                        // 16 rows, two per instruction
+        constexpr int NIT = 16 / RPI, G = 4;                 // 16 rows, RPI per instruction
         if (col_ok) {
 #pragma unroll 1
             for (int g = 0; g < NIT; g += G) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                 float4 mk_[G], ad_[G];
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    const int64_t mr = (int64_t)m0 + 32 * wave + 16 * sm + (lane >> 5) + 2 * (g + i);
+                    const int64_t mr = (int64_t)m0 + 32 * wave + 16 * sm + lane / CPR + RPI * (g + i);
                     const int64_t m = mr < M ? mr : M - 1;
                     RN_EPI_ADDR(GENERAL)
                     off_[i] = off;
@@ -231,7 +232,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                 }
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    const int r = (lane >> 5) + 2 * (g + i);
+                    const int r = lane / CPR + RPI * (g + i);
                     const int64_t m = (int64_t)m0 + 32 * wave + 16 * sm + r;
                     if (m < M) {
                         const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
@@ -253,13 +254,13 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     }
 }
 
-template <bool GENERAL, bool RAW>
+template <bool GENERAL, bool RAW, int BN>
 __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const float *__restrict__ add, const float *__restrict__ mask,
                                                               const float *__restrict__ add2) {
-    conv_mf16_tile<GENERAL, RAW>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_mf16_tile<GENERAL, RAW, BN>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const r
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_mf16_tile<true, false>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_mf16_tile<true, false, 128>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // Which problems take this kernel: RN_MF16=0 turns it off (A/B); launches with fewer than RN_MF16_MIN tiles keep the 32x32x16
@@ -291,23 +292,28 @@ static int mf16_min_tiles() {
 }
 static bool mf16_ok(const rn_conv_desc *d) {
     return mf16_on() && d->w_format == 1 && (d->Cin % 32) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
-           (d->Cout % 4) == 0 && d->Cout > 64 && !d->in_relu;
+           (d->Cout % 4) == 0 && !d->in_relu;
 }
 static int64_t mf16_tiles(const rn_conv_desc *d) {
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-    return ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    return ((M + 127) / 128) * (d->Cout <= 64 ? 1 : (d->Cout + 127) / 128);
 }
 
-// -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 4 dense, 5 general.
+// -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 2 / 3 narrow (Cout <= 64) dense / general, 4 / 5 wide dense / general.
 bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
                           const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc) {
-    if (!mf16_ok(d) || (variant != 0 && variant != 4 && variant != 5)) return false;
+    if (!mf16_ok(d) || variant == 1 || variant < 0 || variant > 5) return false;
+    if ((variant == 2 || variant == 3) != (d->Cout <= 64)) return false;
+    // the 128 x 64 instance measured neutral (3x3 64->64 +3 %, 1x1 256->64 -3 %, conv_igemm_4x1 5.68 -> 5.76 ms per step): opt-in
+    if (d->Cout <= 64 && !(getenv("RN_MF16_NARROW") && atoi(getenv("RN_MF16_NARROW")))) return false;
     const int64_t tiles = mf16_tiles(d);
     if (tiles < mf16_min_tiles() || tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles), block(256);
-    if (variant == 0) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, true>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else if (variant == 4) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else hipLaunchKernelGGL((conv_igemm_mf16_kernel<true, false>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    if (variant == 0) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, true, 128>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else if (variant == 4) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, false, 128>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else if (variant == 5) hipLaunchKernelGGL((conv_igemm_mf16_kernel<true, false, 128>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else if (variant == 2) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, false, 64>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+    else hipLaunchKernelGGL((conv_igemm_mf16_kernel<true, false, 64>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
     const hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? RN_OK : (int)e;
     return true;
@@ -315,7 +321,7 @@ bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, co
 
 bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc) {
     for (int i = 0; i < g->n; ++i)
-        if (!mf16_ok(&g->d[i])) return false;
+        if (!mf16_ok(&g->d[i]) || g->d[i].Cout <= 64) return false;
     rn_conv_group gb = *g;                                  // the caller's tile table counts 128 x 128 tiles: recount
     int64_t total = 0;
     for (int i = 0; i < g->n; ++i) {

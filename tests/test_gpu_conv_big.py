@@ -13,7 +13,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-ENV = ("RN_BIG_TILE_MIN", "RN_BIG_TILE", "RN_MF16", "RN_MF16_MIN")
+ENV = ("RN_BIG_TILE_MIN", "RN_BIG_TILE", "RN_MF16", "RN_MF16_MIN", "RN_MF16_NARROW")
 
 
 @pytest.fixture(scope="module", params=["1", "2", "3", "mf16"])
@@ -27,7 +27,7 @@ def cv(dev, request):
     conv.set_fp32_mfma("split")
     conv.PRESPLIT = True
     if request.param == "mf16":
-        conv._big_on = {"RN_BIG_TILE": "0", "RN_MF16": "1", "RN_MF16_MIN": "1"}
+        conv._big_on = {"RN_BIG_TILE": "0", "RN_MF16": "1", "RN_MF16_MIN": "1", "RN_MF16_NARROW": "1"}
     else:
         conv._big_on = {"RN_BIG_TILE": request.param, "RN_BIG_TILE_MIN": "1", "RN_MF16": "0"}
     os.environ.update(conv._big_on)
@@ -76,6 +76,9 @@ CASES = [  # cin, cout, k, stride, pad, N, H, W
     (32, 192, 3, 1, 1, 3, 9, 11),        # Cout = 192 < 256, several images inside one row tile
     (1024, 256, 1, 1, 0, 2, 17, 15),     # long K
     (128, 256, 3, 2, 1, 2, 37, 29),      # 3x3 stride 2
+    (64, 64, 3, 1, 1, 2, 19, 23),        # at most 64 output channels: the mf16 kernel's 128 x 64 instance (the others: their usual kernel)
+    (256, 64, 1, 1, 0, 1, 33, 31),
+    (128, 32, 3, 2, 1, 2, 21, 17),       # 32 of the 64 columns masked
 ]
 
 
