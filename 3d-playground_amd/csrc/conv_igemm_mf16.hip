@@ -336,13 +336,3 @@ bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const 
     return true;
 }
 
-#if RN_STAMP
-// diagnostic build: read and clear this file's K-step stamps (tools/stamp_split.py --mf16)
-extern "C" int rn_debug_stamps_mf16(unsigned long long *out) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rn_stamps), sizeof(rn_stamps)) != hipSuccess) return -1;
-    unsigned long long z[16] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rn_stamps), z, sizeof(z)) != hipSuccess) return -1;
-    return 0;
-}
-#endif

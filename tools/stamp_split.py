@@ -20,8 +20,6 @@ from bench_conv import SHAPES, timeit  # noqa: E402
 
 SEG = ["issue loads (3 DMA + 2 register loads)", "operand reads landed (12 ds_read_b128)", "split + plane stores landed",
        "24 MFMAs issued", "wait vmcnt(0)", "barrier"]
-SEG16 = ["issue loads (6 DMA + 4 register loads)", "operand reads issued+landed (24 ds_read_b128)", "barrier X", "split + plane stores landed",
-         "96 MFMAs issued", "wait vmcnt(0)", "barrier Y"]
 
 
 def main():
@@ -29,10 +27,9 @@ def main():
     ap.add_argument("--only", default="head 3x3 256->256 P3")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--mf16", action="store_true", help="the 16x16x32 kernel (conv_igemm_mf16.hip; K-steps of 32)")
     args = ap.parse_args()
-    seg = SEG16 if args.mf16 else SEG
-    os.environ["RN_MF16"] = "1" if args.mf16 else "0"
+    seg = SEG
+    os.environ["RN_MF16"] = "0"                              # the stamps are in the 32x32x16 kernel (conv_igemm_tile.h, SPLIT 3)
     cv.set_fp32_mfma("split")
     lib = ctypes.CDLL(_hip.LIB_PATH)
     buf = (ctypes.c_ulonglong * 16)()
@@ -44,7 +41,7 @@ def main():
         w = torch.randn(cout, cin, k, k, device=dev) * 0.05
         wp = cv.pack_weights(w, 0)
         bias = torch.randn(cout, device=dev)
-        read = lib.rn_debug_stamps_mf16 if args.mf16 else lib.rn_debug_stamps
+        read = lib.rn_debug_stamps
         read(buf)                                                 # clear
         t = timeit(lambda: cv.fprop(x, wp, cout, k, stride, pad, shift=bias, act=cv.ACT_RELU), args.iters)
         assert read(buf) == 0
