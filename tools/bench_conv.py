@@ -31,6 +31,11 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W
     ("l4 1x1 512->2048", 512, 2048, 1, 1, 0, 34, 60),
     ("l2.0 3x3 s2 128->128", 128, 128, 3, 2, 1, 270, 480),
     ("gemm-like 1x1 256->256 P3", 256, 256, 1, 1, 0, 135, 240),      # K = 256: the Winograd stage's GEMM shape per position
+    ("ksweep 1x1 64->256 P3", 64, 256, 1, 1, 0, 135, 240),
+    ("ksweep 1x1 128->256 P3", 128, 256, 1, 1, 0, 135, 240),
+    ("ksweep 1x1 512->256 P3", 512, 256, 1, 1, 0, 135, 240),
+    ("ksweep 1x1 1024->256 P3", 1024, 256, 1, 1, 0, 135, 240),
+    ("ksweep 1x1 2048->256 P3", 2048, 256, 1, 1, 0, 135, 240),
     # occupancy probes (run with --batch 1): 256 / 512 / 1024 / 2048 workgroups of the 128x128 tile, K = 2304
     ("probe 256wg", 256, 128, 3, 1, 1, 128, 256),
     ("probe 512wg", 256, 128, 3, 1, 1, 256, 256),
