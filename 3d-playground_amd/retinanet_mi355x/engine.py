@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from . import _hip, arch, conv as cv, ops
+from . import _hip, arch, conv as cv, ops, prof
 
 
 # The two input-side transforms of an output gradient (for the weight gradient and for the data gradient of a Winograd layer) in
@@ -412,6 +412,7 @@ class Engine:
         # slices of it (no packing copy) handed to bucket_hook the moment their last layer retires, and (b) gradient
         # pointers are the same every step (the optimizer's pointer table is uploaded once).
         self.flat_bucket_bytes = None
+        self._tower_streams = {}
         self.flat_tail_bytes = None
         self.bucket_hook = None                    # callable(bucket index, flat slice) when a bucket is complete
         self._flat = None
@@ -559,6 +560,19 @@ class Engine:
         return arena, {n: arena[o:o + k].view(shp) for n, (o, k, shp) in f["slots"].items()}
 
     # ------------------------------------------------------------------------------------------- helpers
+    def tower_streams(self, device):
+        """The two side streams the head towers run on (forward and backward), or None: RN_TOWER_STREAMS=0, CPU tensors, a stream
+        capture in progress (a captured graph keeps the single-stream order) or per-kernel timing (prof.ACTIVE: a kernel's
+        duration means something only when nothing else shares the GPU)."""
+        if device.type != "cuda" or os.environ.get("RN_TOWER_STREAMS", "1") == "0" or prof.ACTIVE is not None:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = self._tower_streams.get(device)
+        if st is None:
+            st = self._tower_streams[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        return st
+
     def anchors(self, H, W, device):
         key = (H, W, str(device))
         if key not in self.anchor_cache:
@@ -840,23 +854,41 @@ class Engine:
         if save:
             S["towers"] = {"regressionModel": [], "classificationModel": []}
             S["counts"] = counts
-        for prefix, out, width, act in (("regressionModel", reg, self.n_reg, cv.ACT_NONE),
-                                        ("classificationModel", cls, self.num_classes, cv.ACT_SIGMOID)):
-            ts = pyramid
-            acts = []                                                     # acts[i][level]
-            for i in range(1, 5):                                         # one launch per tower conv, all 5 levels
-                first = Ls["regressionModel.conv1"]                       # both towers' conv1 transform the same pyramid: once
-                shared = first.saved_v if (i == 1 and prefix == "classificationModel") else None
-                ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16 and not self.fp8,
-                                                             shared_v=shared)
-                acts.append(ts)
-            views, off = [], 0
-            for cnt in counts:
-                views.append(out.view(B, -1)[:, off * width:])
-                off += cnt
-            Ls[prefix + ".output"].fwd_group(ts, act=act, outs=views, y_batch_stride=A * width)
+        # The two towers are independent chains: each runs on a stream of its own (tower_streams), so that one tower's HBM-bound
+        # Winograd transforms and store phases overlap the other's MFMA-bound GEMMs.  The classification tower's first layer reuses
+        # the regression tower's input transform of the pyramid: it waits for that one launch, not for the tower.
+        side = self.tower_streams(x4.device)
+        main = torch.cuda.current_stream(x4.device)
+        v_ready = None
+        if side is not None:
+            fork = main.record_event()
+        for ti, (prefix, out, width, act) in enumerate((("regressionModel", reg, self.n_reg, cv.ACT_NONE),
+                                                        ("classificationModel", cls, self.num_classes, cv.ACT_SIGMOID))):
+            if side is not None:
+                side[ti].wait_event(fork)
+                if ti == 1 and v_ready is not None:
+                    side[ti].wait_event(v_ready)
+            with torch.cuda.stream(side[ti] if side is not None else main):
+                ts = pyramid
+                acts = []                                                 # acts[i][level]
+                for i in range(1, 5):                                     # one launch per tower conv, all 5 levels
+                    first = Ls["regressionModel.conv1"]                   # both towers' conv1 transform the same pyramid: once
+                    shared = first.saved_v if (i == 1 and prefix == "classificationModel") else None
+                    ts = Ls["%s.conv%d" % (prefix, i)].fwd_group(ts, act=cv.ACT_RELU, wino=save and self.use_wino and not self.bf16 and not self.fp8,
+                                                                 shared_v=shared)
+                    acts.append(ts)
+                    if side is not None and ti == 0 and i == 1:
+                        v_ready = side[0].record_event()
+                views, off = [], 0
+                for cnt in counts:
+                    views.append(out.view(B, -1)[:, off * width:])
+                    off += cnt
+                Ls[prefix + ".output"].fwd_group(ts, act=act, outs=views, y_batch_stride=A * width)
             if save:
                 S["towers"][prefix] = [[acts[i][li] for i in range(4)] for li in range(5)]
+        if side is not None:
+            main.wait_stream(side[0])
+            main.wait_stream(side[1])
         if save:
             # The Winograd input transforms kept for the weight gradients belong to THIS call: a second forward before
             # this one's backward must not replace them (the Layer objects are shared between calls).
@@ -911,31 +943,47 @@ class Engine:
         dpyr = [None] * 5
         # ---- heads
         hws = [(f.shape[1], f.shape[2]) for f in pyramid]
-        for prefix, dout, width, sig in (("regressionModel", dreg, self.n_reg, None),
-                                         ("classificationModel", dcls, self.num_classes, cls)):
+        # Two streams as in forward.  The towers meet in the pyramid's gradient: the second tower's last data gradient adds the
+        # first tower's, so it waits for that tower's end there; the gradient bookkeeping (done) runs on the main stream after both.
+        side = self.tower_streams(dreg.device)
+        main = torch.cuda.current_stream(dreg.device)
+        if side is not None:
+            fork = main.record_event()
+        retired = []
+        for ti, (prefix, dout, width, sig) in enumerate((("regressionModel", dreg, self.n_reg, None),
+                                                         ("classificationModel", dcls, self.num_classes, cls))):
             Lout = Ls[prefix + ".output"]
             tower = [Ls["%s.conv%d" % (prefix, i)] for i in range(1, 5)]
             acts = S["towers"][prefix]                                    # acts[level][i]
-            gs, off = [], 0
-            for (Hh, Ww), cnt in zip(hws, counts):                        # head-output gradient slices -> dense, padded
-                byte_off = 4 * off * width
-                g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
-                                       B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device,
-                                       bf16=self.bf16)
-                gs.append(g.view(B, Hh, Ww, Lout.cout_pad))
-                off += cnt
-            Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
-            gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
-            for i in (3, 2, 1):
-                tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
-                gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
-            tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino and not self.bf16)
-            first = dpyr[0] is None
-            dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino and not self.bf16)
+            if side is not None:
+                side[ti].wait_event(fork)
+            with torch.cuda.stream(side[ti] if side is not None else main):
+                gs, off = [], 0
+                for (Hh, Ww), cnt in zip(hws, counts):                    # head-output gradient slices -> dense, padded
+                    byte_off = 4 * off * width
+                    g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
+                                           B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device,
+                                           bf16=self.bf16)
+                    gs.append(g.view(B, Hh, Ww, Lout.cout_pad))
+                    off += cnt
+                Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
+                gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
+                for i in (3, 2, 1):
+                    tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
+                    gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
+                tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino and not self.bf16)
+                first = dpyr[0] is None
+                if side is not None and not first:
+                    side[ti].wait_stream(side[0])                         # the other tower's pyramid gradient is complete
+                dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino and not self.bf16)
             S["towers"][prefix] = None
-            done(Lout)
-            for L in reversed(tower):
-                done(L)
+            retired.append(Lout)
+            retired.extend(reversed(tower))
+        if side is not None:
+            main.wait_stream(side[0])
+            main.wait_stream(side[1])
+        for L in retired:
+            done(L)
         # ---- FPN
         c3, c4, c5, p5lat, p4sum, p3sum, p6 = S["fpn"]
         dp3, dp4, dp5, dp6, dp7 = dpyr
