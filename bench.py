@@ -330,10 +330,10 @@ def pmc_traffic(kind):
     (tools/collect_traffic.sh -> profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).
     PMC counters cannot be read from inside the process, so the number is the last collected one, or None."""
     prefix = {"conv_igemm_2x2": ("conv_igemm_kernel<2, 2", "conv_igemm_grouped_kernel<2, 2", "conv_igemm_split_kernel<2, 2",
-                                 "conv_igemm_split_grouped_kernel<2, 2"),
+                                 "conv_igemm_split_grouped_kernel<2, 2", "conv_igemm_mf16_kernel", "conv_igemm_mf16_grouped_kernel"),
               "conv_igemm_4x1": ("conv_igemm_kernel<4, 1", "conv_igemm_grouped_kernel<4, 1", "conv_igemm_split_kernel<4, 1",
                                  "conv_igemm_split_grouped_kernel<4, 1"),
-              "conv_wgrad": ("conv_wgrad_kernel",),
+              "conv_wgrad": ("conv_wgrad_kernel", "conv_wgrad_once_kernel"),
               "wino_input": ("wino_in_kernel", "wino_in_both_kernel", "wino_dy_kernel"),
               "wino_output": ("wino_out_kernel",)}.get(kind)
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")

@@ -22,12 +22,12 @@ dur = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_split/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "split" in n or "wgrad" in n:
+        if "split" in n or "wgrad" in n or "mf16" in n:
             agg[n[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("gpurun_out/pmc_split/g0/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "split" in n or "wgrad" in n:
+        if "split" in n or "wgrad" in n or "mf16" in n:
             dur[n[:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, d in agg.items():
     print(k, " launches", len(dur[k]), " avg %.1f us" % (sum(dur[k]) / max(len(dur[k]), 1)))
