@@ -325,7 +325,10 @@ def test_training_trajectories_agree_between_product_modes(dev):
     # measured: native vs native 0, 5e-7, 1e-7, 0, 1e-6, 5e-6, 2e-5, 9e-5, 3e-4, 9e-4, 1e-3, 8e-3;
     #           split vs native  2e-7, 0, 2e-7, 2e-6, 1e-4, 3e-4, 1e-4, 9e-5, 1e-4, 1e-4, 3e-3, 4e-3
     assert cross[:3].max() <= 1e-5, cross                                   # fp32 rounding while the dynamics have not amplified it
-    assert cross.max() <= 5 * same.max() + 2e-3, (same, cross)              # and never further apart than two runs of one mode
+    # ... and later never further apart than two runs of ONE mode get: their drift (atomics order) has been measured from 5e-7 (a run
+    # where both orders happened to agree; the split run was 6.1e-3 off by step 12 then) to 8e-3, so the bound cannot lean on this
+    # run's `same` alone
+    assert cross.max() <= 5 * same.max() + 2e-2, (same, cross)
 
 
 def test_fused_clip_adam_matches_torch(dev):
