@@ -61,7 +61,7 @@ bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const 
 
 static int dbg_dyn_lds(const void *fn) {                  // occupancy experiment: RN_DBG_DYN_LDS bytes of unused dynamic LDS per workgroup
     static const int v = getenv("RN_DBG_DYN_LDS") ? atoi(getenv("RN_DBG_DYN_LDS")) : 0;
-    if (v > 16384) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+    if (v > 16384) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, v);
     return v;
 }
 
