@@ -32,6 +32,7 @@
 // 132 registers.  Conditions (the launcher's): pre-split weights, Cin a multiple of 32, div_shift 0, kh * kw <= 24, Cout a multiple
 // of 4 and > 64 (a 128 x 64 instance for narrower layers measured neutral: opt-in), no input ReLU.
 #include "conv_igemm_tile.h"
+#include "conv_wgrad_geom.h"
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
@@ -133,7 +134,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
         const int q = wave * IB + j, plane = q / (BN / 16), brow = (q % (BN / 16)) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ (3 * ((lane >> 5) & 1));
+        const int c = Mf16Geom::dma_chunk(lane);
         const int n = n0 + brow;
         b_voff[j] = n < d.Cout ? (unsigned)(n * Kpad * 6 + (c >> 1) * 96 + plane * 32 + (c & 1) * 16) : 0x80000000u;
     }
@@ -151,7 +152,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         for (int j = 0; j < NSN; ++j) acc[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
     // plane 0 of this lane's operand chunk of weight rows 16 * t + lr (floats, within a buffer): 16 * row + 4 * (lg ^ 3 * ((row >> 3) & 1));
     // 16 * t does not change (row >> 3) & 1, so one address and an immediate per t
-    const int fb0 = 16 * lr + 4 * (lg ^ (3 * ((lr >> 3) & 1)));
+    const int fb0 = Mf16Geom::read_addr(lane, 0) / 4;
 
     // ---- K loop.  `cur` holds the A values of step ks (loaded during step ks - 1): split into the MFMA operands, then the same
     // registers receive step ks + 1 -- a whole MFMA phase to arrive.  Unconditional (one basic block): past the last step the loads

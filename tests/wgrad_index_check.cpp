@@ -118,6 +118,40 @@ static void check_split_once() {
     std::printf("ok split-once: image %d bytes, buffer %d bytes\n", G::IMG, G::BUF);
 }
 
+// conv_igemm_mf16.hip: operand reads of every lane group conflict-free, and the direct-to-LDS fill consistent with them
+static void check_mf16() {
+    using G = Mf16Geom;
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    for (int t = 0; t < 8; ++t)
+        for (int g = 0; g < 4; ++g) {
+            std::set<int> slots;
+            for (int i = 0; i < 16; ++i) {
+                const int a = G::read_addr(groups[g][i], t);
+                CHECK(a >= 0 && a + 16 <= 128 * G::ROWB && a % 16 == 0, "mf16: read address %d of lane %d, tile %d", a, groups[g][i], t);
+                slots.insert((a % 256) / 16);
+            }
+            CHECK((int)slots.size() == 16, "mf16: lane group %d of row block %d covers %d of the 16 slots of the bank row", g, t, (int)slots.size());
+        }
+    // a DMA instruction fills 16 rows x 64 bytes linearly: lane -> row lane >> 2, slot lane & 3; the chunk it fetches must be the one the
+    // readers expect at that slot, in every 16-row block (16 does not change (row >> 3) & 1's pattern within a block)
+    for (int blk = 0; blk < 8; ++blk)
+        for (int l = 0; l < 64; ++l) {
+            const int row = 16 * blk + (l >> 2);
+            CHECK(G::slot(row, G::dma_chunk(l)) == (l & 3), "mf16: lane %d of block %d fetches chunk %d, which belongs at slot %d", l, blk,
+                  G::dma_chunk(l), G::slot(row, G::dma_chunk(l)));
+        }
+    // and every row's four chunks occupy its four slots
+    for (int row = 0; row < 128; ++row) {
+        std::set<int> s4;
+        for (int c = 0; c < 4; ++c) s4.insert(G::slot(row, c));
+        CHECK((int)s4.size() == 4, "mf16: row %d places two chunks in one slot", row);
+    }
+    std::printf("ok mf16: weight planes of 64-byte rows, ds_read_b128 lane groups conflict-free\n");
+}
+
 int main() {
     check_fp32<1, 4, 16>("fp32 64x256");       // the three instances rn_conv_wgrad_batched launches (conv_wgrad.hip)
     check_fp32<4, 1, 16>("fp32 256x64");
@@ -125,6 +159,7 @@ int main() {
     check_fp32<2, 2, 32>("fp32 128x128 / 32-pixel steps");
     check_bf16();
     check_split_once();
+    check_mf16();
     if (fails) std::printf("%d violation(s)\n", fails);
     return fails ? 1 : 0;
 }
