@@ -127,3 +127,30 @@ def test_deterministic_weight_gradients_are_bit_reproducible(dev, mode, mfma):
     for n in g_a:
         err = float((g_a[n].double() - g_c[n].double()).norm() / (g_c[n].double().norm() + 1e-30))
         assert err <= 1e-5, (n, err)
+
+
+@pytest.mark.parametrize("mode", ["wino", "direct"])
+def test_tower_streams_change_no_bit(dev, mode, mfma, monkeypatch):
+    """The two head towers run on a side stream each (engine.py: tower_streams; forward and backward).  In deterministic mode the
+    step's result does not depend on timing, so the run on two streams must equal the run on the caller's stream BIT FOR BIT -- any
+    missing event (a tower reading the pyramid gradient, a Winograd scratch or a saved transform too early) shows up here."""
+    from retinanet_mi355x import conv, synth
+    net = _net(dev, mode == "wino")
+    h, w = 360, 640
+    img = synth.frames(2, h, w, seed=7).to(dev)
+    ann = synth.labels_dir(2, 6, h, w, 8, seed=8, size_px=(40, 120)).to(dev)
+    before = conv.get_option(conv.OPT_DETERMINISTIC)
+    conv.set_deterministic(True)
+    try:
+        monkeypatch.setenv("RN_TOWER_STREAMS", "0")
+        assert net._engine.tower_streams(dev) is None
+        l_one, g_one = _step(net, img, ann)
+        monkeypatch.setenv("RN_TOWER_STREAMS", "1")
+        assert net._engine.tower_streams(dev) is not None
+        for _ in range(3):                                          # several runs: a race need not show the first time
+            l_two, g_two = _step(net, img, ann)
+            assert l_one == l_two
+            for n in g_one:
+                assert torch.equal(g_one[n], g_two[n]), "%s differs between one stream and two" % n
+    finally:
+        conv.set_option(conv.OPT_DETERMINISTIC, before)
