@@ -408,15 +408,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_big_grouped_kernel(
 
 // Which problems take the big tile: RN_BIG_TILE=0 turns it off (A/B); min_tiles = launches with fewer 256 x 256 tiles leave
 // CUs idle (one workgroup per CU) and keep the 128 x 128 kernels.
-// (read at every launch, not cached: the parity tests force the big tile onto small problems at run time)
-static int big_tile_mode() {
-    const char *e = getenv("RN_BIG_TILE");
-    return e ? atoi(e) : 0;
-}
-static int big_min_tiles() {
-    const char *e = getenv("RN_BIG_TILE_MIN");
-    return e ? atoi(e) : 200;
-}
+// (rn_get_option: the environment is read once; the parity tests force the big tile onto small problems with rn_set_option)
+static int big_tile_mode() { return rn_get_option(RN_OPT_BIG_TILE); }
+static int big_min_tiles() { return rn_get_option(RN_OPT_BIG_TILE_MIN); }
 static bool big_ok(const rn_conv_desc *d) {
     return big_tile_mode() && d->w_format == 1 && (d->Cin % 16) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
            (d->Cout % 4) == 0 && d->Cout >= 192 && !d->in_relu;

@@ -287,16 +287,10 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const r
     conv_mf16_tile<true, false, 128>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
-// Which problems take this kernel: RN_MF16=0 turns it off (A/B); launches with fewer than RN_MF16_MIN tiles keep the 32x32x16
-// kernels (three workgroups per CU there, two here).  (read at every launch, not cached: the parity tests force it onto small problems)
-static int mf16_on() {
-    const char *e = getenv("RN_MF16");
-    return e ? atoi(e) : 1;
-}
-static int mf16_min_tiles() {
-    const char *e = getenv("RN_MF16_MIN");
-    return e ? atoi(e) : 1;
-}
+// Which problems take this kernel: RN_OPT_MF16 = 0 turns it off (A/B); launches with fewer than RN_OPT_MF16_MIN tiles keep the
+// 32x32x16 kernels.  (rn_get_option: the environment is read once, not per launch; the parity tests switch with rn_set_option.)
+static int mf16_on() { return rn_get_option(RN_OPT_MF16); }
+static int mf16_min_tiles() { return rn_get_option(RN_OPT_MF16_MIN); }
 static bool mf16_ok(const rn_conv_desc *d) {
     return mf16_on() && d->w_format == 1 && (d->Cin % 32) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
            (d->Cout % 4) == 0 && !d->in_relu;
@@ -312,7 +306,7 @@ bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, co
     if (!mf16_ok(d) || variant == 1 || variant < 0 || variant > 5) return false;
     if ((variant == 2 || variant == 3) != (d->Cout <= 64)) return false;
     // the 128 x 64 instance measured neutral (3x3 64->64 +3 %, 1x1 256->64 -3 %, conv_igemm_4x1 5.68 -> 5.76 ms per step): opt-in
-    if (d->Cout <= 64 && !(getenv("RN_MF16_NARROW") && atoi(getenv("RN_MF16_NARROW")))) return false;
+    if (d->Cout <= 64 && !rn_get_option(RN_OPT_MF16_NARROW)) return false;
     const int64_t tiles = mf16_tiles(d);
     if (tiles < mf16_min_tiles() || tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles), block(256);

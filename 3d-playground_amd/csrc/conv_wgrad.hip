@@ -646,9 +646,8 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
         } else if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
         else hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, false, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);         \
     } while (0)
-    // RN_WGRAD_ONCE=0: the per-wave split for the 128 x 128 tile too (A/B)
-    const char *once_env = getenv("RN_WGRAD_ONCE");
-    const bool once = split && shape == 2 && (once_env ? atoi(once_env) : 1) != 0 && Hi + pad < 32000 && Wi + pad < 32000;
+    // RN_OPT_WGRAD_ONCE = 0: the per-wave split for the 128 x 128 tile too (A/B)
+    const bool once = split && shape == 2 && rn_get_option(RN_OPT_WGRAD_ONCE) != 0 && Hi + pad < 32000 && Wi + pad < 32000;
     if (once) {
         if (in_relu) hipLaunchKernelGGL((conv_wgrad_once_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_wgrad_once_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -45,20 +45,34 @@ extern "C" int rn_fp32_split_min_k(void) {
     return v;
 }
 
-// Run-time options (include/retinanet_mi355x.h: RN_OPT_*).  -1 = not set yet -> the environment variable, else the default.
-static int g_opt[RN_OPT_COUNT] = {-1, -1};
+// Run-time options (include/retinanet_mi355x.h: RN_OPT_*).  INT_MIN = not set yet -> the environment variable, read ONCE at the first use,
+// else the default.  The launch paths read the cached value (round 4: the per-launch getenv calls of the split kernels' selectors --
+// up to four per convolution launch, ~700 launches per step -- are gone); tests and A/B tools switch with rn_set_option.
+#include <limits.h>
+static int g_opt[RN_OPT_COUNT];
+static bool g_opt_init = false;
+static const struct { const char *env; int dflt, max; } g_opt_def[RN_OPT_COUNT] = {
+    {"RN_SPLITK", 1, 1},        {"RN_DETERMINISTIC", 0, 1},  {"RN_MF16", 1, 1},         {"RN_MF16_MIN", 1, INT_MAX},
+    {"RN_MF16_NARROW", 0, 1},   {"RN_BIG_TILE", 0, 3},       {"RN_BIG_TILE_MIN", 200, INT_MAX}, {"RN_WGRAD_ONCE", 1, 1},
+    {"RN_PERSIST", 1, 1},       {"RN_PERSIST_MAX_K", 640, INT_MAX},
+};
 extern "C" int rn_get_option(int option) {
     if (option < 0 || option >= RN_OPT_COUNT) return -1;
-    if (g_opt[option] < 0) {
-        static const char *const env[RN_OPT_COUNT] = {"RN_SPLITK", "RN_DETERMINISTIC"};
-        static const int dflt[RN_OPT_COUNT] = {1, 0};
-        const char *e = getenv(env[option]);
-        g_opt[option] = e ? (atoi(e) != 0) : dflt[option];
+    if (!g_opt_init) {
+        for (int i = 0; i < RN_OPT_COUNT; ++i) g_opt[i] = INT_MIN;
+        g_opt_init = true;
+    }
+    if (g_opt[option] == INT_MIN) {
+        const char *e = getenv(g_opt_def[option].env);
+        int v = e ? atoi(e) : g_opt_def[option].dflt;
+        if (g_opt_def[option].max == 1) v = v != 0;
+        g_opt[option] = v < 0 ? 0 : (v > g_opt_def[option].max ? g_opt_def[option].max : v);
     }
     return g_opt[option];
 }
 extern "C" int rn_set_option(int option, int value) {
-    if (option < 0 || option >= RN_OPT_COUNT || (value != 0 && value != 1)) return RN_EINVAL;
+    if (option < 0 || option >= RN_OPT_COUNT || value < 0 || value > g_opt_def[option].max) return RN_EINVAL;
+    rn_get_option(option);
     g_opt[option] = value;
     return RN_OK;
 }

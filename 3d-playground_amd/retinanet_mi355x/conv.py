@@ -158,15 +158,18 @@ def _w_operand(w_packed):
     return w_packed.data_ptr(), 0
 
 
-OPT_SPLITK, OPT_DETERMINISTIC = 0, 1             # RN_OPT_* of include/retinanet_mi355x.h
+# RN_OPT_* of include/retinanet_mi355x.h
+OPT_SPLITK, OPT_DETERMINISTIC, OPT_MF16, OPT_MF16_MIN, OPT_MF16_NARROW, OPT_BIG_TILE, OPT_BIG_TILE_MIN, OPT_WGRAD_ONCE, \
+    OPT_PERSIST, OPT_PERSIST_MAX_K = range(10)
 
 
-def set_option(option, on):
-    _hip.check(_hip.load().rn_set_option(option, int(bool(on))), "rn_set_option")
+def set_option(option, value):
+    """Process-wide run-time option of the library (0 / 1 switches take a bool; the tile-count thresholds and RN_OPT_BIG_TILE an int)."""
+    _hip.check(_hip.load().rn_set_option(option, int(value)), "rn_set_option")
 
 
 def get_option(option):
-    return bool(_hip.load().rn_get_option(option))
+    return int(_hip.load().rn_get_option(option))
 
 
 def set_deterministic(on=True):
@@ -263,7 +266,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     reuse = keep_v and V_in is not None and V_in[1] == shapes and V_in[0].numel() == 36 * Tpad * C   # (V, shapes) of the same inputs
     # V_ready: (V, shapes) of exactly these inputs computed a moment ago by wino_wgrad_group(fuse_dgrad_input=True) -- the
     # output gradient's two transforms in one pass -- so this call (the data gradient) starts at the GEMM
-    ready = not keep_v and V_ready is not None and V_ready[1] == shapes and V_ready[0].numel() >= 36 * Tpad * C
+    ready = not keep_v and isinstance(V_ready, tuple) and V_ready[1] == shapes and V_ready[0].numel() >= 36 * Tpad * C
     if ready:
         V, reuse = V_ready[0], True
     elif reuse:
@@ -299,7 +302,8 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
 
 def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_input=False):
     """Weight gradient of a 3x3 / stride 1 / padding 1 convolution over several problems (gs[i] = dY [N,H,W,Cout],
-    xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum."""
+    xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum.
+    Returns None, or with fuse_dgrad_input the (B^T dy B, shapes) pair for wino_conv_group(V_ready=...) of the same layer's data gradient."""
     lib = _hip.load()
     dev = xs[0].device
     C, cout = xs[0].shape[3], gs[0].shape[3]
@@ -336,7 +340,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
         (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0)))
     _hip.check(rc, "rn_conv_wgrad_batched")
     _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
-    return v_dy if fuse_dgrad_input else dw
+    return v_dy                                      # (B^T dy B, shapes) for the data gradient that follows, or None when not fused
 
 
 def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):

@@ -128,7 +128,8 @@ class GradReducer:
         self.pending, self.pending_bytes = [], 0
 
     def finalize(self, grads):
-        """Wait for every bucket and return {name: averaged grad} (views into the flat buckets)."""
+        """Wait for every bucket and return {name: averaged grad} (views into the flat buckets); with defer_scale the gradient
+        SUMS, to be multiplied by ``grad_scale`` by the optimizer -- the same contract as finalize_flat."""
         if self.world == 1:
             return grads
         self._flush()
@@ -136,7 +137,8 @@ class GradReducer:
         inv = 1.0 / self.world
         for work, flat, layout in self.flights:
             work.wait()
-            flat.mul_(inv)
+            if not self.defer_scale:                  # defer_scale: the optimizer applies grad_scale (as after finalize_flat)
+                flat.mul_(inv)
             for name, shape, off, n in layout:
                 out[name] = flat[off:off + n].view(shape)
         self._reset()

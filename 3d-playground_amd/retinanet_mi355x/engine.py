@@ -756,8 +756,11 @@ class Engine:
         """Per-tensor activation scales of the fp8 path from THIS engine's own fp32 / bf16 forward on `frames` ([B,3,H,W],
         representative inputs): the largest magnitude every convolution output (and the pooled stem) takes, times margin.
         -> dict for Engine(dtype="fp8").fp8_scales.  One host read per layer: a set-up call, not a hot path."""
-        assert not self.fp8, "calibrate with the fp32 (or bf16) engine, then hand the result to the fp8 engine"
+        if self.fp8 or self.bf16:
+            raise RuntimeError("calibrate with the fp32 engine (ResNet.calibrate_fp8 switches to it): the magnitudes are recorded "
+                               "by the fp32 direct kernels' path only")
         rec = {}
+        wino_eval, self.wino_eval = self.wino_eval, False      # the Winograd branches return before the tap: direct kernels here
         for L in self.layers.values():
             L.calib = rec
         self.calib = rec
@@ -768,7 +771,15 @@ class Engine:
             for L in self.layers.values():
                 L.calib = None
             self.calib = None
+            self.wino_eval = wino_eval
+        missing = [n for n in self.fp8_scale_names() if n not in rec]
+        assert not missing, "calibration pass did not record %s" % missing
         return {k: v * margin for k, v in rec.items()}
+
+    def fp8_scale_names(self):
+        """Names the fp8 forward needs an activation scale for: the pooled stem and every convolution whose output is stored as
+        e4m3 (all but the fp32 stem and the fp32 head outputs)."""
+        return ["pool"] + [n for n in self.layers if n != "conv1" and not n.endswith(".output")]
 
     # ------------------------------------------------------------------------------------------- forward
     def forward(self, P, img, save, x4=None):
@@ -784,6 +795,10 @@ class Engine:
                 raise RuntimeError("the fp8 engine is inference-only (no backward pass): train in fp32 / bf16")
             if not self.fp8_scales:
                 raise RuntimeError("the fp8 engine needs activation scales: net.calibrate_fp8(frames) first")
+            missing = [n_ for n_ in self.fp8_scale_names() if not self.fp8_scales.get(n_, 0.0) > 0.0]
+            if missing:                                     # a scale of 0 would saturate every activation to +-448: finite garbage
+                raise RuntimeError("fp8 activation scales are missing (or zero) for %d tensors, e.g. %s: run net.calibrate_fp8(frames) "
+                                   "on representative frames" % (len(missing), ", ".join(missing[:4])))
             for n_, L in Ls.items():
                 L.out_scale = max(self.fp8_scales.get(n_, 0.0), 1e-30) / cv.FP8_MAX
             # the five pyramid maps share ONE scale, so that the towers' first layer takes them in one grouped launch

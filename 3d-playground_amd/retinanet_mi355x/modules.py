@@ -272,18 +272,19 @@ class ResNet(nn.Module):
         ~1e-2 relative differences in losses and gradients (tests/test_gpu_model_bf16.py)."""
         old = self._engine
         eng = engine.Engine(self._arch_name, old.num_classes, old.n_reg, dtype=dtype)
-        eng.set_flat_grads(old.flat_bucket_bytes)
+        eng.set_flat_grads(old.flat_bucket_bytes, old.flat_tail_bytes)    # the attached reducer's bucket layout, tail included
         eng.bucket_hook = old.bucket_hook
         eng.fp8_scales = getattr(old, "fp8_scales", None)
         self.__dict__["_engine"] = eng
         return self
 
     def calibrate_fp8(self, frames, margin=1.0):
-        """BASELINE configs[4], first cut: run the CURRENT (fp32 or bf16) engine on representative frames [B,3,H,W], record the
-        magnitude of every activation tensor, and switch the model to the fp8 inference engine with those per-tensor scales
-        (e4m3 activations and per-output-channel-scaled e4m3 weights on the fp8 MFMA; csrc/conv_fp8.hip).  Inference only:
-        ``net.train()`` forwards raise.  ``set_compute_dtype("fp32")`` switches back (the scales are kept)."""
-        if self._engine.fp8:
+        """BASELINE configs[4]: run the fp32 engine (direct kernels; whatever engine the model is on now, bf16 included, the
+        calibration pass switches to it) on representative frames [B,3,H,W], record the magnitude of every activation tensor,
+        and switch the model to the fp8 inference engine with those per-tensor scales (e4m3 activations and
+        per-output-channel-scaled e4m3 weights on the fp8 MFMA; csrc/conv_fp8.hip).  Inference only: ``net.train()`` forwards
+        raise.  ``set_compute_dtype("fp32")`` switches back (the scales are kept)."""
+        if self._engine.fp8 or self._engine.bf16:
             self.set_compute_dtype("fp32")
         scales = self._engine.calibrate(self._tensor_dict(), frames, margin)
         self.set_compute_dtype("fp8")
@@ -304,6 +305,24 @@ class ResNet(nn.Module):
             "this drop-in does not run under torch.nn.DataParallel: its HIP engine keeps per-device state and would be "
             "shared by the replica threads.  Use one process per GPU instead: retinanet_mi355x.ddp.init_from_env() + "
             "net.set_gradient_reducer(ddp.GradReducer()) (see INTEGRATION.md, 'Multi-GPU').")
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        """nn.Module.load_state_dict, also for the checkpoints the reference's multi-GPU trainer writes: it saves
+        ``nn.DataParallel(model).state_dict()`` (train_detector_3D_angle.py:416-417), whose every key carries a ``module.``
+        prefix, and strips that prefix itself before loading (``to_cpu``, train_detector_3D_angle.py:39-59).  A dict in which
+        EVERY key has the prefix is taken as such a checkpoint and loaded without it; anything else goes through unchanged, so
+        ``strict`` keeps its meaning (a half-prefixed dict still reports its unexpected / missing keys)."""
+        keys = list(state_dict.keys())
+        if keys and all(k.startswith("module.") for k in keys):
+            stripped = type(state_dict)()                  # keeps an OrderedDict an OrderedDict
+            for k in keys:
+                stripped[k[len("module."):]] = state_dict[k]
+            meta = getattr(state_dict, "_metadata", None)
+            if meta is not None:                           # per-module version records, keyed "module.<path>" / "module"
+                stripped._metadata = type(meta)((k[len("module."):] if k.startswith("module.") else ("" if k == "module" else k), v)
+                                                for k, v in meta.items())
+            state_dict = stripped
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     def _tensor_dict(self):
         d = dict(self.named_parameters())

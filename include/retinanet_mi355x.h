@@ -276,18 +276,37 @@ typedef struct rn_conv_desc {
 #define RN_FP32_DEFAULT RN_FP32_SPLIT
 int rn_get_fp32_mfma(void);
 int rn_set_fp32_mfma(int mode);
-/* Process-wide run-time options (0 / 1); initial value from the environment variable named, else the default.
- *   RN_OPT_SPLITK         (RN_SPLITK, default 1)  rn_conv_splitk_workspace_bytes may choose the split-K form.  Off, a
+/* Process-wide run-time options; initial value from the environment variable named (read ONCE, at the option's first use --
+ * never on a launch path), else the default.  rn_set_option returns RN_EINVAL for a value outside the option's range.
+ *   RN_OPT_SPLITK         (RN_SPLITK, 0/1, default 1)  rn_conv_splitk_workspace_bytes may choose the split-K form.  Off, a
  *                         convolution's result does not depend on how many images share the launch: every output element
  *                         is one K loop in a fixed order (the batch-invariance the batch-8 parity test relies on).
- *   RN_OPT_DETERMINISTIC  (RN_DETERMINISTIC, default 0)  weight gradients are reduced in a fixed order: every K slice of
+ *   RN_OPT_DETERMINISTIC  (RN_DETERMINISTIC, 0/1, default 0)  weight gradients are reduced in a fixed order: every K slice of
  *                         rn_conv_wgrad* stores its partial tile in a slab of the workspace and an ordered pass adds the
  *                         slabs (and the column sums) -- two runs give bit-identical gradients, as the reference's CPU path
  *                         does; costs the slab traffic (rn_conv_wgrad_det_workspace_bytes).  Off: fp32 atomics, fastest,
- *                         last bits depend on arrival order. */
+ *                         last bits depend on arrival order.
+ * Kernel selectors of the split-operand family (A/B switches; the defaults are the measured best):
+ *   RN_OPT_MF16           (RN_MF16, 0/1, default 1)  wide layers with Cin % 32 == 0 take csrc/conv_igemm_mf16.hip (16x16x32 MFMA).
+ *   RN_OPT_MF16_MIN       (RN_MF16_MIN, >= 0, default 1)  fewest tiles a launch needs to take it.
+ *   RN_OPT_MF16_NARROW    (RN_MF16_NARROW, 0/1, default 0)  its 128 x 64 instance for layers with at most 64 output channels.
+ *   RN_OPT_BIG_TILE       (RN_BIG_TILE, 0..3, default 0)  256 x 256 tile variants (csrc/conv_igemm_big.hip).
+ *   RN_OPT_BIG_TILE_MIN   (RN_BIG_TILE_MIN, >= 0, default 200)  fewest 256 x 256 tiles a launch needs to take them.
+ *   RN_OPT_WGRAD_ONCE     (RN_WGRAD_ONCE, 0/1, default 1)  weight gradient's 128 x 128 tile splits its operands once per workgroup.
+ *   RN_OPT_PERSIST        (RN_PERSIST, 0/1, default 1)  short-reduction launches of conv_igemm_mf16.hip run as persistent workgroups
+ *                         that issue tile n+1's first loads before tile n's stores (csrc/conv_igemm_mf16.hip).
+ *   RN_OPT_PERSIST_MAX_K  (RN_PERSIST_MAX_K, >= 0, default 640)  longest reduction kh*kw*Cin that takes the persistent form. */
 #define RN_OPT_SPLITK 0
 #define RN_OPT_DETERMINISTIC 1
-#define RN_OPT_COUNT 2
+#define RN_OPT_MF16 2
+#define RN_OPT_MF16_MIN 3
+#define RN_OPT_MF16_NARROW 4
+#define RN_OPT_BIG_TILE 5
+#define RN_OPT_BIG_TILE_MIN 6
+#define RN_OPT_WGRAD_ONCE 7
+#define RN_OPT_PERSIST 8
+#define RN_OPT_PERSIST_MAX_K 9
+#define RN_OPT_COUNT 10
 int rn_get_option(int option);
 int rn_set_option(int option, int value);
 /* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (64; environment RN_FP32_SPLIT_MIN_K);

@@ -63,6 +63,11 @@ def _worker(rank, world, port, out):
     red2.bucket_ready(0, arena[0:100])
     red2.finalize_flat(arena)
     ok &= torch.allclose(arena, torch.arange(100, dtype=torch.float32) * sum(range(1, world + 1))) and red2.grad_scale == 1.0 / world
+    # ... and the generic path keeps the same contract: finalize() returns SUMS, grad_scale times them is the mean (not 1/world^2)
+    gsum = {"w": torch.full((10,), float(rank + 1))}
+    red2.hook(gsum)
+    summed = red2.finalize(gsum)
+    ok &= torch.allclose(summed["w"] * red2.grad_scale, torch.full((10,), sum(range(1, world + 1)) / world))
     # loss scalars for logging / ReduceLROnPlateau (train_detector_3D_angle.py:374-381, 338, 412): one 3-float all-reduce; both
     # ranks step their scheduler with the SAME number and end up with the same learning rate, which rank-local losses do not
     local = [torch.tensor([1.0 + rank]), torch.tensor([0.5 * (1 + rank)]), torch.tensor([3.0 - rank])]

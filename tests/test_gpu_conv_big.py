@@ -13,32 +13,34 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-ENV = ("RN_BIG_TILE_MIN", "RN_BIG_TILE", "RN_MF16", "RN_MF16_MIN", "RN_MF16_NARROW")
+OPTS = ("OPT_BIG_TILE_MIN", "OPT_BIG_TILE", "OPT_MF16", "OPT_MF16_MIN", "OPT_MF16_NARROW", "OPT_PERSIST")
 
 
-@pytest.fixture(scope="module", params=["1", "2", "3", "mf16"])
+def _set(cv, opts):
+    for k, v in opts.items():
+        cv.set_option(getattr(cv, k), v)
+
+
+@pytest.fixture(scope="module", params=["1", "2", "3", "mf16", "mf16p"])
 def cv(dev, request):
-    """RN_BIG_TILE=1: four waves of 128 x 128; =2: eight waves (two per SIMD) of 128 x 64; =3: the same with three LDS buffers and
-    counted waits (loads in flight across the barrier).  mf16: csrc/conv_igemm_mf16.hip -- 128 x 256 tiles on
-    v_mfma_f32_16x16x32_bf16, the product default for layers with more than 128 output channels, here forced onto small shapes
-    (RN_MF16_MIN=1) and compared with the 128 x 128 kernels (RN_MF16=0)."""
+    """RN_OPT_BIG_TILE=1: four waves of 128 x 128; =2: eight waves (two per SIMD) of 128 x 64; =3: the same with three LDS buffers and
+    counted waits (loads in flight across the barrier).  mf16: csrc/conv_igemm_mf16.hip -- 128 x 128 tiles on
+    v_mfma_f32_16x16x32_bf16, the product default for wide layers, here forced onto small shapes (RN_OPT_MF16_MIN=1) and compared
+    with the 32x32x16 kernels (RN_OPT_MF16=0); mf16p: the same with its persistent-workgroup form for short reductions on
+    (RN_OPT_PERSIST: a workgroup walks several tiles and requests tile n+1's first operands before tile n's stores)."""
     from retinanet_mi355x import conv
-    before = (conv.get_fp32_mfma(), conv.PRESPLIT) + tuple(os.environ.get(k) for k in ENV)
+    before = (conv.get_fp32_mfma(), conv.PRESPLIT) + tuple(conv.get_option(getattr(conv, k)) for k in OPTS)
     conv.set_fp32_mfma("split")
     conv.PRESPLIT = True
-    if request.param == "mf16":
-        conv._big_on = {"RN_BIG_TILE": "0", "RN_MF16": "1", "RN_MF16_MIN": "1", "RN_MF16_NARROW": "1"}
+    if request.param in ("mf16", "mf16p"):
+        conv._big_on = {"OPT_BIG_TILE": 0, "OPT_MF16": 1, "OPT_MF16_MIN": 1, "OPT_MF16_NARROW": 1, "OPT_PERSIST": int(request.param == "mf16p")}
     else:
-        conv._big_on = {"RN_BIG_TILE": request.param, "RN_BIG_TILE_MIN": "1", "RN_MF16": "0"}
-    os.environ.update(conv._big_on)
+        conv._big_on = {"OPT_BIG_TILE": int(request.param), "OPT_BIG_TILE_MIN": 1, "OPT_MF16": 0}
+    _set(conv, conv._big_on)
     yield conv
     conv.set_fp32_mfma(before[0])
     conv.PRESPLIT = before[1]
-    for key, val in zip(ENV, before[2:]):
-        if val is None:
-            os.environ.pop(key, None)
-        else:
-            os.environ[key] = val
+    _set(conv, dict(zip(OPTS, before[2:])))
 
 
 def rnd(shape, seed, std=1.0):
@@ -60,11 +62,11 @@ def close(got, want, tol=1e-5):
 def _both_kernels(cv, fn):
     """fn() with the big tile on, then off: the two kernels must agree with each other too (same products, other order)."""
     a = fn()
-    os.environ.update({"RN_BIG_TILE": "0", "RN_MF16": "0"})
+    _set(cv, {"OPT_BIG_TILE": 0, "OPT_MF16": 0})
     try:
         b = fn()
     finally:
-        os.environ.update(cv._big_on)
+        _set(cv, cv._big_on)
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     return a
 

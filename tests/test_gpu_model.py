@@ -37,7 +37,8 @@ pytestmark = pytest.mark.gpu
 GRAD_L2 = {"direct": 3e-5, "wino": 5e-5}             # tight: ~10x measured, >= FLIP_FREE of the tensors
 GRAD_L2_FLIP, GRAD_MAX = 2e-3, 5e-3                   # loose: a flipped ReLU mask upstream (see above), every tensor
 NORM_TOL = {"direct": 2e-5, "wino": 2e-4}
-CFG2_L2 = {"head": 1e-4, "backbone": 5e-3}            # measured 1.1e-5 / 6.1e-4
+CFG2_L2 = {"head": 1e-4, "backbone": 2e-3}            # measured 1.1e-5 / 6.1e-4 .. 7.7e-4 (round 4: backbone 5e-3 -> 2e-3, and only
+                                                      # inside the backward cone of a LOCATED sign flip: test_cfg2_full_size_against_oracle)
 STATS = {}
 
 
@@ -294,12 +295,13 @@ def test_training_step_changes_loss(dev):
 
 def test_training_trajectories_agree_between_product_modes(dev):
     """Twelve optimizer steps (clip 0.1 + Adam 1e-4, the reference trainer's recipe) from the same weights, twice with the fp32
-    products on the fp32 MFMA and once as split operands on the bf16 MFMA.  The first steps agree to fp32 rounding in every
-    pair (a reduced-precision product -- bf16 -- differs at 1e-3 in the FIRST loss); later ones drift apart the way two runs
-    of the SAME mode do (Adam divides by the gradient's own magnitude, and the weight gradients' atomic accumulation order differs
-    from run to run): the split run must stay within a small multiple of that run-to-run spread."""
+    products on the fp32 MFMA and once as split operands on the bf16 MFMA -- in FIXED-ORDER mode (conv.set_deterministic: the
+    weight gradients' reduction order no longer depends on arrival), so that two runs of one mode are bit-identical and whatever
+    separates the modes is the products' rounding alone, amplified by twelve Adam steps (round 3 ran this with the atomics on and
+    had to allow 2e-2 for their run-to-run drift, which hid a systematic difference of that size).  A reduced-precision product --
+    bf16 -- differs at 1e-3 in the FIRST loss."""
     from retinanet_mi355x import conv, optim
-    before = conv.get_fp32_mfma()
+    before = conv.get_fp32_mfma(), conv.get_option(conv.OPT_DETERMINISTIC)
 
     def run(mode):
         conv.set_fp32_mfma(mode)
@@ -315,20 +317,24 @@ def test_training_trajectories_agree_between_product_modes(dev):
             opt.step()
             seq.append(float(loss.detach()))
         return np.array(seq)
+    conv.set_deterministic(True)
     try:
         n1, n2, sp = run("native"), run("native"), run("split")
     finally:
-        conv.set_fp32_mfma(before)
+        conv.set_fp32_mfma(before[0])
+        conv.set_deterministic(before[1])
     assert n1[-1] < n1[0]
     rel = lambda a, b: np.abs(a - b) / np.abs(a)
-    same, cross = rel(n1, n2), np.minimum(rel(n1, sp), rel(n2, sp))
-    # measured: native vs native 0, 5e-7, 1e-7, 0, 1e-6, 5e-6, 2e-5, 9e-5, 3e-4, 9e-4, 1e-3, 8e-3;
-    #           split vs native  2e-7, 0, 2e-7, 2e-6, 1e-4, 3e-4, 1e-4, 9e-5, 1e-4, 1e-4, 3e-3, 4e-3
+    same, cross = rel(n1, n2), rel(n1, sp)
+    print("trajectory, fixed order: same-mode drift", same.max(), "| split vs native", cross)
+    STATS["trajectory_fixed_order"] = {"same_mode": same.tolist(), "split_vs_native": cross.tolist()}
+    _dump()
+    assert same.max() == 0.0, same                                          # fixed order: the same bits, step after step
     assert cross[:3].max() <= 1e-5, cross                                   # fp32 rounding while the dynamics have not amplified it
-    # ... and later never further apart than two runs of ONE mode get: their drift (atomics order) has been measured from 5e-7 (a run
-    # where both orders happened to agree; the split run was 6.1e-3 off by step 12 then) to 8e-3, so the bound cannot lean on this
-    # run's `same` alone
-    assert cross.max() <= 5 * same.max() + 2e-2, (same, cross)
+    assert cross.max() <= TRAJ_CROSS, cross
+
+
+TRAJ_CROSS = 5e-3     # split vs native after 12 steps at fixed order
 
 
 def test_fused_clip_adam_matches_torch(dev):
@@ -621,31 +627,46 @@ def test_cfg2_full_size_against_oracle(dev, mode, mfma):
     assert np.allclose(got, o["losses"], rtol=1e-4), (got, o["losses"])
     sum(l.mean() for l in losses).backward()
     assert len(CFG2_PARAMS) >= 30
+    test = "cfg2_full_%s_%s" % (mode, mfma)
     named = dict(net.named_parameters())
-    for name in CFG2_PARAMS:
-        group = "head" if name.startswith(("fpn.", "regressionModel.", "classificationModel.")) else "backbone"
-        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, "cfg2_full_%s_%s" % (mode, mfma),
-                   l2_tol=CFG2_L2[group], max_tol=2 * GRAD_MAX)
+    errs = {}
+    for name in CFG2_PARAMS:                                   # measured first, judged below (once the flips are located)
+        grad_close(named[name].grad.cpu().numpy(), o["grads"][name].numpy(), name, test, l2_tol=np.inf, max_tol=np.inf)
+        errs[name] = STATS[test]["all"][name]
     for name, p in named.items():                              # and every other gradient by its norm
         want = float(o["grads"][name].double().norm())
         assert abs(float(p.grad.double().norm()) - want) <= 2e-3 * want + 1e-12, name
     for p in net.parameters():
         p.grad = None
-    # The backbone's 1e-4 .. 8e-4 above is attributed to ReLU outputs within rounding of zero that land on the other side than in
-    # the CPU run.  Count them AT THIS SIZE: every ReLU output of this run against the oracle's, element by element.
+    # The backbone's 1e-4 .. 8e-4 is attributed to ReLU outputs within rounding of zero that land on the other side than in the CPU
+    # run.  LOCATE them at this size -- every ReLU output of this run against the oracle's, element by element -- and apply the rule
+    # of the small tests (round 4): only the parameters inside the backward cone of a located flip (Engine.backward_cone) may use the
+    # bound a flip can reach (CFG2_L2["backbone"], 2.6x the measured worst); EVERY tensor outside the cones must meet the tight one.
     with torch.no_grad():
         S = net._engine.forward(net._tensor_dict(), img, save=True)[2]
-    total, flips, by_group = 0, 0, {}
+    total, flips, by_group, cone = 0, 0, {}, set()
     for aname, t in net._engine.relu_outputs(S).items():
         n = int(((t > 0).permute(0, 3, 1, 2).cpu() != o["signs"][aname]).sum())
         total += t.numel()
         flips += n
+        if n:
+            cone.update(net._engine.backward_cone(aname))
         grp = aname.split(".")[0] if aname.startswith("layer") else ("heads" if "Model" in aname else aname.split("@")[0])
         by_group[grp] = by_group.get(grp, 0) + n
     del S
-    STATS["cfg2_full_%s_%s" % (mode, mfma)].update(relu_outputs=total, sign_flips=flips, sign_flips_by_group=by_group)
+    outside = [n for n in errs if n not in cone]
+    STATS[test].update(relu_outputs=total, sign_flips=flips, sign_flips_by_group=by_group, params_outside_every_cone=outside)
     _dump()
     assert 0 < total and flips <= 2e-5 * total, (flips, total, by_group)      # measured: a few hundred among 1.4e8
+    if not MEASURE_ONLY:
+        for name, (l2, mx) in errs.items():
+            tol = CFG2_L2["backbone"] if name in cone else CFG2_L2["head"]
+            assert l2 <= tol and mx <= 2 * GRAD_MAX, "%s [%s]: L2-rel %.3e, max-rel %.3e (%s the cone of a located flip: %s)" % (
+                name, test, l2, mx, "inside" if name in cone else "OUTSIDE", by_group)
+        # the heads and the pyramid see few flips and short cones: whatever the cone rule allows them, they stay at their measured level
+        for name, (l2, mx) in errs.items():
+            if name.startswith(("fpn.", "regressionModel.", "classificationModel.")):
+                assert l2 <= CFG2_L2["head"], (name, l2)
     net.eval()
     boxes, cls = net(img, LOCALIZE=True)
     rel_close(cls.cpu().numpy(), o["cls"].numpy(), 1e-4)

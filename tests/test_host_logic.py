@@ -118,3 +118,32 @@ def test_custom_operators_are_registered_and_have_no_cpu_kernel():
         l, ws = torch.ops.retinanet_mi355x.focal_loss_fwd(torch.empty(2, 100, 8, device="cuda"), torch.empty(2, 100, 12, device="cuda"),
                                                           torch.empty(1, 100, 4, device="cuda"), torch.empty(2, 5, 27, device="cuda"), True)
         assert tuple(l.shape) == (3,) and ws.dtype == torch.uint8
+
+
+def test_data_parallel_checkpoint_keys_load_without_their_prefix():
+    """train_detector_3D_angle.py:416-417 saves nn.DataParallel(model).state_dict(): every key is 'module.<name>', and the
+    reference strips the prefix before loading (to_cpu, :39-59).  The drop-in's load_state_dict takes such a dict as it is;
+    a dict in which only SOME keys carry the prefix is not one and keeps strict's errors."""
+    import collections
+    from retinanet_mi355x import modules
+    net = modules.resnet18(num_classes=3)
+    sd = net.state_dict()
+    dp = collections.OrderedDict(("module." + k, (v.float() + 1).to(v.dtype)) for k, v in sd.items())
+    dp._metadata = collections.OrderedDict((("module." + k) if k else "module", v) for k, v in sd._metadata.items())
+    res = net.load_state_dict(dp)
+    assert not res.missing_keys and not res.unexpected_keys
+    now = net.state_dict()
+    assert list(now) == list(sd) and all(torch.equal(now[k], dp["module." + k]) for k in sd)
+    # round trip: what a DataParallel wrapper of THIS model would save loads back into a fresh model
+    wrapped = collections.OrderedDict(("module." + k, v) for k, v in now.items())
+    other = modules.resnet18(num_classes=3)
+    other.load_state_dict(wrapped)
+    assert all(torch.equal(other.state_dict()[k], now[k]) for k in now)
+    half = collections.OrderedDict(dp)
+    half["conv1.weight"] = sd["conv1.weight"]
+    with pytest.raises(RuntimeError, match="Missing key|Unexpected key"):
+        net.load_state_dict(half)
+    # strict=False still filters by name only after the prefix is gone (ImageNet backbone into a detector)
+    part = collections.OrderedDict((k, v) for k, v in dp.items() if k.startswith("module.layer1."))
+    res = net.load_state_dict(part, strict=False)
+    assert not res.unexpected_keys and res.missing_keys
