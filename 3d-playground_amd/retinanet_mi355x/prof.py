@@ -41,3 +41,21 @@ def timed(kind, work, fn, nbytes=0.0):
     if ACTIVE is None:
         return fn()
     return ACTIVE.launch(kind, work, fn, nbytes)
+
+
+def sources_digest():
+    """sha256 over the kernel sources and the launch schedule (csrc/*.hip, csrc/*.h, include/*.h, engine.py, conv.py): what a
+    committed PMC collection (profiles/pmc_traffic.json) is stamped with, and what bench.py compares it against before it quotes
+    that collection's bytes beside THIS run's times (there is no git on the GPU box to ask for a commit)."""
+    import glob
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.dirname(here))
+    files = sorted(glob.glob(os.path.join(here, "..", "csrc", "*.hip")) + glob.glob(os.path.join(here, "..", "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "include", "*.h")) + [os.path.join(here, "engine.py"), os.path.join(here, "conv.py")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()

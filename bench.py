@@ -60,9 +60,15 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp8"],
                     help="fp32 = the reference's arithmetic = the headline (BASELINE configs[1]); bf16 = configs[2]'s storage "
-                         "format (bf16 activations / MFMA, fp32 accumulation and master weights), reported with dtype bf16")
+                         "format (bf16 activations / MFMA, fp32 accumulation and master weights), reported with dtype bf16; "
+                         "fp8 = configs[4]'s arithmetic (e4m3 activations / weights), INFERENCE forward only: a different metric "
+                         "(forward images/sec), e.g. --arch resnet101 --dtype fp8 --batch 16")
+    ap.add_argument("--sections", default="all", choices=["all", "headline"],
+                    help="headline: ONLY the benchmark's own steps (warm-up, timed steps, the same steps with per-kernel events) -- no "
+                         "native-MFMA / bf16 / fp8 sections, no forward-only passes, no loss micro-benchmark -- so that a rocprofv3 "
+                         "--kernel-trace --stats of this command divides by (warmup + 2 * steps) into the line's kernels.*.ms_per_step")
     ap.add_argument("--fp32-mfma", default="", choices=["", "split", "native"],
                     help="how the fp32 convolution kernels form their products (include/retinanet_mi355x.h: RN_FP32_SPLIT / "
                          "RN_FP32_NATIVE); default: the library's (RN_FP32_DEFAULT, or the environment's RN_FP32_MFMA)")
@@ -240,8 +246,21 @@ def fp8_section(dev, args, B, H, W):
                      "peak": PEAK_FP8_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP8_MFMA_TF, 4), "ms": round(ms, 4),
                      "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes}
         del x, xq, wq, y
-    net = getattr(modules, args.arch)(num_classes=8)
-    net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))
+    out["forward_pass"] = fp8_forward(dev, args.arch, B, H, W, with_fp32=True)
+    try:                                       # BASELINE configs[4] at its own size: ResNet-101, 1920x1080, batch 16 per GPU
+        torch.cuda.empty_cache()
+        out["forward_pass_resnet101_b16"] = fp8_forward(dev, "resnet101", 16, H, W, with_fp32=False)
+    except Exception as e:
+        out["forward_pass_resnet101_b16"] = {"error": str(e)[:300]}
+    return out
+
+
+def fp8_forward(dev, arch, B, H, W, with_fp32, iters=3):
+    """The detector's forward pass (eval: backbone + FPN + heads, no post-process) with e4m3 activations / weights, activation
+    scales calibrated on two of the benchmark's frames; with_fp32: the same pass in fp32 first, for the ratio."""
+    from retinanet_mi355x import modules, synth
+    net = getattr(modules, arch)(num_classes=8)
+    net.load_state_dict(synth.state_dict(arch, 8, 12, seed=2))
     net = net.to(dev).eval()
     img = frames(B, H, W, 0, dev)
     P = net._tensor_dict()
@@ -249,14 +268,79 @@ def fp8_section(dev, args, B, H, W):
     def fwd():
         with torch.no_grad():
             net._engine.forward(P, img, save=False)
-    ms32 = timeit(fwd, 3)
+
+    def timeit(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    ms32 = timeit(fwd, iters) if with_fp32 else None
     net.calibrate_fp8(img[:2])
-    ms8 = timeit(fwd, 3)
-    out["forward_pass"] = {"value": round(B / (ms8 * 1e-3), 1), "unit": "images/sec", "ms_per_pass": round(ms8, 2), "dtype": "fp8 (e4m3fn)",
-                           "fp32_ms_per_pass": round(ms32, 2), "speedup_over_fp32_forward": round(ms32 / ms8, 2),
-                           "note": "forward only (backbone + FPN + heads, no post-process), fp32 stem and head outputs; one launch per "
-                                   "pyramid level in the heads (no grouped fp8 launch yet); not the reference's arithmetic, not the headline"}
-    return out
+    P = net._tensor_dict()
+    ms8 = timeit(fwd, iters)
+    res = {"value": round(B / (ms8 * 1e-3), 1), "unit": "images/sec", "ms_per_pass": round(ms8, 2), "dtype": "fp8 (e4m3fn)",
+           "arch": arch, "batch": B,
+           "note": "forward only (backbone + FPN + heads, no post-process), fp32 stem and head outputs; the five pyramid levels of a "
+                   "head layer in one grouped fp8 launch; not the reference's arithmetic, not the headline"}
+    if ms32 is not None:
+        res.update(fp32_ms_per_pass=round(ms32, 2), speedup_over_fp32_forward=round(ms32 / ms8, 2))
+    return res
+
+
+def fp8_main(args, dev, rank, world):
+    """`--dtype fp8`: BASELINE configs[4]'s per-GPU leg -- the INFERENCE forward pass with e4m3 activations / weights (the fp8 engine
+    has no backward).  A different metric from the headline: forward images/sec; one step = one forward pass of one batch.  N > 1:
+    every rank runs its own batch (replicas, no collective in the data path)."""
+    from retinanet_mi355x import modules, synth
+    B, H, W = args.batch, args.height, args.width
+    net = getattr(modules, args.arch)(num_classes=8)
+    net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))
+    net = net.to(dev).eval()
+    img = frames(B, H, W, 0 + rank, dev)
+    net.calibrate_fp8(img[:2])
+    P = net._tensor_dict()
+
+    def step():
+        with torch.no_grad():
+            return net._engine.forward(P, img, save=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        reg, cls, _ = step()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        line = {"metric": "inference forward images/sec at %dx%d, %s 3D-RetinaNet, fp8" % (W, H, args.arch),
+                "value": round(world * B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "fp8 (e4m3fn activations and weights, fp32 accumulation)", "data": "synthetic",
+                "config": {"workload": "%s directional 3D-RetinaNet, %dx%d synthetic frames, batch %d per GPU, forward pass only "
+                                       "(backbone + FPN + heads), fp32 stem and head outputs (BASELINE configs[4])" % (args.arch, W, H, B),
+                           "global_batch": world * B, "parallelism": "replicas x%d" % world,
+                           "finite_outputs": bool(torch.isfinite(cls).all() and torch.isfinite(reg).all())},
+                "backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
+                "note": "NOT the headline metric (training images/sec, fp32): the fp8 engine is inference-only"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def native_section(dev, args, B, H, W):
@@ -337,18 +421,40 @@ def pmc_traffic(kind):
               "wino_input": ("wino_in_kernel", "wino_in_both_kernel", "wino_dy_kernel"),
               "wino_output": ("wino_out_kernel",)}.get(kind)
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if prefix is None or not os.path.exists(path):
+    if prefix is None or not os.path.exists(path) or not traffic_source()["matches_current_sources"]:
         return None
     rows = [v for k, v in json.load(open(path)).items() if k.startswith(prefix)]
     n = sum(v["launches"] for v in rows)
     return int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n) if n else None
 
 
+_TRAFFIC_SOURCE = {}
+
+
+def traffic_source():
+    """Where `traffic` comes from: PMC counters cannot be read inside the process, so the bytes are those of the last committed
+    collection (tools/collect_traffic.sh) -- quoted ONLY when that collection was made on the same kernel sources and launch
+    schedule as this run (prof.sources_digest; no git on the GPU box), otherwise traffic is null."""
+    if not _TRAFFIC_SOURCE:
+        from retinanet_mi355x import prof
+        path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        meta = json.load(open(path)).get("_meta", {}) if os.path.exists(path) else {}
+        now = prof.sources_digest()
+        _TRAFFIC_SOURCE.update({"file": "profiles/pmc_traffic.json", "collected": meta.get("collected"),
+                                "sources_sha256": meta.get("sources_sha256"), "this_run_sources_sha256": now,
+                                "matches_current_sources": bool(meta) and meta.get("sources_sha256") == now,
+                                "note": "HBM bytes per launch from two separate rocprofv3 --pmc passes of this command (FETCH_SIZE "
+                                        "doubled per the gfx950 correction), collected earlier on the sources named; null when they "
+                                        "differ from this run's"})
+    return _TRAFFIC_SOURCE
+
+
 def cpu_baseline(arch, H, W):
     """oracle/ (torch CPU kernels, reference algorithm) on this box's host cores, a bounded sample of the workload:
     the whole model (forward + loss + backward on ONE image, all cores) = `value`, plus the path's components one by one at
     the benchmark's own sizes, with all cores and with one thread: anchors, the fused loss forward and
-    forward + backward (B = 2), box decode (B = 2), the MULTI_FRAME post-process, the homography round trip."""
+    forward + backward, box decode and the MULTI_FRAME post-process at the benchmark's batch (B = 8), the
+    homography round trip."""
     import numpy as np
     from oracle import anchors as oanchors, boxes as oboxes, homography as ohg, losses as olosses, model as omodel
     from retinanet_mi355x import synth
@@ -366,7 +472,7 @@ def cpu_baseline(arch, H, W):
            "sample": "1 image %dx%d, %s forward+loss+backward, torch CPU fp32 (%.1f s)" % (W, H, arch, dt)}
     del params, losses
     # ---- components (seconds per call; [all cores, 1 thread])
-    Bc = 2
+    Bc = 8
     anc = torch.from_numpy(oanchors.anchors_for_image(H, W))
     A = anc.shape[1]
     cls, reg = synth.head_outputs(1, A, 8, 12, seed=3)
@@ -443,6 +549,8 @@ def main():
     torch.cuda.set_device(dev)
     B, H, W = args.batch, args.height, args.width
     from retinanet_mi355x import conv as cv
+    if args.dtype == "fp8":
+        return fp8_main(args, dev, rank, world)
     if args.fp32_mfma:
         cv.set_fp32_mfma(args.fp32_mfma)
     fp32_mode = cv.get_fp32_mfma()
@@ -532,6 +640,21 @@ def main():
         dt = float(t)
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
+    # The library's DEFAULT mode checks the labels eagerly (one host read per step, as the reference's FocalLoss raises inside the
+    # forward); the loop above defers that check (RN_DEFERRED_LABEL_CHECK, set in main).  The same K steps in the default mode:
+    eager = None
+    if world == 1 and args.sections == "all" and not (args.graph and graph_note and "replayed" in graph_note):
+        os.environ["RN_EAGER_LABEL_CHECK"] = "1"
+        try:
+            step()
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            eager = B * args.steps / (time.time() - t1)
+        finally:
+            del os.environ["RN_EAGER_LABEL_CHECK"]
 
     if rank == 0:
         arch_label = {"resnet50": "ResNet-50", "resnet101": "ResNet-101", "resnet152": "ResNet-152", "resnet18": "ResNet-18",
@@ -545,7 +668,14 @@ def main():
                                        % (args.arch, W, H, B, "fp32" if args.dtype == "fp32" else
                                           "bf16 activations / MFMA with fp32 accumulation and master weights",
                                           1 if args.dtype == "fp32" else 2),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)}}
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 5)},
+                # what the process group actually is: an 8-GPU line with backend "nccl" (= RCCL on ROCm) and ranks 8 is an RCCL run
+                "backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1}
+        if eager is not None:
+            line["value_eager_label_check"] = round(eager, 3)
+            line["label_check"] = ("value: all-empty-batch check deferred by one call (RN_DEFERRED_LABEL_CHECK=1, no host read per step); "
+                                   "value_eager_label_check: the library's default, one host read per step as the reference's loss raises "
+                                   "inside the forward")
         if args.dtype == "fp32":
             line["config"]["fp32_products"] = (
                 "split operands: every fp32 operand as three bf16 terms (h + m + l == x exactly), six v_mfma_f32_32x32x16_bf16 "
@@ -582,6 +712,7 @@ def main():
             r = dict(kernels[dom])
             r["kernel"] = dom
             r["traffic"] = pmc_traffic(dom)
+            r["traffic_source"] = traffic_source()
             # ALGORITHMIC bytes per launch of the same family (every operand once), so that the line itself shows the ratio:
             # traffic well above it = re-reads
             a = summ[dom]
@@ -590,6 +721,8 @@ def main():
                 if r["traffic"]:
                     r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
             line["roofline"] = r
+            line["kernels"] = kernels
+        if timer is not None and args.sections == "all":
             kernels.update(loss_kernel_roofline(dev, B, H, W))
             # north_star target "MFMA roofline on the ResNet-50-FPN forward": conv kernels of forward-only passes, with the
             # DIRECT kernels everywhere (executed FLOPs = algorithmic FLOPs, so the fraction is a true MFMA utilisation)
@@ -622,7 +755,7 @@ def main():
                     "ms_per_pass": round(wms / 3, 2), "algorithmic_tflops": round(fwork / (wms * 1e-3) / 1e12, 2),
                     "note": "3x3 stride-1 layers with >= 128 channels by Winograd F(4x4,3x3): a quarter of the multiplications there"}
             line["kernels"] = kernels
-        if world == 1 and args.dtype == "fp32" and timer is not None:
+        if world == 1 and args.dtype == "fp32" and timer is not None and args.sections == "all":
             del net, opt, params
             torch.cuda.empty_cache()
             if split:

@@ -10,12 +10,20 @@ batch k; ingest (to_tensor + normalize, fused into the stem's layout), network, 
 all run on the compute stream and never leave the device until the parsed states do.
 
   python tools/bench_infer.py [--cams 18] [--batch 3] [--iters 5]
+  python tools/bench_infer.py --gpus N ...      the cameras dealt over N GPUs, one process each (retinanet_mi355x/multicam.py):
+                                                rank r detects cameras r, r+N, ..., the ranks' survivors are gathered, rank 0
+                                                merges them and runs parse_detections + state_to_im once per time step; one JSON
+                                                line with frames/s per GPU and aggregate.  Starts its own ranks (a
+                                                torch.distributed.run child, before this process touches the GPU) or reads
+                                                torchrun's environment.
 """
 import argparse
+import json
 import os
+import socket
+import subprocess
 import sys
 import time
-import types
 
 import numpy as np
 import torch
@@ -24,7 +32,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "3d-playground_amd"))
 import homography as hgm  # noqa: E402
 import mc3d_post  # noqa: E402
-from retinanet_mi355x import conv as cv, modules, synth  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from retinanet_mi355x import conv as cv, ddp, modules, multicam, synth  # noqa: E402
 
 H, W = 1080, 1920
 
@@ -56,13 +65,130 @@ def tracker(dev, names):
     return me
 
 
+def launch_ranks(args):
+    """--gpus N without a torchrun environment: N rank processes as a torch.distributed.run CHILD, started before this process
+    has touched the GPU (never re-exec a process that has); exit with their code."""
+    have = torch.cuda.device_count()                       # does not initialise the GPU on this image
+    if have < args.gpus and not os.environ.get("RN_REHEARSE_ONE_GPU"):
+        raise SystemExit("bench_infer.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def sharded(args, rank, local, world):
+    """The N-GPU protocol of retinanet_mi355x/multicam.py (also runs with world = 1: the same chain with one rank, the yardstick
+    for the aggregate).  Every rank: its cameras' uint8 frames in pinned host memory -> copy stream -> detector(MULTI_FRAME) in
+    calls of --batch cameras -> survivors with global camera ids; then gather, and on rank 0 merge + parse_detections +
+    state_to_im once per time step."""
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    net = detector(dev)
+    if args.dtype == "bf16":
+        net.set_compute_dtype("bf16")
+    names = multicam.CAMERAS[:args.cams] if args.cams <= 18 else ["cam%d" % i for i in range(args.cams)]
+    mine = multicam.shard(args.cams, world, rank)
+    me = tracker(dev, names)
+    g = torch.Generator().manual_seed(7)
+    frames_all = torch.randint(0, 256, (args.cams, H, W, 3), generator=g, dtype=torch.uint8)     # every rank draws the same 18 frames ...
+    host = frames_all[mine].contiguous().pin_memory()                                             # ... and keeps its cameras'
+    del frames_all
+    n = len(mine)
+    spans = [(a, min(n, a + args.batch)) for a in range(0, n, args.batch)]
+    compute, copy = torch.cuda.current_stream(), torch.cuda.Stream()
+    bufs = [torch.empty((args.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k):
+        a, b = spans[k]
+        with torch.cuda.stream(copy):
+            copy.wait_event(free[k % 2])
+            bufs[k % 2][:b - a].copy_(host[a:b], non_blocking=True)
+            copied[k % 2].record(copy)
+
+    def time_step():
+        for e in free:
+            e.record(compute)
+        parts = []
+        if spans:
+            upload(0)
+        for k, (a, b) in enumerate(spans):
+            if k + 1 < len(spans):
+                upload(k + 1)                                # under the detector of call k
+            compute.wait_event(copied[k % 2])
+            s, c, bx, im = net(bufs[k % 2][:b - a], MULTI_FRAME=True)
+            free[k % 2].record(compute)
+            parts.append((s, c, bx, multicam.to_global(im, mine[a:b])))
+        if parts:
+            s, c, bx, cam = (torch.cat([p[i] for p in parts]) for i in range(4))
+        else:                                                # more ranks than cameras: this rank only takes part in the gather
+            s, c = torch.empty(0, device=dev), torch.empty(0, dtype=torch.int64, device=dev)
+            bx, cam = torch.empty((0, 20), device=dev), torch.empty(0, dtype=torch.int64, device=dev)
+        gathered = multicam.gather_detections(s, c, bx, cam)
+        kept = sum(int(p[0].numel()) for p in gathered)
+        parsed = 0
+        if rank == 0 and kept:
+            ms, mc, mb, mcam = multicam.merge(gathered)
+            st, lb, sc, cm = me.parse_detections(ms, mc, mb, mcam)
+            if isinstance(st, torch.Tensor) and st.shape[0]:
+                me.hg.state_to_im(st, name=[names[i] for i in cm.cpu().tolist()])
+                parsed = int(st.shape[0])
+        return kept, parsed
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    time_step()
+    barrier()
+    t0 = time.time()
+    for _ in range(args.iters):
+        kept, parsed = time_step()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    per_step = dt / args.iters
+    if rank == 0:
+        label = args.dtype if args.dtype != "fp32" else "fp32, %s products" % cv.get_fp32_mfma()
+        print(json.dumps({"metric": "inference frames/sec, %d cameras x %dx%d uint8, ResNet-50 3D-RetinaNet (%s), detect + parse_detections "
+                                    "+ state_to_im" % (args.cams, W, H, label),
+                          "value": round(args.cams / per_step, 2), "unit": "frames/sec", "n_gpus": world, "ms_per_time_step": round(1e3 * per_step, 2),
+                          "frames_per_sec_per_gpu": round(args.cams / per_step / world, 2), "cameras_per_rank": [len(s) for s in multicam.shards(args.cams, world)],
+                          "cameras_per_call": args.batch, "time_steps": args.iters, "detections_kept": kept, "objects_parsed": parsed,
+                          "scaling": "strong (18 cameras whatever N)", "data": "synthetic (uniform-noise frames)",
+                          "backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
+                          "protocol": "rank r: cameras r, r+N, ...; all_gather of the survivors; rank 0 merges and parses (retinanet_mi355x/multicam.py)"}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="> 1: the cameras dealt over N GPUs, one process each (JSON line)")
+    ap.add_argument("--sharded", action="store_true", help="run the N-GPU protocol with one rank as well (JSON line) and stop")
     ap.add_argument("--cams", type=int, default=18)
     ap.add_argument("--batch", type=int, default=3, help="cameras per detector call (18 cameras over 8 GPUs: 2-3 each)")
     ap.add_argument("--iters", type=int, default=5, help="time steps (one frame from every camera each)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: DESIGN.md 4.5 (opt-in, not the reference's arithmetic)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
+    rank, local, world = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("bench_infer.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world))
+    if world > 1 or args.sharded:
+        return sharded(args, rank, local, world)
     dev = torch.device("cuda:0")
     net = detector(dev)
     if args.dtype == "bf16":

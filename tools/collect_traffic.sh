@@ -8,5 +8,5 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/traffic/$c
   rm -rf "$d"
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$d" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/traffic_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$d" -- python3 bench.py --steps 1 --warmup 1 --sections headline --no-cpu-baseline --no-kernel-timing > gpurun_out/traffic_$c.log 2>&1
 done

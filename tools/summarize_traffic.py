@@ -27,4 +27,13 @@ for k, d in acc.items():
     w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
     out[k.replace("void ", "")] = {"launches": len(d["FETCH_SIZE"]), "fetch_kib_raw": round(f, 1), "write_kib": round(w, 1),
                                    "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-json.dump(dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])), sys.stdout, indent=1)
+res = dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))
+# stamp: the sources these counters were collected on (bench.py quotes the bytes only beside a run of the SAME sources)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-playground_amd"))
+from retinanet_mi355x import prof  # noqa: E402
+import time  # noqa: E402
+res["_meta"] = {"sources_sha256": prof.sources_digest(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
+                "command": "tools/collect_traffic.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py "
+                           "--steps 1 --warmup 1 --sections headline --no-cpu-baseline --no-kernel-timing)",
+                "step_total_hbm_bytes": int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in res.values()) / 2)}
+json.dump(res, sys.stdout, indent=1)
