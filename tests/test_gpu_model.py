@@ -334,7 +334,7 @@ def test_training_trajectories_agree_between_product_modes(dev):
     assert cross.max() <= TRAJ_CROSS, cross
 
 
-TRAJ_CROSS = 5e-3     # split vs native after 12 steps at fixed order
+TRAJ_CROSS = 1e-2     # split vs native after 12 steps at fixed order: measured 2e-7 .. 1e-6 for steps 1-4, 3.4e-3 at step 12 (round 3's bound with the atomics on: 2e-2 + 5 x the same-mode drift)
 
 
 def test_fused_clip_adam_matches_torch(dev):

@@ -48,9 +48,10 @@ def test_train_ddp_two_ranks_on_one_gpu(dev, tmp_path):
 def test_camera_sharding_two_ranks_equal_one(dev):
     """Same four 1080p frames, same detector: one rank running all four cameras through the sharded protocol against two ranks
     with two cameras each (calls of one camera, so that the per-call 10 000-candidate cap sees the same frames either way)."""
-    common = ["tools/bench_infer.py", "--cams", "4", "--batch", "1", "--iters", "1"]
+    common = ["tools/bench_infer.py", "--cams", "4", "--batch", "1", "--iters", "1", "--checksum"]
     one = _run(common + ["--sharded"])
     two = _run(common + ["--gpus", "2"], RN_REHEARSE_ONE_GPU="1")
     assert one["ranks"] == 1 and two["ranks"] == 2 and two["cameras_per_rank"] == [2, 2]
     assert one["detections_kept"] > 100
     assert two["detections_kept"] == one["detections_kept"] and two["objects_parsed"] == one["objects_parsed"]
+    assert one["objects_parsed"] > 0 and two["parsed_states_checksum"] == one["parsed_states_checksum"]   # the same states, bit for bit

@@ -132,14 +132,15 @@ def sharded(args, rank, local, world):
             bx, cam = torch.empty((0, 20), device=dev), torch.empty(0, dtype=torch.int64, device=dev)
         gathered = multicam.gather_detections(s, c, bx, cam)
         kept = sum(int(p[0].numel()) for p in gathered)
-        parsed = 0
+        parsed, checksum = 0, 0.0
         if rank == 0 and kept:
             ms, mc, mb, mcam = multicam.merge(gathered)
             st, lb, sc, cm = me.parse_detections(ms, mc, mb, mcam)
             if isinstance(st, torch.Tensor) and st.shape[0]:
                 me.hg.state_to_im(st, name=[names[i] for i in cm.cpu().tolist()])
                 parsed = int(st.shape[0])
-        return kept, parsed
+                checksum = float(torch.nan_to_num(st.double()).sum()) if args.checksum else 0.0
+        return kept, parsed, checksum
 
     def barrier():
         if world > 1:
@@ -149,7 +150,7 @@ def sharded(args, rank, local, world):
     barrier()
     t0 = time.time()
     for _ in range(args.iters):
-        kept, parsed = time_step()
+        kept, parsed, checksum = time_step()
     barrier()
     dt = time.time() - t0
     if world > 1:
@@ -164,6 +165,7 @@ def sharded(args, rank, local, world):
                           "value": round(args.cams / per_step, 2), "unit": "frames/sec", "n_gpus": world, "ms_per_time_step": round(1e3 * per_step, 2),
                           "frames_per_sec_per_gpu": round(args.cams / per_step / world, 2), "cameras_per_rank": [len(s) for s in multicam.shards(args.cams, world)],
                           "cameras_per_call": args.batch, "time_steps": args.iters, "detections_kept": kept, "objects_parsed": parsed,
+                          "parsed_states_checksum": checksum if args.checksum else None,
                           "scaling": "strong (18 cameras whatever N)", "data": "synthetic (uniform-noise frames)",
                           "backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
                           "protocol": "rank r: cameras r, r+N, ...; all_gather of the survivors; rank 0 merges and parses (retinanet_mi355x/multicam.py)"}),
@@ -176,6 +178,7 @@ def sharded(args, rank, local, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="> 1: the cameras dealt over N GPUs, one process each (JSON line)")
+    ap.add_argument("--checksum", action="store_true", help="sharded protocol: also print the sum of the parsed states (one host read per step)")
     ap.add_argument("--sharded", action="store_true", help="run the N-GPU protocol with one rank as well (JSON line) and stop")
     ap.add_argument("--cams", type=int, default=18)
     ap.add_argument("--batch", type=int, default=3, help="cameras per detector call (18 cameras over 8 GPUs: 2-3 each)")
