@@ -58,6 +58,8 @@ bool rn_igemm_big_grouped_launch(const rn_conv_group *g, const float *w, const f
 bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
                           const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc);
 bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc);
+// conv_igemm_mf16p.hip: the plain-GEMM form with a short reduction as a continuous K-step stream (persistent, stores spread over the next tile)
+bool rn_igemm_mf16_pipe_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, hipStream_t s, int *rc);
 
 static int dbg_dyn_lds(const void *fn) {                  // occupancy experiment: RN_DBG_DYN_LDS bytes of unused dynamic LDS per workgroup
     static const int v = getenv("RN_DBG_DYN_LDS") ? atoi(getenv("RN_DBG_DYN_LDS")) : 0;
@@ -73,6 +75,7 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
     {
         int rc = RN_OK;
         if (rn_igemm_big_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
+        if (rn_igemm_mf16_pipe_launch(variant, d, x, w, y, s, &rc)) return rc;
         if (rn_igemm_mf16_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
     }
     const dim3 grid(tiles), block(256);

@@ -293,9 +293,13 @@ int rn_set_fp32_mfma(int mode);
  *   RN_OPT_BIG_TILE       (RN_BIG_TILE, 0..3, default 0)  256 x 256 tile variants (csrc/conv_igemm_big.hip).
  *   RN_OPT_BIG_TILE_MIN   (RN_BIG_TILE_MIN, >= 0, default 200)  fewest 256 x 256 tiles a launch needs to take them.
  *   RN_OPT_WGRAD_ONCE     (RN_WGRAD_ONCE, 0/1, default 1)  weight gradient's 128 x 128 tile splits its operands once per workgroup.
- *   RN_OPT_PERSIST        (RN_PERSIST, 0/1, default 1)  short-reduction launches of conv_igemm_mf16.hip run as persistent workgroups
- *                         that issue tile n+1's first loads before tile n's stores (csrc/conv_igemm_mf16.hip).
- *   RN_OPT_PERSIST_MAX_K  (RN_PERSIST_MAX_K, >= 0, default 640)  longest reduction kh*kw*Cin that takes the persistent form. */
+ *   RN_OPT_PERSIST        (RN_PERSIST, 0/1, default 0)  the plain-GEMM launches with a short reduction (the Winograd stage) run as
+ *                         persistent workgroups with two accumulator sets and the stores of tile n spread over the K-steps of
+ *                         tile n + 1 (csrc/conv_igemm_mf16p.hip).  Measured 4-9 % slower than the plain launch
+ *                         (profiles/r04_persist_analysis.txt): opt-in, kept with its parity tests.
+ *   RN_OPT_PERSIST_MAX_K  (RN_PERSIST_MAX_K, >= 0, default 640)  longest reduction Cin that takes that form.
+ *   RN_OPT_PERSIST_WGS    (RN_PERSIST_WGS, >= 0, default 0 = two per CU)  workgroups of a persistent launch (rounded up to a multiple
+ *                         of 8); a launch takes the persistent form only when it has more tiles than that. */
 #define RN_OPT_SPLITK 0
 #define RN_OPT_DETERMINISTIC 1
 #define RN_OPT_MF16 2
@@ -306,7 +310,8 @@ int rn_set_fp32_mfma(int mode);
 #define RN_OPT_WGRAD_ONCE 7
 #define RN_OPT_PERSIST 8
 #define RN_OPT_PERSIST_MAX_K 9
-#define RN_OPT_COUNT 10
+#define RN_OPT_PERSIST_WGS 10
+#define RN_OPT_COUNT 11
 int rn_get_option(int option);
 int rn_set_option(int option, int value);
 /* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (64; environment RN_FP32_SPLIT_MIN_K);

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-OPTS = ("OPT_BIG_TILE_MIN", "OPT_BIG_TILE", "OPT_MF16", "OPT_MF16_MIN", "OPT_MF16_NARROW", "OPT_PERSIST")
+OPTS = ("OPT_BIG_TILE_MIN", "OPT_BIG_TILE", "OPT_MF16", "OPT_MF16_MIN", "OPT_MF16_NARROW", "OPT_PERSIST", "OPT_PERSIST_MAX_K", "OPT_PERSIST_WGS")
 
 
 def _set(cv, opts):
@@ -33,7 +33,11 @@ def cv(dev, request):
     conv.set_fp32_mfma("split")
     conv.PRESPLIT = True
     if request.param in ("mf16", "mf16p"):
-        conv._big_on = {"OPT_BIG_TILE": 0, "OPT_MF16": 1, "OPT_MF16_MIN": 1, "OPT_MF16_NARROW": 1, "OPT_PERSIST": int(request.param == "mf16p")}
+        # mf16p: the plain-GEMM launches of this file (the Winograd stage, test_plain_gemm_short_reductions) take the continuous-stream
+        # form of csrc/conv_igemm_mf16p.hip on 8 workgroups -- a workgroup walks up to dozens of tiles, with ragged last tiles, column
+        # blocks past Cout and trip counts that differ between the workgroups of a launch
+        conv._big_on = {"OPT_BIG_TILE": 0, "OPT_MF16": 1, "OPT_MF16_MIN": 1, "OPT_MF16_NARROW": 1, "OPT_PERSIST": int(request.param == "mf16p"),
+                        "OPT_PERSIST_MAX_K": 1 << 20, "OPT_PERSIST_WGS": 8}
     else:
         conv._big_on = {"OPT_BIG_TILE": int(request.param), "OPT_BIG_TILE_MIN": 1, "OPT_MF16": 0}
     _set(conv, conv._big_on)
@@ -142,3 +146,35 @@ def test_winograd_group_takes_the_big_gemm(cv, dev):
     ys = cv.wino_conv_group([nhwc(x).to(dev) for x in xs], U, shift=b.to(dev), act=cv.ACT_RELU)
     for x, y in zip(xs, ys):
         close(y.permute(0, 3, 1, 2), F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1)), tol=1e-4)
+
+
+PLAIN = [  # cin, cout, N, H, W: 1x1, no epilogue -> the plain-GEMM instance (conv_igemm_mf16p.hip when the persistent form is on)
+    (64, 256, 2, 19, 23),        # two K-steps: eight stores per step; M = 874, ragged last row tile
+    (128, 192, 1, 30, 34),       # four K-steps; Cout = 192: the second column tile's upper half is past Cout
+    (192, 256, 3, 17, 15),       # six K-steps (not a power of two): the slices leave a remainder for the end of the tile
+    (512, 320, 1, 33, 31),       # sixteen K-steps: one store per step; three column tiles, the last 64 wide
+    (256, 128, 4, 16, 16),       # one column tile, M a multiple of 128
+]
+
+
+@pytest.mark.parametrize("case", PLAIN)
+def test_plain_gemm_short_reductions(cv, dev, case):
+    cin, cout, N, H, W = case
+    x, w = rnd((N, cin, H, W), 31), rnd((cout, cin, 1, 1), 32, (2.0 / cin) ** 0.5)
+    want = F.conv2d(x.double(), w.double())
+    xg, wp = nhwc(x).to(dev), cv.pack_weights(w.to(dev), 0)
+    y = _both_kernels(cv, lambda: cv.fprop(xg, wp, cout, 1, 1, 0))
+    close(y.permute(0, 3, 1, 2), want)
+
+
+def test_plain_gemm_per_position_weights(cv, dev):
+    """The Winograd stage's launch shape: `images` of 256 rows with a weight matrix of their own each (rn_conv_desc.w_batch_stride),
+    K = 128, the tiles of one workgroup crossing from image to image."""
+    P, T, C, Co = 9, 256, 128, 256
+    V = rnd((P, 1, T, C), 41).to(dev)
+    U = rnd((P, Co, C), 42, (2.0 / C) ** 0.5).to(dev)
+    Uv = cv.split_weights(U.view(P * Co, C).contiguous())
+    M = torch.empty((P, 1, T, Co), device=dev)
+    cv.conv_igemm(V, Uv, M, (1, T, Co, 1, 1, 1, 1, 0, 0), w_batch_stride=Co * C)
+    want = torch.einsum("ptc,poc->pto", V[:, 0].double().cpu(), U.double().cpu())
+    close(M[:, 0], want)

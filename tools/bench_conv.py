@@ -69,6 +69,26 @@ def main():
     dev = torch.device("cuda:0")
     B = args.batch
     print("%-26s %9s %9s %9s   (TFLOP/s; %% of %.1f TF fp32 MFMA peak)" % ("layer", "fprop", "dgrad", "wgrad", PEAK))
+    # The Winograd stage's batched GEMM as the training step launches it (conv.wino_conv_group): 36 positions x T tiles of the five
+    # pyramid levels of a tower layer at batch B, K = N = 256, raw epilogue.  fprop column only.
+    for name, c, co in (("wino gemm 36 x T 256->256", 256, 256), ("wino gemm 36 x T 512->512 l4", 512, 512), ("wino gemm 36 x T 128->128 l2", 128, 128),
+                        ("wino gemm 36 x T 256->256 l3", 256, 256)):
+        if args.only and args.only not in name:
+            continue
+        hw = {"256->256": [(135, 240), (68, 120), (34, 60), (17, 30), (9, 15)], "512 l4": [(34, 60)], "128 l2": [(135, 240)],
+              "256 l3": [(68, 120)]}["256->256" if name.endswith("256->256") else name[-6:]]
+        T = sum(B * ((h + 3) // 4) * ((w_ + 3) // 4) for h, w_ in hw)
+        Tpad = (T + 255) // 256 * 256
+        V = torch.randn(36, 1, Tpad, c, device=dev)
+        Mo = torch.empty(36, 1, Tpad, co, device=dev)
+        U = torch.randn(36, co, c, device=dev) * 0.05
+        Uv = U.view(36 * co, c)
+        if cv.PRESPLIT and cv.get_fp32_mfma() == "split":
+            Uv = cv.split_weights(Uv)
+        t = timeit(lambda: cv.conv_igemm(V, Uv, Mo, (1, Tpad, co, 1, 1, 1, 1, 0, 0), w_batch_stride=co * c), args.iters)
+        tf = 2.0 * 36 * Tpad * co * c / (t * 1e-3) / 1e12
+        print("%-26s %5.1f %3.0f%%   ms %.3f   (T %d, %.0f MB in + %.0f MB out)" % (name[:26], tf, 100 * tf / PEAK, t, Tpad, V.numel() * 4e-6, Mo.numel() * 4e-6))
+        del V, Mo, U, Uv
     for name, cin, cout, k, stride, pad, H, W in SHAPES:
         if args.only and args.only not in name:
             continue
