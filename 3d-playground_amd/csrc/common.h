@@ -124,3 +124,41 @@ __device__ __forceinline__ void rn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sign bits of an fp32 tensor (round 4): bit (e & 31) of word (e >> 5) says element e is > 0 -- one bit per element at the element's
+// own offset, so every addressing scheme of the fp32 tensor (batch strides, parity classes, slices) carries over with offset >> 5.
+// The backward pass needs of a ReLU output only this bit (the mask of its gradient): 1/32 of the bytes of re-reading the activation.
+// A lane finishes four consecutive elements (a 16-byte chunk, offset a multiple of 4); the eight chunks of a word sit in eight
+// consecutive lanes (an aligned group of 8: the epilogues' lanes run along the channels), which OR their nibbles over the DPP crossbar;
+// the lane whose chunk starts the word stores it.  Every lane of the group must be active (the callers' bounds are uniform per group).
+// (rn_conv_desc.mask_mode | RN_MASK_BITS, include/retinanet_mi355x.h: `mask` points to such words)
+__device__ __forceinline__ void rn_sign_store(unsigned *bits, int64_t off, float a, float b, float c, float d) {
+    unsigned w = ((unsigned)(a > 0.f) | ((unsigned)(b > 0.f) << 1) | ((unsigned)(c > 0.f) << 2) | ((unsigned)(d > 0.f) << 3)) << ((unsigned)off & 28u);
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xF, 0xF, true);    // row_half_mirror: lane i <-> 7 - i of its group of 8
+    if (((unsigned)off & 31u) == 0) bits[off >> 5] = w;
+}
+// the mask of four consecutive elements as 1.0 / 0.0: from the fp32 tensor itself (x > 0 is tested by the caller) or from its sign bits
+__device__ __forceinline__ float4 rn_mask_load4(const float *mask, int64_t off, bool bits) {
+    if (bits) {
+        const unsigned n = reinterpret_cast<const unsigned *>(mask)[off >> 5] >> ((unsigned)off & 28u);
+        return make_float4((n & 1u) ? 1.f : 0.f, (n & 2u) ? 1.f : 0.f, (n & 4u) ? 1.f : 0.f, (n & 8u) ? 1.f : 0.f);
+    }
+    return *reinterpret_cast<const float4 *>(mask + off);
+}
+// The same for a lane that finishes EIGHT consecutive elements (the bf16 kernels' 16-byte chunk): a byte per lane, four lanes per word.
+__device__ __forceinline__ void rn_sign_store8(unsigned *bits, int64_t off, const float (&v)[8]) {
+    unsigned b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b |= (unsigned)(v[j] > 0.f) << j;
+    unsigned w = b << ((unsigned)off & 24u);
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    if (((unsigned)off & 31u) == 0) bits[off >> 5] = w;
+}
+// sign bits of elements off .. off + n - 1 (n = 4 or 8, off a multiple of n) in the low bits
+__device__ __forceinline__ unsigned rn_sign_bits(const void *bits, int64_t off, int n) {
+    return (reinterpret_cast<const unsigned *>(bits)[off >> 5] >> ((unsigned)off & (32u - (unsigned)n))) & ((1u << n) - 1u);
+}

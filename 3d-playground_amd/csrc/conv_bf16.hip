@@ -329,6 +329,17 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
         constexpr int NR = RP / RPP;                         // rows per lane per pass
         constexpr int G = NR % 2 == 0 ? 2 : 1;               // rows per group (more costs registers the K loop needs: spills)
         typedef __bf16 opv __attribute__((ext_vector_type(CH)));
+        // the mask of CH consecutive elements: the bf16 tensor itself, or (mask_mode | RN_MASK_BITS) its sign bits (common.h) as 1 / 0
+        const bool mbits = (d.mask_mode & RN_MASK_BITS) != 0;
+        const int mmode = d.mask_mode & 3;
+        auto load_mask = [&](const int64_t off) -> opv {
+            if (!mbits) return *reinterpret_cast<const opv *>(mask + off);
+            const unsigned b = rn_sign_bits(mask, off, CH);
+            opv m;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) m[j] = (__bf16)((b >> j) & 1u ? 1.0f : 0.0f);
+            return m;
+        };
 #pragma unroll 1
         for (int g0 = 0; g0 < NR; g0 += G) {
             int64_t off_[G];
@@ -339,7 +350,7 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
                 const int64_t m = mr < M ? mr : M - 1;
                 if constexpr (DENSE) {
                     off_[i] = m * d.Cout + col;
-                    if (d.mask_mode != 0) mk_[i] = *reinterpret_cast<const opv *>(mask + off_[i]);
+                    if (d.mask_mode != 0) mk_[i] = load_mask(off_[i]);
                     if (d.add_mode == 1) ad_[i] = *reinterpret_cast<const opv *>(add + off_[i]);
                     continue;
                 }
@@ -350,7 +361,7 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
                 const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
                 const int64_t pix = (int64_t)ph * d.Wy + pw;
                 off_[i] = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
-                if (d.mask_mode != 0) mk_[i] = *reinterpret_cast<const opv *>(mask + off_[i]);
+                if (d.mask_mode != 0) mk_[i] = load_mask(off_[i]);
                 if (d.add_mode == 1) ad_[i] = *reinterpret_cast<const opv *>(add + (int64_t)n * d.add_batch_stride + pix * d.Cout + col);
                 else if (d.add_mode == 2)                      // nearest x2 upsample, cropped (D/model.py:88-108)
                     ad_[i] = *reinterpret_cast<const opv *>(add + (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col);
@@ -368,11 +379,11 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
                         float u = v[j] * sc[j] + sh[j];
-                        if (d.mask_mode == 1) u = (float)mk_[i][j] > 0.f ? u : 0.f;
+                        if (mmode == 1) u = (float)mk_[i][j] > 0.f ? u : 0.f;
                         if (d.add_mode != 0) u += (float)ad_[i][j];
                         if (d.act == 1) u = fmaxf(u, 0.f);
                         else if (d.act == 2) u = 1.0f / (1.0f + expf(-u));
-                        if (d.mask_mode == 2) u = (float)mk_[i][j] > 0.f ? u : 0.f;
+                        if (mmode == 2) u = (float)mk_[i][j] > 0.f ? u : 0.f;
                         v[j] = u;
                     }
                     if constexpr (YF32) {
@@ -382,6 +393,12 @@ __device__ __forceinline__ void conv_igemm_bf16_tile(const rn_conv_desc &d, cons
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
                         *reinterpret_cast<bf16x8 *>(yb + off_[i]) = o;
+                        if (d.sign_out != nullptr) {           // the sign of what was STORED (after the rounding to bf16)
+                            float st[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) st[j] = (float)o[j];
+                            rn_sign_store8(reinterpret_cast<unsigned *>(d.sign_out), off_[i], st);
+                        }
                     }
                 }
             }
@@ -433,7 +450,9 @@ static inline int check_desc_bf16(const rn_conv_desc *d) {
     const int64_t Kpad = ((int64_t)d->kh * d->kw * d->Cin + 31) / 32 * 32;
     if (d->Cout * Kpad * 2 > 0x7fffffffLL || (int64_t)d->N * HoWo > 0x7fffffffLL) return RN_EINVAL;
     if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
-    if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2 || d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;
+    if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
+    if (d->mask_mode < 0 || (d->mask_mode & ~(3 | RN_MASK_BITS)) || (d->mask_mode & 3) == 3 || d->mask_mode == RN_MASK_BITS) return RN_EINVAL;
+    if (((d->mask_mode & RN_MASK_BITS) || d->sign_out != nullptr) && ((d->Cout & 31) || (d->y_batch_stride & 31))) return RN_EINVAL;
     if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0) return RN_EINVAL;
     if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
     if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
@@ -445,7 +464,9 @@ static inline int check_ptrs_bf16(const rn_conv_desc *d, const void *x, const vo
     if ((d->add_mode != 0) != (add != nullptr) || (d->mask_mode != 0) != (mask != nullptr)) return RN_EINVAL;
     if (!y_is_f32 && (d->Cout & 7)) return RN_EINVAL;                    // bf16 result: 8 channels = 16 bytes per lane
     const uintptr_t am = y_is_f32 ? 7 : 15;                               // addend / mask: 8 bytes beside an fp32 result, else 16
-    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add & am) || ((uintptr_t)mask & am)) return RN_EINVAL;
+    const uintptr_t mm = (d->mask_mode & RN_MASK_BITS) ? 3 : am;           // sign-bit words
+    if (d->sign_out != nullptr && (y_is_f32 || ((uintptr_t)d->sign_out & 3))) return RN_EINVAL;   // sign bits: bf16 results only
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add & am) || ((uintptr_t)mask & mm)) return RN_EINVAL;
     if (!y_is_f32 && ((d->y_batch_stride & 7) || (d->add_batch_stride & 7))) return RN_EINVAL;
     return RN_OK;
 }

@@ -122,7 +122,8 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, G, K>), grid, block, 0, s, *d, x, w_packed, y, scale, shift, add, mask, add2)
     // K-step 16 (34-41 KB of LDS, four workgroups per CU) everywhere: with the operands arriving by direct-to-LDS loads it
     // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
-    const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0;
+    const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0 &&
+                     d->sign_out == nullptr;
     if (d->w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;
     if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d->w_format == 1 || d->kh * d->kw * d->Cin >= rn_fp32_split_min_k()))
         return rn_igemm_split_launch(raw ? 0 : (d->in_relu ? 1 : (narrow ? (dense ? 2 : 3) : (dense ? 4 : 5))), (unsigned)tiles, d, x,

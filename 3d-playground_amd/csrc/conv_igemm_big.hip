@@ -413,7 +413,7 @@ static int big_tile_mode() { return rn_get_option(RN_OPT_BIG_TILE); }
 static int big_min_tiles() { return rn_get_option(RN_OPT_BIG_TILE_MIN); }
 static bool big_ok(const rn_conv_desc *d) {
     return big_tile_mode() && d->w_format == 1 && (d->Cin % 16) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
-           (d->Cout % 4) == 0 && d->Cout >= 192 && !d->in_relu;
+           (d->Cout % 4) == 0 && d->Cout >= 192 && !d->in_relu && !(d->mask_mode & RN_MASK_BITS) && d->sign_out == nullptr;
 }
 static int64_t big_tiles(const rn_conv_desc *d) {
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;

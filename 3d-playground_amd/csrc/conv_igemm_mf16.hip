@@ -233,7 +233,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                     off_[i] = off;
                     mk_[i] = make_float4(1.f, 1.f, 1.f, 1.f);
                     ad_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!RAW && d.mask_mode != 0) mk_[i] = *reinterpret_cast<const float4 *>(mask + off);
+                    if (!RAW && d.mask_mode != 0) mk_[i] = rn_mask_load4(mask, off, (d.mask_mode & RN_MASK_BITS) != 0);
                     if (!RAW && d.add_mode != 0) ad_[i] = *reinterpret_cast<const float4 *>(add + aoff);
                     (void)a2off;
                 }

@@ -42,7 +42,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RN_EPI_LOAD()                                                                                            \
         float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f}; \
         if (vec) { \
-            if (d.mask_mode != 0) { const float4 q = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; } \
+            if (d.mask_mode != 0) { const float4 q = rn_mask_load4(mask, off, (d.mask_mode & RN_MASK_BITS) != 0); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; } \
             if (aoff >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add + aoff); ad[0] = q.x; ad[1] = q.y; ad[2] = q.z; ad[3] = q.w; } \
             if (a2off >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2off); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; } \
         } else { \
@@ -59,15 +59,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     _Pragma("unroll") \
         for (int j = 0; j < 4; ++j) { \
             float u = v[j]; \
-            if (d.mask_mode == 1) u = mk[j] > 0.f ? u : 0.f; \
+            if ((d.mask_mode & 3) == 1) u = mk[j] > 0.f ? u : 0.f; \
             u += ad[j]; \
             if (d.act == 1) u = fmaxf(u, 0.f); \
             else if (d.act == 2) u = 1.0f / (1.0f + expf(-u)); \
-            if (d.mask_mode == 2) u = mk[j] > 0.f ? u : 0.f; \
+            if ((d.mask_mode & 3) == 2) u = mk[j] > 0.f ? u : 0.f; \
             v[j] = u; \
         } \
         if (vec) { \
             *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]); \
+            if (d.sign_out != nullptr) rn_sign_store(reinterpret_cast<unsigned *>(d.sign_out), off, v[0], v[1], v[2], v[3]); \
         } else { \
     _Pragma("unroll") \
             for (int j = 0; j < 4; ++j) \
@@ -657,7 +658,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                         off_[i] = off;
                         mk_[i] = make_float4(1.f, 1.f, 1.f, 1.f);
                         ad_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (d.mask_mode != 0) mk_[i] = *reinterpret_cast<const float4 *>(mask + off);
+                        if (d.mask_mode != 0) mk_[i] = rn_mask_load4(mask, off, (d.mask_mode & RN_MASK_BITS) != 0);
                         if (d.add_mode != 0) ad_[i] = *reinterpret_cast<const float4 *>(add + aoff);
                         (void)a2off;
                     }
@@ -711,7 +712,9 @@ static inline int check_desc(const rn_conv_desc *d) {
     }
     if (d->kh <= 0 || d->kw <= 0 || d->div_shift < 0 || d->div_shift > 2) return RN_EINVAL;
     if (d->add_mode < 0 || d->add_mode > 2 || d->act < 0 || d->act > 2) return RN_EINVAL;
-    if (d->mask_mode < 0 || d->mask_mode > 2) return RN_EINVAL;
+    if (d->mask_mode < 0 || (d->mask_mode & ~(3 | RN_MASK_BITS)) || (d->mask_mode & 3) == 3 || d->mask_mode == RN_MASK_BITS) return RN_EINVAL;
+    // sign bits (read: mask_mode | RN_MASK_BITS; written: sign_out) live at element offset >> 5: whole words per pixel and per image
+    if (((d->mask_mode & RN_MASK_BITS) || d->sign_out != nullptr) && ((d->Cout & 31) || (d->y_batch_stride & 31))) return RN_EINVAL;
     if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0 || (d->add2_mode != 0 && d->add2_mode != 3)) return RN_EINVAL;
     if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
     if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;

@@ -67,6 +67,7 @@ struct WinoTable {
     float *dst[RN_MAX_GROUP];                    // y (output transform)
     const float *add[RN_MAX_GROUP];
     const float *mask[RN_MAX_GROUP];
+    unsigned *sign[RN_MAX_GROUP];                // output transform: sign bits of y (common.h: rn_sign_store), or NULL
 };
 __device__ __forceinline__ int wino_locate(const WinoTable &g, int64_t gt, int64_t &local) {
     int q = 0;
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
     const int q = wino_locate(g, gt, tile);
     float *y = g.dst[0];
     const float *add = g.add[0], *mask = g.mask[0];
-    WINO_SELECT(q, g, pr, y = g.dst[i_]; add = g.add[i_]; mask = g.mask[i_];)
+    unsigned *sign = g.sign[0];
+    WINO_SELECT(q, g, pr, y = g.dst[i_]; add = g.add[i_]; mask = g.mask[i_]; sign = g.sign[i_];)
+    const bool mbits = (mask_mode & RN_MASK_BITS) != 0;
+    mask_mode &= 3;
     const int H = pr.H, W = pr.W, TW = pr.TW;
     const int n = (int)(tile / (pr.TH * TW));
     const int r = (int)(tile - (int64_t)n * pr.TH * TW);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
             const int64_t yoff = (int64_t)n * ybs + ((int64_t)oh * W + ow) * Cout + c4;   // y: batch stride (a slice of [B, A, n])
             float v[4] = {sc.x * o[j].x + sh.x, sc.y * o[j].y + sh.y, sc.z * o[j].z + sh.z, sc.w * o[j].w + sh.w};
             float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
-            if (mask_mode != 0) { const float4 q4 = *reinterpret_cast<const float4 *>(mask + off); mk[0] = q4.x; mk[1] = q4.y; mk[2] = q4.z; mk[3] = q4.w; }
+            if (mask_mode != 0) { const float4 q4 = rn_mask_load4(mask, off, mbits); mk[0] = q4.x; mk[1] = q4.y; mk[2] = q4.z; mk[3] = q4.w; }
             if (add) { const float4 q4 = *reinterpret_cast<const float4 *>(add + off); ad[0] = q4.x; ad[1] = q4.y; ad[2] = q4.z; ad[3] = q4.w; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
                 v[k] = u;
             }
             *reinterpret_cast<float4 *>(y + yoff) = make_float4(v[0], v[1], v[2], v[3]);
+            if (sign != nullptr) rn_sign_store(sign, off, v[0], v[1], v[2], v[3]);      // (dense geometry: the 8 lanes of a word share the pixel)
         }
     }
 }
@@ -400,6 +405,7 @@ static int wino_table(const rn_wino_group *g, WinoTable &t) {
         if (i < g->n) end += (int64_t)g->N[k] * t.p[i].TH * t.p[i].TW;
         t.tile_end[i] = end;
         t.src[i] = g->src[k]; t.dst[i] = g->dst[k]; t.add[i] = g->add[k]; t.mask[i] = g->mask[k];
+        t.sign[i] = reinterpret_cast<unsigned *>(g->sign[k]);
     }
     return RN_OK;
 }
@@ -439,9 +445,11 @@ extern "C" int rn_wino_output_group(const rn_wino_group *g, const float *M, int 
     const int rc = wino_table(g, t);
     if (rc) return rc;
     if (Cout <= 0 || (Cout & 3) || tile_offset < 0 || tile_offset + t.tile_end[t.n - 1] > Tpad) return RN_EINVAL;
-    if (mask_mode < 0 || mask_mode > 2 || act < 0 || act > 2 || y_batch_stride < 0 || (y_batch_stride & 3)) return RN_EINVAL;
+    if (mask_mode < 0 || (mask_mode & ~(3 | RN_MASK_BITS)) || (mask_mode & 3) == 3 || mask_mode == RN_MASK_BITS) return RN_EINVAL;
+    if (act < 0 || act > 2 || y_batch_stride < 0 || (y_batch_stride & 3)) return RN_EINVAL;
     for (int i = 0; i < t.n; ++i) {
         if (!t.dst[i] || (mask_mode != 0) != (t.mask[i] != nullptr)) return RN_EINVAL;
+        if (((mask_mode & RN_MASK_BITS) || t.sign[i]) && (Cout & 31)) return RN_EINVAL;     // whole words per pixel
         if (y_batch_stride && y_batch_stride < (int64_t)t.p[i].H * t.p[i].W * Cout) return RN_EINVAL;
     }
     hipLaunchKernelGGL(wino_out_kernel, dim3(rn_blocks(t.tile_end[t.n - 1] * (Cout >> 2), 256)), dim3(256), 0,

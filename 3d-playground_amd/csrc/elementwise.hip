@@ -334,8 +334,8 @@ __global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *_
             if (a.w == pos) g.w += d.w;
         }
     }
-    if (relu_mask) {
-        const float4 v = x[i];
+    if (relu_mask) {                                            // 1: x is the fp32 activation; 2: x points to its sign bits (common.h)
+        const float4 v = rn_mask_load4(reinterpret_cast<const float *>(x), 4 * i, relu_mask == 2);
         g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
     }
     dx[i] = g;
@@ -344,6 +344,7 @@ __global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *_
 extern "C" int rn_maxpool_bwd(const float *x, const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
                               int Ho, int Wo, int relu_mask, void *stream) {
     if (N <= 0 || (C & 3) || argmax == nullptr || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RN_EINVAL;
+    if (relu_mask < 0 || relu_mask > 2 || (relu_mask == 2 && (C & 31))) return RN_EINVAL;
     const int64_t total = (int64_t)N * H * W * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy),

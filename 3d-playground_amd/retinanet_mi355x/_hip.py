@@ -72,7 +72,7 @@ class ConvDesc(ctypes.Structure):
                 ("os", c_i32), ("oo_h", c_i32), ("oo_w", c_i32), ("Hy", c_i32), ("Wy", c_i32),
                 ("add2_mode", c_i32), ("Ha2", c_i32), ("Wa2", c_i32), ("add2_batch_stride", c_i64),
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64),
-                ("w_batch_stride", c_i64), ("w_format", c_i32)]
+                ("w_batch_stride", c_i64), ("w_format", c_i32), ("sign_out", c_vp)]
 
 
 RN_MAX_GROUP = 5
@@ -104,7 +104,7 @@ class WinoGroup(ctypes.Structure):
     """rn_wino_group of include/retinanet_mi355x.h."""
     _fields_ = [("n", c_i32), ("N", c_i32 * RN_MAX_GROUP), ("H", c_i32 * RN_MAX_GROUP), ("W", c_i32 * RN_MAX_GROUP),
                 ("src", c_vp * RN_MAX_GROUP), ("dst", c_vp * RN_MAX_GROUP), ("add", c_vp * RN_MAX_GROUP),
-                ("mask", c_vp * RN_MAX_GROUP)]
+                ("mask", c_vp * RN_MAX_GROUP), ("sign", c_vp * RN_MAX_GROUP)]
 
 
 SIGNATURES.update({

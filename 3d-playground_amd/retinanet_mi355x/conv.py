@@ -44,9 +44,35 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None,
     return _maybe_split(out) if presplit else out        # split mode: with the pre-split twin attached
 
 
+# Sign bits of ReLU outputs (round 4; csrc/common.h: rn_sign_store).  A producer called with sign=True also writes one bit per
+# element of its result (y > 0) and attaches the words as y._rn_sign; a consumer whose `mask` tensor carries that attribute reads the
+# bits instead of the fp32 activation (1/32 of the bytes; same mask, bit-identical gradients).  RN_BITMASKS=0: fp32 masks (A/B).
+BITMASKS = os.environ.get("RN_BITMASKS", "1") != "0"
+MASK_BITS = 4                                    # RN_MASK_BITS of include/retinanet_mi355x.h
+
+
+def _sign_words(y, want):
+    """-> int32 tensor for the sign bits of the dense fp32 tensor y (attached as y._rn_sign), or None."""
+    if not (want and BITMASKS) or y.dtype != torch.float32 or y.shape[-1] % 32 or not y.is_contiguous():
+        return None
+    bits = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
+    y._rn_sign = bits
+    return bits
+
+
+def _mask_operand(mask, mask_mode):
+    """(pointer, mask_mode) of a mask operand: the sign bits its producer left, if any, else the fp32 tensor itself."""
+    if mask is None:
+        return None, 0
+    bits = getattr(mask, "_rn_sign", None) if BITMASKS else None
+    if bits is not None:
+        return bits.data_ptr(), mask_mode | MASK_BITS
+    return mask.data_ptr(), mask_mode
+
+
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
                mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0,
-               out_map=None, add2=None, w_batch_stride=0, kind=None):
+               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift) with p an int or (p_rows, p_cols).
     out_map = (os, oo_h, oo_w, Hy, Wy) stores output pixel (oh,ow) at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
@@ -60,9 +86,12 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
     if add_batch_stride is None:
         add_batch_stride = ybs if add_mode == 1 else add_hw[0] * add_hw[1] * Cout
     a2 = (0, 0, 0, 0) if add2 is None else (3, add2.shape[1], add2.shape[2], add2.shape[1] * add2.shape[2] * Cout)
+    mask_ptr, mask_mode = _mask_operand(mask, mask_mode)
     d = ConvDesc(N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, a, b, p_h, p_w, ds, act, add_mode, add_hw[0], add_hw[1],
-                 (mask_mode if mask is not None else 0), int(in_relu), os_, oo_h, oo_w, Hy, Wy,
+                 mask_mode, int(in_relu), os_, oo_h, oo_w, Hy, Wy,
                  a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride, w_batch_stride)
+    bits = _sign_words(y, sign and y_batch_stride is None and out_map is None)
+    d.sign_out = None if bits is None else bits.data_ptr()
     if kind is None:
         kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
     if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
@@ -72,18 +101,19 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_splitk(
             ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
-            _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), ws.data_ptr(), _hip.stream()))
+            _hip.ptr(add), mask_ptr, _hip.ptr(add2), ws.data_ptr(), _hip.stream()))
         _hip.check(rc, "rn_conv_igemm_splitk")
         return y
     wptr, d.w_format = _w_operand(w_packed)
     nb = 0.0
     if prof.ACTIVE is not None:            # algorithmic bytes: every operand once (the split kernels read weights as 6-byte terms)
         out_el = N * Ho * Wo * Cout
-        nb = 4.0 * (x.numel() + out_el * (1 + (add is not None) + (mask is not None))) + (6.0 if d.w_format else 4.0) * w_packed.numel() \
-            + (4.0 * add2.numel() if add2 is not None else 0.0)
+        mask_el = 0.0 if mask is None else (1.0 / 32 if mask_mode & MASK_BITS else 1.0)
+        nb = 4.0 * (x.numel() + out_el * (1 + (add is not None) + mask_el + (1.0 / 32 if bits is not None else 0.0))) \
+            + (6.0 if d.w_format else 4.0) * w_packed.numel() + (4.0 * add2.numel() if add2 is not None else 0.0)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm(
         ctypes.byref(d), x.data_ptr(), wptr, y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
-        _hip.ptr(add), _hip.ptr(mask), _hip.ptr(add2), _hip.stream()), nb)
+        _hip.ptr(add), mask_ptr, _hip.ptr(add2), _hip.stream()), nb)
     _hip.check(rc, "rn_conv_igemm")
     return y
 
@@ -209,8 +239,9 @@ def wino_weights(weight, mode=0, scale=None):
 _WINO_WS = {}
 
 
-def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None):
-    """rn_wino_group for problems shaped like xs ([N,H,W,.]); at most RN_MAX_GROUP of them."""
+def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None, mask_bits=False, signs=None):
+    """rn_wino_group for problems shaped like xs ([N,H,W,.]); at most RN_MAX_GROUP of them.  mask_bits: the masks' sign-bit words
+    (tensor._rn_sign) instead of the fp32 tensors; signs: per problem the words that receive the result's sign bits, or None."""
     g = _hip.WinoGroup()
     g.n = len(xs)
     for i, x in enumerate(xs):
@@ -218,7 +249,11 @@ def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None):
         g.src[i] = None if srcs is None else srcs[i].data_ptr()
         g.dst[i] = None if dsts is None else dsts[i].data_ptr()
         g.add[i] = None if adds is None or adds[i] is None else adds[i].data_ptr()
-        g.mask[i] = None if masks is None or masks[i] is None else masks[i].data_ptr()
+        if masks is None or masks[i] is None:
+            g.mask[i] = None
+        else:
+            g.mask[i] = masks[i]._rn_sign.data_ptr() if mask_bits else masks[i].data_ptr()
+        g.sign[i] = None if signs is None or signs[i] is None else signs[i].data_ptr()
     return g
 
 
@@ -249,7 +284,7 @@ def _wino_workspace(device, floats_v, floats_m):
 
 
 def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds=None, masks=None, mask_mode=2,
-                    flops=0.0, keep_v=False, y_batch_stride=0, V_in=None, V_ready=None):
+                    flops=0.0, keep_v=False, y_batch_stride=0, V_in=None, V_ready=None, sign=False):
     """3x3 / stride 1 / padding 1 convolution of several inputs [N,H,W,C] with the same (transformed) weights U
     [36, Cout, Kpad]: one grouped input transform into V, ONE batched GEMM launch, one grouped output transform with
     the epilogue (outs: dense tensors, or slices with y_batch_stride).  Returns the outputs (and, with keep_v, the
@@ -289,12 +324,16 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
         part, t = xs[sl], sum(tiles[sl])
         pa = None if adds is None else adds[sl]
         pm = None if masks is None else masks[sl]
-        g = _wino_group(part, dsts=outs[sl], adds=pa, masks=pm)
         has_mask = pm is not None and pm[0] is not None
-        nops = 1 + (pa is not None and pa[0] is not None) + has_mask
+        # sign bits: read instead of the fp32 masks when every mask of the launch carries them; written for dense results on request
+        mbits = has_mask and BITMASKS and all(getattr(m, "_rn_sign", None) is not None for m in pm)
+        signs = [_sign_words(o, sign and not y_batch_stride) for o in outs[sl]]
+        g = _wino_group(part, dsts=outs[sl], adds=pa, masks=pm, mask_bits=mbits, signs=signs)
+        nops = 1 + (pa is not None and pa[0] is not None) + (1.0 / 32 if mbits else 1.0) * has_mask + (1.0 / 32 if signs[0] is not None else 0.0)
         nb = 4.0 * (36 * t * cout + nops * sum(x.shape[0] * x.shape[1] * x.shape[2] for x in part) * cout)
+        mm = (mask_mode | (MASK_BITS if mbits else 0)) if has_mask else 0
         _hip.check(prof.timed("wino_output", nb, lambda: lib.rn_wino_output_group(
-            ctypes.byref(g), M.data_ptr(), cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), mask_mode if has_mask else 0,
+            ctypes.byref(g), M.data_ptr(), cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), mm,
             act, y_batch_stride, _hip.stream())), "rn_wino_output_group")
         off += t
     return (outs, (V, tuple(tuple(x.shape) for x in xs))) if keep_v else outs   # V + the shapes it belongs to
@@ -345,7 +384,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
 
 def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE, flops=0.0):
     """One launch for up to 5 problems sharing weights / epilogue scalars (the pyramid levels of a head tower).
-    problems: list of dicts with x, y, geom and optional add, mask, mask_mode, y_batch_stride."""
+    problems: list of dicts with x, y, geom and optional add, mask, mask_mode, y_batch_stride, sign (write y's sign bits)."""
     lib = _hip.load()
     g = _hip.ConvGroup()
     g.n = len(problems)
@@ -354,14 +393,16 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
     for i, pr in enumerate(problems):
         x, geom = pr["x"], pr["geom"]
         add, mask = pr.get("add"), pr.get("mask")
-        d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), (pr.get("mask_mode", 2) if mask is not None else 0),
-                       False, None, pr.get("y_batch_stride"), None, None)
+        mask_ptr, mmode = _mask_operand(mask, pr.get("mask_mode", 2))
+        d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), mmode, False, None, pr.get("y_batch_stride"), None, None)
         d.w_format = wfmt
+        bits = _sign_words(pr["y"], pr.get("sign", False) and pr.get("y_batch_stride") is None)
+        d.sign_out = None if bits is None else bits.data_ptr()
         g.d[i] = d
         M = d.N * d.Ho * d.Wo
         total += (M + 255) // 256 if d.Cout <= 64 else ((M + 127) // 128) * ((d.Cout + 127) // 128)
         g.tile_end[i] = total
-        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
+        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), mask_ptr
     kind = "conv_igemm_4x1" if problems[0]["geom"][2] <= 64 else "conv_igemm_2x2"
     if prof.BY_SHAPE:
         kind += " grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh)
@@ -503,8 +544,10 @@ def maxpool_bwd(x, dy, argmax, relu_mask=True):
     lib = _hip.load()
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
-    _hip.check(lib.rn_maxpool_bwd(x.data_ptr(), dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(), N, H, W, C,
-                                  dy.shape[1], dy.shape[2], int(relu_mask), _hip.stream()), "rn_maxpool_bwd")
+    bits = getattr(x, "_rn_sign", None) if (relu_mask and BITMASKS) else None      # the stem's sign bits instead of re-reading it
+    _hip.check(lib.rn_maxpool_bwd(x.data_ptr() if bits is None else bits.data_ptr(), dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(),
+                                  N, H, W, C, dy.shape[1], dy.shape[2], (2 if bits is not None else int(relu_mask)), _hip.stream()),
+               "rn_maxpool_bwd")
     return dx
 
 

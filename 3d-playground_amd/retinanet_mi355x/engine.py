@@ -49,6 +49,8 @@ class Layer:
         # few columns); set per step by the engine
         self.wino_layer = self.wino_ok and min(spec.cin, spec.cout) >= 64 and max(spec.cin, spec.cout) >= 128 and not bf16
         self.wino_active = False
+        self.sign = False                              # training forward: ReLU outputs also leave their sign bits (conv.BITMASKS), the
+                                                       # backward pass reads those instead of the activations (set per step by the engine)
         self.keep_v = True
         self._cache = None
         self.reset()
@@ -136,8 +138,11 @@ class Layer:
         return self.wd
 
     # ---- forward
-    def fwd(self, x, act=cv.ACT_NONE, add=None, add_mode=0, add_hw=(0, 0), out=None, y_batch_stride=None, in_relu=False):
+    def fwd(self, x, act=cv.ACT_NONE, add=None, add_mode=0, add_hw=(0, 0), out=None, y_batch_stride=None, in_relu=False, sign=None):
+        """sign: also write the result's sign bits (default: when the engine asked for them, self.sign, and the result is a ReLU output;
+        True for a tensor whose sign masks a later gradient although it is stored before its ReLU: fpn.P6)."""
         s = self.spec
+        sign = (self.sign and act == cv.ACT_RELU) if sign is None else (sign and self.sign)
         N, Hi, Wi, _ = x.shape
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
         if self.fp8:
@@ -152,14 +157,14 @@ class Layer:
                                       y_batch_stride=y_batch_stride, flops=self.flops(N, Ho, Wo))
         if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
                 and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
-            r = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, keep_v=self.keep_v)
+            r = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, keep_v=self.keep_v, sign=sign)
             ys, self.saved_v = r if self.keep_v else (r, None)
             return ys[0]
         if out is None:
             out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
         cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
                       shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
-                      y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo))
+                      y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo), sign=sign)
         self._tap(out if y_batch_stride is None else None)
         return out
 
@@ -220,7 +225,8 @@ class Layer:
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
             r = cv.wino_conv_group(xs, self.wino_weights(0), outs=outs, scale=self.scale, shift=self.shift, act=act, flops=fl,
-                                   keep_v=self.keep_v, y_batch_stride=y_batch_stride or 0, V_in=shared_v if self.keep_v else None)
+                                   keep_v=self.keep_v, y_batch_stride=y_batch_stride or 0, V_in=shared_v if self.keep_v else None,
+                                   sign=self.sign and act == cv.ACT_RELU)
             ys, self.saved_v = r if self.keep_v else (r, None)
             return ys
         probs, ys, fl = [], [], 0.0
@@ -231,7 +237,7 @@ class Layer:
             ys.append(y)
             fl += self.flops(N, Ho, Wo)
             probs.append({"x": x, "y": y, "geom": (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
-                          "y_batch_stride": y_batch_stride})
+                          "y_batch_stride": y_batch_stride, "sign": self.sign and act == cv.ACT_RELU})
         cv.conv_igemm_grouped(probs, self.wf, scale=self.scale, shift=self.shift, act=act, flops=fl)
         if outs is None:
             for y in ys:
@@ -809,6 +815,7 @@ class Engine:
         for L in Ls.values():                              # Winograd where it pays; in inference only on request
             L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer and not self.bf16 and not self.fp8)
             L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow
+            L.sign = bool(save) and not L.bf16 and not L.fp8    # ReLU outputs leave their sign bits for the backward pass
         if x4 is None:
             _hip.need_gpu(img)
             x4 = cv.nchw_to_nhwc4(img)
@@ -851,7 +858,7 @@ class Engine:
         p4 = Ls["fpn.P4_2"].fwd(p4sum)
         p3sum = Ls["fpn.P3_1"].fwd(c3, add=p4sum, add_mode=2, add_hw=(p4sum.shape[1], p4sum.shape[2]))
         p3 = Ls["fpn.P3_2"].fwd(p3sum)
-        p6 = Ls["fpn.P6"].fwd(c5)
+        p6 = Ls["fpn.P6"].fwd(c5, sign=True)               # stored before its ReLU; P7_2's data gradient is masked by its sign
         p6r = cv.relu_bf16(p6) if self.bf16 else None                      # fp32: the ReLU rides on the fragments (in_relu)
         if self.fp8:                                                       # (a 17 x 30 map: through fp32, same scale)
             p6r = cv.fp8_quantize(torch.relu(cv.fp8_dequantize(p6)), p6._rn_scale)

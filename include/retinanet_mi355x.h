@@ -261,7 +261,12 @@ typedef struct rn_conv_desc {
                                       be a multiple of 256 so that no tile spans two images */
     int w_format;                  /* 0: w_packed is the fp32 tensor of rn_pack_weights; 1: its pre-split form (rn_split_weights),
                                       accepted in RN_FP32_SPLIT mode only (RN_EINVAL otherwise; not by the split-K form) */
+    void *sign_out;                /* NULL, or uint32 words that receive the SIGN BITS of the result: bit (e & 31) of word (e >> 5)
+                                      = (y[e] > 0) for every stored element at float offset e -- what the backward pass needs of a ReLU
+                                      output (D/utils.py:60-80), at 1/32 of the bytes.  Needs Cout % 32 == 0 and y_batch_stride % 32
+                                      == 0.  mask_mode | RN_MASK_BITS (4): `mask` points to such words (the consumer's side). */
 } rn_conv_desc;
+#define RN_MASK_BITS 4
 
 /* How the fp32 convolution kernels (rn_conv_igemm*, rn_conv_wgrad*, and through them the Winograd GEMMs) form their
  * products.  Operands, accumulation, epilogue and results are fp32 either way.
@@ -459,7 +464,8 @@ typedef struct rn_wino_group {
     const float *src[RN_MAX_GROUP];
     float *dst[RN_MAX_GROUP];
     const float *add[RN_MAX_GROUP];
-    const float *mask[RN_MAX_GROUP];
+    const float *mask[RN_MAX_GROUP];       /* rn_wino_output_group: fp32, or sign-bit words with mask_mode | RN_MASK_BITS */
+    void *sign[RN_MAX_GROUP];              /* rn_wino_output_group: NULL or the words that receive the result's sign bits (rn_conv_desc.sign_out) */
 } rn_wino_group;
 int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form, void *stream);
 /* Both input-side transforms of an output gradient in one pass over it: V = B^T dy B (rn_wino_input_group, dy_form 0: what the
@@ -542,6 +548,8 @@ int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const f
  *                       accumulate != 0 adds to out (shared heads sum their five pyramid levels)
  *   rn_upsample_add_bwd: dst[n,h,w,c] += sum_{dy,dx<2} src[n,2h+dy,2w+dx,c] within src bounds (FPN top-down bwd)
  *   rn_relu_mask:       g = (z > 0) ? g : 0 in place
+ *   rn_maxpool_bwd:     relu_mask 1: the gradient is also masked by x > 0 (x = the pooled tensor, a ReLU output); 2: the same with
+ *                       x pointing to that tensor's SIGN BITS (rn_conv_desc.sign_out) instead of the tensor (C % 32 == 0)
  *   rn_sigmoid_bwd_pad: out[b][p][c<C] = dy[b][p][c] * s[b][p][c]*(1-s[b][p][c]) (s = sigmoid output, NULL =
  *                       identity), out[..][C..ld) = 0: a head-output gradient slice (rows_per_image rows per
  *                       image, images src_batch_stride floats apart in dy and s) copied to a dense, channel-
