@@ -48,12 +48,15 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None,
 # element of its result (y > 0) and attaches the words as y._rn_sign; a consumer whose `mask` tensor carries that attribute reads the
 # bits instead of the fp32 activation (1/32 of the bytes; same mask, bit-identical gradients).  RN_BITMASKS=0: fp32 masks (A/B).
 BITMASKS = os.environ.get("RN_BITMASKS", "1") != "0"
+# The bf16 engine's tensors can carry them too (conv_bf16.hip), but there a mask costs 2 bytes, not 4, and the step measured the same
+# with and without (194.8 / 195.3 against 194.1 / 194.8 images/s, profiles/r04_bitmask_ab_step.txt): opt-in.
+BITMASKS_BF16 = os.environ.get("RN_BITMASKS_BF16", "0") == "1"
 MASK_BITS = 4                                    # RN_MASK_BITS of include/retinanet_mi355x.h
 
 
 def _sign_words(y, want):
-    """-> int32 tensor for the sign bits of the dense fp32 tensor y (attached as y._rn_sign), or None."""
-    if not (want and BITMASKS) or y.dtype != torch.float32 or y.shape[-1] % 32 or not y.is_contiguous():
+    """-> int32 tensor for the sign bits of the dense fp32 / bf16 tensor y (attached as y._rn_sign), or None."""
+    if not (want and BITMASKS) or y.dtype not in (torch.float32, torch.bfloat16) or y.shape[-1] % 32 or not y.is_contiguous():
         return None
     bits = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
     y._rn_sign = bits
@@ -626,18 +629,21 @@ def pack_weights_bf16(weight, mode=0, scale=None, c_pad=None, taps=None):
 
 
 def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
-                    mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, flops=0.0, out_map=None):
-    """rn_conv_igemm_bf16: x [N,Hi,Wi,Cin] bf16, w_packed bf16, y bf16 or fp32 (its dtype decides); geom as conv_igemm."""
+                    mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, flops=0.0, out_map=None, sign=False):
+    """rn_conv_igemm_bf16: x [N,Hi,Wi,Cin] bf16, w_packed bf16, y bf16 or fp32 (its dtype decides); geom as conv_igemm.
+    sign / a mask that carries ._rn_sign: the sign bits of conv_igemm, here of the bf16 tensors."""
     lib = _hip.load()
     assert x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and y.dtype in (torch.bfloat16, torch.float32)
-    d = _make_desc(x, geom, act, add_mode, add_hw, (mask_mode if mask is not None else 0), False, out_map, y_batch_stride,
-                   add_batch_stride, None)
+    mask_ptr, mask_mode = _mask_operand(mask, mask_mode)
+    d = _make_desc(x, geom, act, add_mode, add_hw, mask_mode, False, out_map, y_batch_stride, add_batch_stride, None)
+    bits = _sign_words(y, sign and y_batch_stride is None and out_map is None and y.dtype == torch.bfloat16)
+    d.sign_out = None if bits is None else bits.data_ptr()
     kind = "conv_igemm_bf16"
     if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
         kind += " %dx%dx%d %d->%d k%d a%d b%d ds%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh, d.a, d.b, d.div_shift)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16(
         ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), int(y.dtype == torch.float32), _hip.ptr(scale),
-        _hip.ptr(shift), _hip.ptr(add), _hip.ptr(mask), _hip.stream()))
+        _hip.ptr(shift), _hip.ptr(add), mask_ptr, _hip.stream()))
     _hip.check(rc, "rn_conv_igemm_bf16")
     return y
 
@@ -717,8 +723,10 @@ def maxpool_bwd_bf16(x, dy, argmax, relu_mask=True):
     lib = _hip.load()
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
-    _hip.check(lib.rn_maxpool_bwd_bf16in(x.data_ptr(), dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(), N, H, W, C,
-                                         dy.shape[1], dy.shape[2], int(relu_mask), _hip.stream()), "rn_maxpool_bwd_bf16in")
+    bits = getattr(x, "_rn_sign", None) if (relu_mask and BITMASKS) else None      # the stem's sign bits instead of re-reading it
+    _hip.check(lib.rn_maxpool_bwd_bf16in(x.data_ptr() if bits is None else bits.data_ptr(), dy.data_ptr(), argmax.data_ptr(),
+                                         dx.data_ptr(), N, H, W, C, dy.shape[1], dy.shape[2],
+                                         (2 if bits is not None else int(relu_mask)), _hip.stream()), "rn_maxpool_bwd_bf16in")
     return dx
 
 
@@ -740,10 +748,12 @@ def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_
         x, geom = pr["x"], pr["geom"]
         add, mask = pr.get("add"), pr.get("mask")
         assert x.dtype == torch.bfloat16 and (pr["y"].dtype == torch.float32) == yf32
-        d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), (pr.get("mask_mode", 2) if mask is not None else 0),
-                       False, None, pr.get("y_batch_stride"), None, None)
+        mask_ptr, mmode = _mask_operand(mask, pr.get("mask_mode", 2))
+        d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), mmode, False, None, pr.get("y_batch_stride"), None, None)
+        bits = _sign_words(pr["y"], pr.get("sign", False) and pr.get("y_batch_stride") is None and not yf32)
+        d.sign_out = None if bits is None else bits.data_ptr()
         g.d[i] = d
-        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), _hip.ptr(mask)
+        g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), _hip.ptr(add), mask_ptr
     trm, trn = divmod(lib.rn_conv_igemm_bf16_tile_rows(ctypes.byref(g), int(yf32)), 1000)   # the launcher's tile for this group
     for i in range(g.n):
         d = g.d[i]

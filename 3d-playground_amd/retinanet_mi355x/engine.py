@@ -154,7 +154,7 @@ class Layer:
                 out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.bfloat16, device=x.device)
             return cv.conv_igemm_bf16(x, self.wf16, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
                                       scale=self.scale, shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
-                                      y_batch_stride=y_batch_stride, flops=self.flops(N, Ho, Wo))
+                                      y_batch_stride=y_batch_stride, flops=self.flops(N, Ho, Wo), sign=sign)
         if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
                 and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
             r = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, keep_v=self.keep_v, sign=sign)
@@ -219,7 +219,7 @@ class Layer:
                 ys.append(y)
                 fl += self.flops(N, Hi, Wi)
                 probs.append({"x": x, "y": y, "geom": (Hi, Wi, s.cout, s.k, self.kw_pad, 1, 1, -s.pad, 0),
-                              "y_batch_stride": y_batch_stride})
+                              "y_batch_stride": y_batch_stride, "sign": self.sign and act == cv.ACT_RELU})
             cv.conv_igemm_bf16_grouped(probs, self.wf16, scale=self.scale, shift=self.shift, act=act, flops=fl)
             return ys
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
@@ -815,7 +815,8 @@ class Engine:
         for L in Ls.values():                              # Winograd where it pays; in inference only on request
             L.wino_active = bool((save or self.wino_eval) and self.use_wino and L.wino_layer and not self.bf16 and not self.fp8)
             L.keep_v = bool(save)                          # the input transform is kept only when a backward will follow
-            L.sign = bool(save) and not L.bf16 and not L.fp8    # ReLU outputs leave their sign bits for the backward pass
+            # ReLU outputs leave their sign bits for the backward pass (fp32 engine; bf16: opt-in, measured neutral)
+            L.sign = bool(save) and not L.fp8 and (not L.bf16 or cv.BITMASKS_BF16)
         if x4 is None:
             _hip.need_gpu(img)
             x4 = cv.nchw_to_nhwc4(img)

@@ -183,3 +183,65 @@ def test_training_step_gradients_are_bit_identical_with_and_without_bits(dev, wi
     finally:
         conv.BITMASKS = before[0]
         conv.set_deterministic(before[1])
+
+
+# ------------------------------------------------------------------------------------------------ the bf16 engine's tensors
+def test_bf16_producer_and_consumer(dev):
+    """conv_bf16.hip: a lane finishes 8 consecutive bf16 channels = one byte of sign bits, four lanes a word."""
+    from retinanet_mi355x import conv as cv
+    before = cv.BITMASKS
+    cv.BITMASKS = True
+    try:
+        cin, cout, N, H, W = 64, 256, 2, 19, 23
+        x, w, b = rnd((N, cin, H, W), 1), rnd((cout, cin, 3, 3), 2, 0.06), rnd((cout,), 3)
+        xb = cv.to_bf16(nhwc(x).to(dev))
+        wp = cv.pack_weights_bf16(w.to(dev), 0)
+        y = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=dev)
+        cv.conv_igemm_bf16(xb, wp, y, (H, W, cout, 3, 3, 1, 1, -1, 0), shift=b.to(dev), act=cv.ACT_RELU, sign=True)
+        assert 0.2 < float((y > 0).float().mean()) < 0.8
+        assert torch.equal(y._rn_sign, packed_sign(y.float()))
+        # consumer: the data gradient of a 3x3 layer masked by y, from the bits and from the tensor
+        gy = cv.to_bf16(nhwc(rnd((N, 128, H, W), 6)).to(dev))
+        wd = cv.pack_weights_bf16(rnd((128, cout, 3, 3), 5, 0.03).to(dev), 1)
+        plain = y.clone()
+        for mode in (1, 2):
+            a = cv.dgrad_bf16(gy, wd, (H, W), cout, 3, 1, mask=y, mask_mode=mode)
+            b_ = cv.dgrad_bf16(gy, wd, (H, W), cout, 3, 1, mask=plain, mask_mode=mode)
+            assert torch.equal(a, b_)
+    finally:
+        cv.BITMASKS = before
+
+
+def test_bf16_training_step_with_and_without_bits(dev):
+    """The bf16 engine: same losses (the forward does not change), every ReLU output carries its bits, parameter gradients equal up to
+    the order of the bf16 weight gradient's fp32 atomics (1e-6 relative)."""
+    import golden_cases as gc
+    from retinanet_mi355x import conv, modules
+    before = conv.BITMASKS, conv.BITMASKS_BF16
+    conv.BITMASKS_BF16 = True                              # (opt-in for this engine: measured neutral on its step)
+    try:
+        out = {}
+        for on in (True, False):
+            conv.BITMASKS = on
+            fn, sd, img, ann = gc.model_case("resnet50", True)
+            net = modules.resnet50(num_classes=4)
+            net.load_state_dict(sd)
+            net = net.to(dev)
+            net.set_compute_dtype("bf16")
+            net.train()
+            net.freeze_bn()
+            if on:
+                with torch.no_grad():
+                    S = net._engine.forward(net._tensor_dict(), img.to(dev), save=True)[2]
+                acts = net._engine.relu_outputs(S)
+                missing = [n for n, t in acts.items() if getattr(t, "_rn_sign", None) is None]
+                assert not missing, missing
+            losses = net([img.to(dev), ann.to(dev)])
+            sum(l.mean() for l in losses).backward()
+            out[on] = ([float(l.detach()) for l in losses], {n: p.grad.clone() for n, p in net.named_parameters()})
+        assert out[True][0] == out[False][0]
+        for n, g in out[True][1].items():
+            h = out[False][1][n]
+            assert float((g - h).double().norm()) <= 1e-6 * float(h.double().norm()) + 1e-30, n
+    finally:
+        conv.BITMASKS, conv.BITMASKS_BF16 = before
