@@ -244,7 +244,8 @@ typedef struct rn_conv_desc {
     int act;                       /* 0 none, 1 ReLU, 2 sigmoid */
     int add_mode;                  /* 0 none, 1 same geometry, 2 nearest-upsample x2 */
     int Ha, Wa;
-    int mask_mode;                 /* 0 none, 1 before the add, 2 after the activation */
+    int mask_mode;                 /* 0 none, 1 before the add, 2 after the activation; | RN_MASK_BITS (4): `mask` points to the
+                                      masking tensor's SIGN BITS (see sign_out below) instead of the tensor */
     int in_relu;                   /* ReLU applied to x on load */
     int os, oo_h, oo_w, Hy, Wy;    /* output pixel (oh,ow) is stored at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
                                       tensor (os = 1, offsets 0, Hy = Ho, Wy = Wo: dense).  add (mode 1) and mask

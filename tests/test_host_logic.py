@@ -147,3 +147,29 @@ def test_data_parallel_checkpoint_keys_load_without_their_prefix():
     part = collections.OrderedDict((k, v) for k, v in dp.items() if k.startswith("module.layer1."))
     res = net.load_state_dict(part, strict=False)
     assert not res.unexpected_keys and res.missing_keys
+
+
+def test_run_time_options_are_read_once_and_range_checked():
+    """rn_get_option / rn_set_option (include/retinanet_mi355x.h: RN_OPT_*): defaults, the environment read at first use only (the launch
+    paths never call getenv), values outside an option's range refused.  No GPU needed: host-side state of the library."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ["RN_MF16_MIN"] = "7"
+from retinanet_mi355x import _hip, conv
+lib = _hip.load()
+assert conv.get_option(conv.OPT_MF16) == 1 and conv.get_option(conv.OPT_PERSIST) == 0 and conv.get_option(conv.OPT_BIG_TILE) == 0
+assert conv.get_option(conv.OPT_WGRAD_ONCE) == 1 and conv.get_option(conv.OPT_SPLITK) == 1 and conv.get_option(conv.OPT_DETERMINISTIC) == 0
+assert conv.get_option(conv.OPT_MF16_MIN) == 7                      # from the environment, at first use
+os.environ["RN_MF16_MIN"] = "9"
+assert conv.get_option(conv.OPT_MF16_MIN) == 7                      # ... and never again
+conv.set_option(conv.OPT_MF16_MIN, 3)
+assert conv.get_option(conv.OPT_MF16_MIN) == 3
+conv.set_option(conv.OPT_BIG_TILE, 3)
+assert lib.rn_set_option(conv.OPT_BIG_TILE, 4) != 0 and conv.get_option(conv.OPT_BIG_TILE) == 3      # out of range: refused, unchanged
+assert lib.rn_set_option(conv.OPT_MF16, 2) != 0 and lib.rn_set_option(99, 1) != 0 and lib.rn_get_option(99) == -1
+assert lib.rn_set_option(conv.OPT_PERSIST_WGS, -1) != 0
+print("ok")
+''' % PKG
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr[-2000:])
