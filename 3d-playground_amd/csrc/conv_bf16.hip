@@ -435,6 +435,30 @@ __global__ __launch_bounds__(64 * WM * WN, TM == 4 ? 2 : BF_OCC) void conv_igemm
                                        reinterpret_cast<const __bf16 *>(add), reinterpret_cast<const __bf16 *>(mask), tile - first);
 }
 
+// The eight-wave 256 x 256 x 64 tile with the phased K loop (conv_bf16_p8.hip) for stride-1 same-size layers.
+bool rn_bf16_p8_legal(const rn_conv_desc *d, int y_is_f32);
+int rn_bf16_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift,
+                      const void *add, const void *mask, hipStream_t stream);
+int rn_bf16_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, hipStream_t stream);
+// RN_OPT_BF16_P8: 0 never, 2 wherever legal, 1 (default): full 256-channel tiles (Cout % 256 == 0), a reduction of at least 1024
+// (RN_BF16_P8_MIN_K) and at least 200 tiles in the launch (RN_BF16_P8_MIN_TILES; one workgroup per CU: below ~a round of the 256 CUs the
+// 128 x 128 tile's four workgroups per CU win).  Measured per layer shape in profiles/r04_bf16_p8_by_shape.txt.
+static inline bool bf16_p8_pick(const rn_conv_desc *d, int y_is_f32, int64_t tiles_in_launch) {
+    const int mode = rn_get_option(RN_OPT_BF16_P8);
+    if (mode == 0 || !rn_bf16_p8_legal(d, y_is_f32)) return false;
+    if (mode == 2) return true;
+    static const int min_k = [] { const char *e = getenv("RN_BF16_P8_MIN_K"); return e ? atoi(e) : 1024; }();
+    static const int min_tiles = [] { const char *e = getenv("RN_BF16_P8_MIN_TILES"); return e ? atoi(e) : 200; }();
+    return (d->Cout & 255) == 0 && d->kh * d->kw * d->Cin >= min_k && tiles_in_launch >= min_tiles;
+}
+static inline bool bf16_group_is_p8(const rn_conv_group *g, int y_is_f32) {
+    int64_t t = 0;
+    for (int i = 0; i < g->n; ++i) t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 255) / 256);
+    for (int i = 0; i < g->n; ++i)
+        if (!bf16_p8_pick(&g->d[i], y_is_f32, t)) return false;
+    return true;
+}
+
 static inline bool bf16_desc_is_dense(const rn_conv_desc *d) {
     return d->os == 1 && d->oo_h == 0 && d->oo_w == 0 && d->Hy == d->Ho && d->Wy == d->Wo &&
            d->y_batch_stride == (int64_t)d->Ho * d->Wo * d->Cout && d->add_mode != 2 &&
@@ -507,6 +531,7 @@ static inline bool bf16_group_is_tall(const rn_conv_group *g, int y_is_f32) {
 // (tile_end[i] = running sum of ceil(N*Ho*Wo / rows) * ceil(Cout / cols)).  Returns rows * 1000 + cols.
 extern "C" int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32) {
     if (g->n < 1 || g->n > RN_MAX_GROUP) return 0;
+    if (bf16_group_is_p8(g, y_is_f32)) return 256 * 1000 + 256;
     if (bf16_tile_is_big(g, y_is_f32)) return 256 * 1000 + 256;
     if (bf16_group_is_tall(g, y_is_f32)) return 256 * 1000 + 128;
     return 128 * 1000 + 128;
@@ -516,8 +541,9 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
                                           const float *shift, void *stream) {
     if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const rn_conv_desc &d0 = g->d[0];
-    const bool big = bf16_tile_is_big(g, y_is_f32);          // the caller's tile_end must follow rn_conv_igemm_bf16_tile_rows()
-    const bool tall = bf16_group_is_tall(g, y_is_f32);
+    const bool p8 = bf16_group_is_p8(g, y_is_f32);
+    const bool big = p8 || bf16_tile_is_big(g, y_is_f32);    // the caller's tile_end must follow rn_conv_igemm_bf16_tile_rows()
+    const bool tall = !p8 && bf16_group_is_tall(g, y_is_f32);
     const int TR = big ? 256 : 128, TRM = (big || tall) ? 256 : 128;
     int prev = 0;
     for (int i = 0; i < g->n; ++i) {
@@ -535,6 +561,7 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
     const __bf16 *wb = reinterpret_cast<const __bf16 *>(w_packed);
     bool dense = true;
     for (int i = 0; i < g->n; ++i) dense = dense && bf16_desc_is_dense(&g->d[i]);
+    if (p8) return rn_bf16_p8_launch_grouped(g, prev, w_packed, scale, shift, (hipStream_t)stream);
     if (big) {
         const dim3 grid((unsigned)prev), block(1024);
         hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 4, 4, false>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
@@ -556,6 +583,8 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     const int rp = check_ptrs_bf16(d, x, y, add, mask, y_is_f32);
     if (rp || ((uintptr_t)w_packed & 15)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    if (bf16_p8_pick(d, y_is_f32, ((M + 255) / 256) * ((d->Cout + 255) / 256)))
+        return rn_bf16_p8_launch(d, x, w_packed, y, scale, shift, add, mask, (hipStream_t)stream);
     const bool big = bf16_big_tile(((M + 255) / 256) * ((d->Cout + 255) / 256), d->Cout, d->kh * d->kw * d->Cin, y_is_f32);
     // 256 x 128 tile (4 waves of 128 x 64, two workgroups per CU): 85 FLOP per staged byte instead of 64, for dense bf16
     // results with a long K loop and enough tiles (RN_BF16_TALL_TILE=0 turns it off, =1 forces it where it is legal)

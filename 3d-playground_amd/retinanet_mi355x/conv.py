@@ -193,7 +193,7 @@ def _w_operand(w_packed):
 
 # RN_OPT_* of include/retinanet_mi355x.h
 OPT_SPLITK, OPT_DETERMINISTIC, OPT_MF16, OPT_MF16_MIN, OPT_MF16_NARROW, OPT_BIG_TILE, OPT_BIG_TILE_MIN, OPT_WGRAD_ONCE, \
-    OPT_PERSIST, OPT_PERSIST_MAX_K, OPT_PERSIST_WGS = range(11)
+    OPT_PERSIST, OPT_PERSIST_MAX_K, OPT_PERSIST_WGS, OPT_BF16_P8 = range(12)
 
 
 def set_option(option, value):

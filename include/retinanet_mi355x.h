@@ -305,7 +305,9 @@ int rn_set_fp32_mfma(int mode);
  *                         (profiles/r04_persist_analysis.txt): opt-in, kept with its parity tests.
  *   RN_OPT_PERSIST_MAX_K  (RN_PERSIST_MAX_K, >= 0, default 640)  longest reduction Cin that takes that form.
  *   RN_OPT_PERSIST_WGS    (RN_PERSIST_WGS, >= 0, default 0 = two per CU)  workgroups of a persistent launch (rounded up to a multiple
- *                         of 8); a launch takes the persistent form only when it has more tiles than that. */
+ *                         of 8); a launch takes the persistent form only when it has more tiles than that.
+ *   RN_OPT_BF16_P8        (RN_BF16_P8, 0..2, default 1)  the bf16 engine's stride-1 same-size convolutions on the eight-wave 256 x 256 x 64
+ *                         tile with the phased K loop (csrc/conv_bf16_p8.hip): 0 never, 1 where it measured faster, 2 wherever legal. */
 #define RN_OPT_SPLITK 0
 #define RN_OPT_DETERMINISTIC 1
 #define RN_OPT_MF16 2
@@ -317,7 +319,8 @@ int rn_set_fp32_mfma(int mode);
 #define RN_OPT_PERSIST 8
 #define RN_OPT_PERSIST_MAX_K 9
 #define RN_OPT_PERSIST_WGS 10
-#define RN_OPT_COUNT 11
+#define RN_OPT_BF16_P8 11
+#define RN_OPT_COUNT 12
 int rn_get_option(int option);
 int rn_set_option(int option, int value);
 /* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (64; environment RN_FP32_SPLIT_MIN_K);
