@@ -814,11 +814,24 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
         }
 }
 
+// The eight-wave 256 x 256 tile over 64-pixel K-tiles (conv_wgrad_bf16_p8.hip) for stride-1 same-size layers with Cin, Cout % 256 == 0.
+bool rn_wgrad_bf16_p8_legal(int ldy, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad);
+int rn_wgrad_bf16_p8_launch(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int H, int W, int Cin, int Cout,
+                            int k, int pad, hipStream_t stream);
+
 extern "C" int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi,
                                   int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 8 || (Cin & 7) || (ldy & 7) || ldy < Cout)
         return RN_EINVAL;
     if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return RN_EINVAL;
+    // The 256 x 256 form (conv_wgrad_bf16_p8.hip) is correct and SLOWER than this kernel on every layer but one (head tower 3x3:
+    // 0.51 ms against 0.40; profiles/r04_wgrad_p8_knockouts.txt has the breakdown): it runs only where RN_OPT_BF16_P8 = 2 forces it
+    // (its parity tests) or RN_WGRAD_P8=1 asks for it.
+    {
+        static const int wp8_env = [] { const char *e = getenv("RN_WGRAD_P8"); return e ? atoi(e) : 0; }();
+        if ((rn_get_option(RN_OPT_BF16_P8) == 2 || wp8_env == 1) && rn_wgrad_bf16_p8_legal(ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad))
+            return rn_wgrad_bf16_p8_launch(dy, ldy, x, dw, colsum, N, Hi, Wi, Cin, Cout, kh, pad, (hipStream_t)stream);
+    }
     WgradBf16Args a;
     a.dy = reinterpret_cast<const __bf16 *>(dy); a.x = reinterpret_cast<const __bf16 *>(x); a.dw = dw; a.colsum = colsum; a.ldy = ldy;
     a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;

@@ -18,6 +18,8 @@
 //   * epilogue straight from the accumulators: v_permlane16_swap pairs the two 16-channel blocks of a lane's row so that a lane holds
 //     eight consecutive channels -- 16-byte loads of the addend / mask and 16-byte stores, as in conv_bf16.hip.
 // Roofline: MFMA (2.5 PFLOP/s dense bf16).  Algorithmic bytes per tile: (256 + 256) rows x 128 B per K-tile from L2, 128 KB stored.
+#include <type_traits>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -30,6 +32,9 @@ constexpr int P8_BUFB = 2 * P8_OPB;              // one K-tile: pixels' rows, th
 constexpr int P8_LDS = 2 * P8_BUFB;              // 128 KB (dynamic)
 __device__ __forceinline__ int p8_swz(int r) { return (r >> 1) & 7; }
 
+#ifndef P8_STAGGER
+#define P8_STAGGER 0                             // experiments (profiles/r04_bf16_p8_stagger.txt): 1 = the wr = 1 waves sleep after each barrier, 2 = they issue MFMAs first
+#endif
 #ifndef P8_ABL
 #define P8_ABL 0                                 // knock-outs for profiles/ (bits): 1 no epilogue, 2 no validity test, 4 no staging after the prologue
 #endif
@@ -237,7 +242,7 @@ __device__ __forceinline__ void p8_tile(const rn_conv_desc &d, const __bf16 *__r
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    P8Tap t2 = t1;                                              // t1: the tap of K-tile t + 1, t2: of K-tile t + 2 (in body(t))
+    P8Tap t2 = t1;                                              // the tap of K-tile t + 2 (in body(t))
     next_tap(t2);
     asm volatile("s_barrier" ::: "memory");
     read_a(fa0, lds, 0);
@@ -248,31 +253,61 @@ __device__ __forceinline__ void p8_tile(const rn_conv_desc &d, const __bf16 *__r
     // pixel set 1 -- loads the NEXT tile's pixel set 0 and its weight quadrant qy into the y set: the next tile starts from (0, y).
     // Before the barrier of tile t every fragment of the tile is in registers and tile t + 1 has been requested completely (its last
     // instruction a phase ago); after it buffer t & 1 is free for tile t + 2 and buffer (t + 1) & 1 is readable.
-    auto body = [&](const int t, bf16x8 (&fbx)[2][2], bf16x8 (&fby)[2][2], const int qx, const int qy) {
+    auto body = [&](auto late_tag, const int t, bf16x8 (&fbx)[2][2], bf16x8 (&fby)[2][2], const int qx, const int qy) {
+        constexpr bool LATE = decltype(late_tag)::value;        // P8_STAGGER 2: the wr = 1 waves issue a phase's MFMAs BEFORE its reads / staging
         const char *S = lds + (t & 1) * P8_BUFB;
         const char *Sn = lds + ((t + 1) & 1) * P8_BUFB;
-        const bool more = t + 1 < nkt, pre = t > 0 && more && !(P8_ABL & 4);
-        read_b(fby, S, qy);
+        const bool more = t + 1 < nkt, stage = t + 2 < nkt && !(P8_ABL & 4);
+        if (!LATE) read_b(fby, S, qy);
         mma(fa0, fbx, 0, qx);
-        if (pre) { dma(3, t1, t + 1, (t + 1) & 1); dma(4, t1, t + 1, (t + 1) & 1); dma(5, t1, t + 1, (t + 1) & 1); }
-        read_a(fa1, S, 1);
+        if (LATE) { __builtin_amdgcn_sched_barrier(0); read_b(fby, S, qy); }
+        if (!LATE) read_a(fa1, S, 1);
         mma(fa0, fby, 0, qy);
-        if (pre) { dma(6, t1, t + 1, (t + 1) & 1); dma(7, t1, t + 1, (t + 1) & 1); }
+        if (LATE) { __builtin_amdgcn_sched_barrier(0); read_a(fa1, S, 1); }
         mma(fa1, fby, 1, qy);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        if (more) {
+        if (P8_STAGGER == 1 && wr) __builtin_amdgcn_s_sleep(2);
+        if (!LATE && more) {
             read_a(fa0, Sn, 0);
             read_b(fby, Sn, qy);
         }
-        mma(fa1, fbx, 1, qx);
-        if (t + 2 < nkt && !(P8_ABL & 4)) { dma(0, t2, t + 2, t & 1); dma(1, t2, t + 2, t & 1); dma(2, t2, t + 2, t & 1); }
-        t1 = t2;
+        // the last quadrant, with the WHOLE staging of K-tile t + 2 (its buffer was released by the barrier) between its MFMAs: one
+        // instruction per two MFMAs, so that every load has the three phases of K-tile t + 1 to land in (spread over phases 0, 1 and 3 as
+        // at first, the last ones had a single phase: -24 % with the staging knocked out, profiles/r04_bf16_p8_knockouts.txt)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int kh = g >> 2, i = g & 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[4 + i][2 * qx + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbx[j][kh], fa1[i][kh], acc[4 + i][2 * qx + j], 0, 0, 0);
+            if (!LATE && stage) dma(g, t2, t + 2, t & 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                read_a(fa0, Sn, 0);
+                read_b(fby, Sn, qy);
+            }
+            if (stage) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) dma(g, t2, t + 2, t & 1);
+            }
+        }
         next_tap(t2);
     };
-    for (int t = 0; t < nkt; t += 2) {
-        body(t, fb0, fb1, 0, 1);
-        if (t + 1 < nkt) body(t + 1, fb1, fb0, 1, 0);
+    if (P8_STAGGER == 2 && wr) {
+        for (int t = 0; t < nkt; t += 2) {
+            body(std::true_type{}, t, fb0, fb1, 0, 1);
+            if (t + 1 < nkt) body(std::true_type{}, t + 1, fb1, fb0, 1, 0);
+        }
+    } else {
+        for (int t = 0; t < nkt; t += 2) {
+            body(std::false_type{}, t, fb0, fb1, 0, 1);
+            if (t + 1 < nkt) body(std::false_type{}, t + 1, fb1, fb0, 1, 0);
+        }
     }
 
     // ---- epilogue (p8_epilogue)

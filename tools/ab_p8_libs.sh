@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of hand-built libraries (csrc/build_ab/*.so against the tree's) on the eight-wave bf16 kernel's shapes: bash tools/ab_p8_libs.sh lib1 lib2 ...
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/p8
+for rep in 1 2; do
+for n in tree "$@"; do
+  lib=$PWD/3d-playground_amd/csrc/build_ab/$n.so
+  [ $n = tree ] && lib=$PWD/3d-playground_amd/retinanet_mi355x/lib/libretinanet_mi355x.so
+  echo "== $n"
+  RN_LIB_PATH=$lib RN_BF16_P8=2 timeout -k 10 200 python3 tools/bench_conv_bf16.py --no-fp32 --only "3x3 256" 2>&1 | grep -E "fprop|dgrad" || exit 1
+done
+done
