@@ -377,6 +377,36 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_fp8_grouped_kernel(const rn
                               reinterpret_cast<const unsigned char *>(add), fa_, tile - first);
 }
 
+// The eight-wave 256 x 256 x 128 tile with the phased K loop (conv_fp8_p8.hip) for stride-1 same-size layers.
+bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32);
+int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift, const void *add,
+                     float add_scale, float out_inv_scale, hipStream_t stream);
+int rn_fp8_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, float add_scale,
+                             float out_inv_scale, hipStream_t stream);
+// RN_OPT_FP8_P8: 0 never, 1 (default) and 2: wherever legal -- on BASELINE configs[4]'s layers it is faster or equal on every shape it
+// can compute, the short reductions and partial channel tiles included (profiles/r04_fp8_p8_by_shape.txt: 1x1 256 -> 1024 2.4x,
+// 3x3 256 -> 256 1.6x, the whole forward pass 35.6 -> 24.5 ms).  RN_FP8_P8_MIN_K / RN_FP8_P8_MIN_TILES restrict mode 1 for A/B runs.
+static inline bool fp8_p8_pick(const rn_conv_desc *d, int y_is_f32, int64_t tiles_in_launch) {
+    const int mode = rn_get_option(RN_OPT_FP8_P8);
+    if (mode == 0 || !rn_fp8_p8_legal(d, y_is_f32)) return false;
+    if (mode == 2) return true;
+    static const int min_k = [] { const char *e = getenv("RN_FP8_P8_MIN_K"); return e ? atoi(e) : 0; }();
+    static const int min_tiles = [] { const char *e = getenv("RN_FP8_P8_MIN_TILES"); return e ? atoi(e) : 0; }();
+    return d->kh * d->kw * d->Cin >= min_k && tiles_in_launch >= min_tiles;
+}
+static inline bool fp8_group_is_p8(const rn_conv_group *g, int y_is_f32) {
+    int64_t t = 0;
+    for (int i = 0; i < g->n; ++i) t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 255) / 256);
+    for (int i = 0; i < g->n; ++i)
+        if (!fp8_p8_pick(&g->d[i], y_is_f32, t)) return false;
+    return true;
+}
+// Tile shape rn_conv_igemm_fp8_grouped will use for this group (rows * 1000 + cols): the caller builds tile_end with it.
+extern "C" int rn_conv_igemm_fp8_tile_rows(const rn_conv_group *g, int y_is_f32) {
+    if (g->n < 1 || g->n > RN_MAX_GROUP) return 0;
+    return fp8_group_is_p8(g, y_is_f32) ? 256 * 1000 + 256 : 128 * 1000 + 128;
+}
+
 static int check_desc_fp8(const rn_conv_desc *d, int y_is_f32) {
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return RN_EINVAL;
     if (d->Cin < 16 || (d->Cin & 15) || (d->Cout & (y_is_f32 ? 3 : 15)) || d->w_format != 0) return RN_EINVAL;
@@ -402,6 +432,8 @@ extern "C" int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const v
     if ((d->add_mode != 0) != (add_q != nullptr)) return RN_EINVAL;
     if (((uintptr_t)x_q & 15) || ((uintptr_t)w_q & 15) || ((uintptr_t)y & 15) || ((uintptr_t)add_q & 3)) return RN_EINVAL;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    if (!((uintptr_t)add_q & 15) && fp8_p8_pick(d, y_is_f32, ((M + 255) / 256) * ((d->Cout + 255) / 256)))
+        return rn_fp8_p8_launch(d, x_q, w_q, y, scale, shift, add_q, add_scale, out_inv_scale, (hipStream_t)stream);
     const int64_t tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
     if (tiles > 0x7fffffff) return RN_EINVAL;
     Fp8Args a;
@@ -422,6 +454,8 @@ extern "C" int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q
                                          float add_scale, float out_inv_scale, void *stream) {
     if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_q & 15)) return RN_EINVAL;
     const rn_conv_desc &d0 = g->d[0];
+    const bool p8 = fp8_group_is_p8(g, y_is_f32);               // the caller's tile_end must follow rn_conv_igemm_fp8_tile_rows()
+    const int TR = p8 ? 256 : 128;
     int prev = 0;
     for (int i = 0; i < g->n; ++i) {
         const rn_conv_desc &d = g->d[i];
@@ -429,12 +463,13 @@ extern "C" int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q
         if (rc) return rc;
         if (d.Cin != d0.Cin || d.Cout != d0.Cout || d.kh != d0.kh || d.kw != d0.kw || d.act != d0.act) return RN_EINVAL;
         if ((d.add_mode != 0) != (g->add[i] != nullptr)) return RN_EINVAL;
-        if (((uintptr_t)g->x[i] & 15) || ((uintptr_t)g->y[i] & 15) || ((uintptr_t)g->add[i] & 3)) return RN_EINVAL;
+        if (((uintptr_t)g->x[i] & 15) || ((uintptr_t)g->y[i] & 15) || ((uintptr_t)g->add[i] & (p8 ? 15 : 3))) return RN_EINVAL;
         const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
-        const int64_t tiles = ((M + 127) / 128) * ((d.Cout + 127) / 128);
+        const int64_t tiles = ((M + TR - 1) / TR) * ((d.Cout + TR - 1) / TR);
         if (g->tile_end[i] - prev != tiles) return RN_EINVAL;
         prev = g->tile_end[i];
     }
+    if (p8) return rn_fp8_p8_launch_grouped(g, prev, w_q, scale, shift, add_scale, out_inv_scale, (hipStream_t)stream);
     Fp8Args a;
     a.add_scale = add_scale;
     a.out_inv_scale = out_inv_scale;

@@ -1,0 +1,334 @@
+// fp8 (OCP e4m3fn) implicit-GEMM convolution, eight-wave 256 x 256 x 128 tile with a phased K loop (round 4) -- conv_bf16_p8.hip's
+// structure for the inference form of BASELINE configs[4] (conv_fp8.hip: the fprop of every convolution of the detector behind the fp32
+// stem, D/model.py:59-205, D/utils.py:12-80): the stride-1 same-size layers with Cin % 128 == 0.  Same rn_conv_desc, same e4m3 weights
+// and per-channel scales, same epilogue arithmetic as conv_fp8.hip; its launchers choose between the two (fp8_p8_pick).
+//
+// What changes against the bf16 form: a staged row is again 128 bytes, now 128 K values; the MFMA is
+// v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 2^0: the scaled form is the one at the fp8 rate), one per 16 x 16 block and K-tile,
+// 32 cycles each -- a K-tile is four phases of 8 MFMAs, the same ~1000 matrix-core cycles per wave between barriers at twice the math per
+// staged byte.  A lane's operand is 32 consecutive K values of row lane & 15 (K quarter lane >> 4): two ds_read_b128, chunks 2 q and
+// 2 q + 1 of the row's eight.  The bf16 kernel's chunk permutation is 2-way conflicting under that read; the one used here -- chunk c of
+// row r in slot c ^ s(r), s(r) = bit 2 of r | bit 1 of r << 2 -- was found by enumerating the linear permutations over the real service
+// groups of ds_read_b128 (MI355X_MICROARCH.md, LDS) and is conflict-free for both reads.
+// Epilogue: two exchange levels (v_permlane16_swap, then v_permlane32_swap) give a lane SIXTEEN consecutive channels of one pixel --
+// 16-byte e4m3 stores and addend loads, as in conv_fp8.hip.
+// Roofline: MFMA (~5 PFLOP/s dense fp8).
+#include "common.h"
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int Q8_BM = 256, Q8_BN = 256, Q8_BK = 128, Q8_ROWB = 128;
+constexpr int Q8_OPB = 256 * Q8_ROWB;            // bytes of one operand tile: 32 KB
+constexpr int Q8_BUFB = 2 * Q8_OPB;              // one K-tile: pixels' rows, then weights' rows
+constexpr int Q8_LDS = 2 * Q8_BUFB;              // 128 KB (dynamic)
+#define Q8_MAX 448.0f                            // largest finite e4m3fn
+__device__ __forceinline__ int q8_swz(int r) { return ((r >> 2) & 1) | (((r >> 1) & 1) << 2); }
+__device__ __forceinline__ float q8_clamp(float a) { return fminf(fmaxf(a, -Q8_MAX), Q8_MAX); }
+__device__ __forceinline__ int q8_pack4(float a, float b, float c, float d) {      // conv_fp8.hip: f8_pack4
+    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(q8_clamp(a), q8_clamp(b), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(q8_clamp(c), q8_clamp(d), lo, true);
+}
+
+struct Q8Tap { int r, s, c; };                   // filter row, filter column, first channel of a K-tile (wave-uniform)
+struct Q8Args { float add_scale, out_inv_scale; };   // conv_fp8.hip: Fp8Args
+
+// ---- epilogue: u = acc * scale[c] + shift[c]; u += add * add_scale; [ReLU]; y = e4m3(u * out_inv_scale) (conv_fp8.hip's arithmetic).
+// acc[rb][cb][e]: pixel row rb * 16 + lr, channel cb * 16 + 4 lg + e of the wave's 128 x 64.  Level 1 (conv_bf16_p8.hip): a lane holds
+// channels 8 k8 .. + 7 of block (2 pr + half), half = lg & 1, k8 = lg >> 1.  Level 2, v_permlane32_swap(X, Y) with X / Y the pr = 0 / 1
+// values (the upper 32 lanes of X change places with the lower 32 of Y): a lower lane (k8 = 0) then holds [own X, the X of lane + 32] =
+// channels 0 .. 15 of block `half`, an upper lane [the Y of lane - 32, own Y] = channels 0 .. 15 of block 2 + half.
+template <bool RELU, bool ADD>
+__device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_conv_desc &d, unsigned char *__restrict__ y,
+                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                            const unsigned char *__restrict__ add, const Q8Args qa, const int mw, const int nw, const int M,
+                                            const int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const int col_raw = nw + (2 * (lg >> 1) + (lg & 1)) * 16;
+    const bool col_ok = col_raw < d.Cout;                        // Cout % 16 == 0 (launcher): a chunk is inside or outside
+    const int col = col_ok ? col_raw : 0;                        // loads stay inside the tensors; nothing is stored
+    float sc[16], sh[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 s4 = (col_ok && scale != nullptr) ? *reinterpret_cast<const float4 *>(scale + col + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 h4 = (col_ok && shift != nullptr) ? *reinterpret_cast<const float4 *>(shift + col + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
+        sh[4 * q] = h4.x; sh[4 * q + 1] = h4.y; sh[4 * q + 2] = h4.z; sh[4 * q + 3] = h4.w;
+    }
+    const float is = qa.out_inv_scale;
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+        const int m = mw + rb * 16 + lr;
+        const bool row_ok = m < M;
+        const int64_t off = (int64_t)(row_ok ? m : M - 1) * d.Cout + col;
+        i32x4 aq = {0, 0, 0, 0};
+        if constexpr (ADD) aq = *reinterpret_cast<const i32x4 *>(add + off);
+        unsigned x1[2][8];                                       // level 1: [pr][8 channels]
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[rb][2 * pr][e]), __float_as_uint(acc[rb][2 * pr + 1][e]), false, false);
+                x1[pr][e] = r[0];
+                x1[pr][4 + e] = r[1];
+            }
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32x2 r = __builtin_amdgcn_permlane32_swap(x1[0][j], x1[1][j], false, false);
+            v[j] = __uint_as_float(r[0]);
+            v[8 + j] = __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float u = v[j] * sc[j] + sh[j];
+            if constexpr (ADD) {
+                const int word = aq[j >> 2];
+                const float a = (j & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8(word, 0) : (j & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8(word, 1)
+                              : (j & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8(word, 2) : __builtin_amdgcn_cvt_f32_fp8(word, 3);
+                u += a * qa.add_scale;
+            }
+            if constexpr (RELU) u = fmaxf(u, 0.f);
+            v[j] = u * is;
+        }
+        i32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = q8_pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if (row_ok && col_ok) *reinterpret_cast<i32x4 *>(y + off) = o;
+    }
+}
+
+__device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned char *__restrict__ x, const unsigned char *__restrict__ w,
+                                        unsigned char *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+                                        const unsigned char *__restrict__ add, const Q8Args qa, const int tile, char *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wr = wave >> 2, wc = wave & 3;     // rows wr * 128, columns wc * 64 of the tile
+    const int ntn = (d.Cout + Q8_BN - 1) / Q8_BN;
+    const int m0 = (tile / ntn) * Q8_BM, n0 = (tile % ntn) * Q8_BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int M = d.N * HoWo;                    // < 2^31 - 256 (launcher)
+    const int Cin = d.Cin, K = d.kh * d.kw * Cin, nkt = K / Q8_BK;
+
+    // descriptors.  Pixels: the flat [M][Cin] tensor from `halo` rows in front of the tile (the farthest a tap reaches back).
+    const int ab = d.b < 0 ? -d.b : d.b;
+    const int halo = ((d.p < 0 ? -d.p : d.p) + (d.kh - 1) * ab) * d.Wi + (d.p_w < 0 ? -d.p_w : d.p_w) + (d.kw - 1) * ab;
+    const int base_row = m0 > halo ? m0 - halo : 0;
+    const int64_t a_bytes = ((int64_t)M - base_row) * Cin;
+    const v4i32 rs_a = make_rsrc(x + (int64_t)base_row * Cin, (unsigned)(a_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : a_bytes));
+    const v4i32 rs_b = make_rsrc(w, (unsigned)((int64_t)d.Cout * K));
+    const unsigned lds0 = lds_addr(lds);
+
+    // ---- staging (conv_bf16_p8.hip): instruction i of this wave fills rows 64 (i & 3) + 8 wave + (lane >> 3) of the pixels (i < 4) or
+    // the weights; the swizzle of the row (its bits 1, 2) does not depend on i
+    const int row0 = 8 * wave + (lane >> 3);
+    const int chunk = (lane & 7) ^ q8_swz(row0);
+    const unsigned voff_a = (unsigned)((m0 - base_row + row0) * Cin + chunk * 16);
+    const unsigned voff_b = (unsigned)((n0 + row0) * K + chunk * 16);       // rows past Cout: past the descriptor's range
+    unsigned pk = 0;                             // bits 8 j + r: filter row r of pixel row j reads inside the image; 8 j + 4 + s: column s
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + row0 + 64 * j;
+        if (m < M) {
+            const unsigned rem = (unsigned)m % (unsigned)HoWo;
+            const int oh = (int)(rem / (unsigned)d.Wo), ow = (int)(rem - (unsigned)oh * (unsigned)d.Wo);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < d.kh && (unsigned)(oh + d.p + t * d.b) < (unsigned)d.Hi) pk |= 1u << (8 * j + t);
+                if (t < d.kw && (unsigned)(ow + d.p_w + t * d.b) < (unsigned)d.Wi) pk |= 1u << (8 * j + 4 + t);
+            }
+        }
+    }
+    auto uni = [](const v4i32 r) {
+        v4i32 o;
+        o.x = __builtin_amdgcn_readfirstlane(r.x); o.y = __builtin_amdgcn_readfirstlane(r.y);
+        o.z = __builtin_amdgcn_readfirstlane(r.z); o.w = __builtin_amdgcn_readfirstlane(r.w);
+        return o;
+    };
+    // instruction i of this wave for K-tile kt (at tap tp).  live = false (past the last K-tile): every lane sends the out-of-range
+    // offset -- zeros into a buffer nobody reads -- instead of a branch around the instruction: with branches in the K loop the compiler
+    // sank the MFMAs of three phases below them (every operand live at once, nine accumulators spilled)
+    auto dma = [&](const int i, const Q8Tap &tp, const int kt, const int buf, const bool live) {
+        const unsigned dst = lds0 + (unsigned)(buf * Q8_BUFB + (wave_u + 8 * i) * 1024);
+        if (i < 4) {
+            const int sh = __builtin_amdgcn_readfirstlane(((d.p + tp.r * d.b) * d.Wi + d.p_w + tp.s * d.b + 64 * i) * Cin + tp.c);
+            const unsigned ok = (pk >> (8 * i + (tp.r & 3))) & (pk >> (8 * i + 4 + (tp.s & 3))) & (live ? 1u : 0u);
+            dma16(uni(rs_a), dst, ok ? voff_a + (unsigned)sh : 0x80000000u, 0u);
+        } else {
+            dma16(uni(rs_b), dst, live ? voff_b : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane(live ? kt * Q8_BK + (i - 4) * 64 * K : 0));
+        }
+    };
+    auto next_tap = [&](Q8Tap &tp) {
+        tp.c += Q8_BK;
+        if (tp.c == Cin) { tp.c = 0; if (++tp.s == d.kw) { tp.s = 0; ++tp.r; } }
+    };
+
+    // ---- fragments: block (16 rows) of this wave's 128 pixel rows / 64 weight rows; the lane's 32 K values = chunks 2 lg, 2 lg + 1
+    const int lr = lane & 15, lg = lane >> 4;
+    const int ra = wr * 128 + lr, rbb = wc * 64 + lr;
+    int a_ad[2], b_ad[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        a_ad[e] = ra * Q8_ROWB + 16 * ((2 * lg + e) ^ q8_swz(ra));
+        b_ad[e] = Q8_OPB + rbb * Q8_ROWB + 16 * ((2 * lg + e) ^ q8_swz(rbb));
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Operand registers: ALL weight fragments of the K-tile (B0 / B1: 32 rows each) and the pixel fragments in four groups of 32 rows
+    // through two sets -- 64 registers.  (The bf16 kernel's scheme, two 64-row pixel sets and two weight sets = 96, does not fit here:
+    // the 8-register operands of this MFMA fragment the file, and nine accumulators spilled.)
+    i32x8 A[2][2], B0[2], B1[2];
+    auto rd = [&](const char *S, const int (&ad)[2], int blk) {
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(S + ad[0] + blk * 2048), hi = *reinterpret_cast<const i32x4 *>(S + ad[1] + blk * 2048);
+        return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto read_a = [&](i32x8 (&f)[2], const char *S, int g) {     // pixel rows 32 g .. 32 g + 31 of the wave's 128
+        f[0] = rd(S, a_ad, 2 * g);
+        f[1] = rd(S, a_ad, 2 * g + 1);
+    };
+    auto read_b = [&](i32x8 (&f)[2], const char *S, int q) {     // weight rows 32 q .. 32 q + 31 of the wave's 64
+        f[0] = rd(S, b_ad, 2 * q);
+        f[1] = rd(S, b_ad, 2 * q + 1);
+    };
+    const int one = 0x7F7F7F7F;                                  // E8M0 block scales: 2^0 in every byte
+    // weight fragment first: a lane then holds 4 consecutive channels of one pixel
+    auto mma = [&](const i32x8 (&fa)[2], const i32x8 (&fb)[2], int g, int q) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[2 * g + i][2 * q + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[2 * g + i][2 * q + j], 0, 0, 0, one, 0, one);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);                       // phases stay in this order (the reads of all of them in front of the
+    };                                                           // MFMAs of all of them is what the compiler prefers)
+
+    // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1 (all 8 instructions each); wait for tile 0, read its first fragments
+    Q8Tap t2 = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma(i, t2, 0, 0, true);
+    next_tap(t2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma(i, t2, 1, 1, nkt > 1);
+    next_tap(t2);                                                // now the tap of K-tile t + 2 (in iteration t)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    read_a(A[0], lds, 0);
+    read_b(B0, lds, 0);
+
+    // ---- main loop: K-tile t in buffer t & 1, eight phases of 4 MFMAs = (pixel group g, weight half): (0,0) (0,1) (1,0) (1,1) .. (3,0)
+    // | barrier | (3,1).  A phase's operands are read one or two phases ahead; the last read of the buffer (group 3) is consumed by phase
+    // (3,0), so at the barrier every read of it has returned and K-tile t + 1 has landed; phase (3,1) then reads the next K-tile's first
+    // operands and restages the buffer for K-tile t + 2 between its MFMAs.
+    for (int t = 0; t < nkt; ++t) {
+        const char *S = lds + (t & 1) * Q8_BUFB;
+        const char *Sn = lds + ((t + 1) & 1) * Q8_BUFB;
+        const bool stage = t + 2 < nkt;
+        read_b(B1, S, 1);
+        mma(A[0], B0, 0, 0);
+        read_a(A[1], S, 1);
+        mma(A[0], B1, 0, 1);
+        mma(A[1], B0, 1, 0);
+        read_a(A[0], S, 2);
+        mma(A[1], B1, 1, 1);
+        mma(A[0], B0, 2, 0);
+        read_a(A[1], S, 3);
+        mma(A[0], B1, 2, 1);
+        mma(A[1], B0, 3, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        read_b(B0, Sn, 0);                                       // after the last K-tile: stale bytes nobody uses (a conditional read costs
+        read_a(A[0], Sn, 0);                                     // copies of the 8-register operands at the join)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = g >> 1, j = g & 1;
+            acc[6 + i][2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B1[j], A[1][i], acc[6 + i][2 + j], 0, 0, 0, one, 0, one);
+            dma(2 * g, t2, t + 2, t & 1, stage);
+            dma(2 * g + 1, t2, t + 2, t & 1, stage);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        next_tap(t2);
+    }
+
+    const bool relu = d.act == 1, has_add = d.add_mode == 1;
+#define Q8_EPI(RELU, ADD) q8_epilogue<RELU, ADD>(acc, d, y, scale, shift, add, qa, m0 + wr * 128, n0 + wc * 64, M, lane)
+    if (has_add) { if (relu) Q8_EPI(true, true); else Q8_EPI(false, true); }
+    else { if (relu) Q8_EPI(true, false); else Q8_EPI(false, false); }
+#undef Q8_EPI
+}
+
+__global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
+                                                                  const unsigned char *__restrict__ w, unsigned char *__restrict__ y,
+                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                  const unsigned char *__restrict__ add, const Q8Args qa) {
+    extern __shared__ __attribute__((aligned(16))) char q8_lds[];
+    q8_tile(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), q8_lds);
+}
+
+// Grouped launch (rn_conv_igemm_fp8_grouped): the pyramid levels of a head layer as ONE grid; a workgroup finds its problem by tile id.
+__global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_grouped_kernel(const rn_conv_group g, const unsigned char *__restrict__ w,
+                                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                          const Q8Args qa) {
+    extern __shared__ __attribute__((aligned(16))) char q8_lds[];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int first = p > 0 ? g.tile_end[p - 1] : 0;
+    q8_tile(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
+            reinterpret_cast<const unsigned char *>(g.add[p]), qa, tile - first, q8_lds);
+}
+
+// ---------------------------------------------------------------------------------------------- host side (used by conv_fp8.hip)
+// What the kernel can compute: a stride-1 convolution whose output plane is the input plane, batch-dense NHWC operands, Cin a multiple of
+// the 128-channel K-tile, at most 4 x 4 taps, a dense e4m3 result, no sigmoid, no upsampled addend.
+bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32) {
+    if (y_is_f32 || d->a != 1 || d->div_shift != 0 || d->Hi != d->Ho || d->Wi != d->Wo || d->act == 2) return false;
+    if (d->Cin < 128 || (d->Cin & 127) || (d->Cout & 15) || d->kh > 4 || d->kw > 4) return false;
+    const int64_t plane = (int64_t)d->Hi * d->Wi;
+    if (d->x_batch_stride != plane * d->Cin || d->y_batch_stride != plane * d->Cout) return false;
+    if (d->os != 1 || d->oo_h != 0 || d->oo_w != 0 || d->Hy != d->Ho || d->Wy != d->Wo || d->add_mode == 2) return false;
+    if (d->add_mode == 1 && d->add_batch_stride != d->y_batch_stride) return false;
+    const int64_t K = (int64_t)d->kh * d->kw * d->Cin, M = (int64_t)d->N * plane;
+    const int64_t ab = d->b < 0 ? -d->b : d->b;
+    const int64_t halo = (llabs((long long)d->p) + (d->kh - 1) * ab) * d->Wi + llabs((long long)d->p_w) + (d->kw - 1) * ab;
+    if (M + 256 > 0x7fffffffLL || (256 + 2 * halo + 64) * d->Cin > 0x7fffffffLL || ((int64_t)d->Cout + 256) * K > 0x7fffffffLL) return false;
+    return true;
+}
+int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift, const void *add,
+                     float add_scale, float out_inv_scale, hipStream_t stream) {
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    const int64_t tiles = ((M + 255) / 256) * ((d->Cout + 255) / 256);
+    if (tiles > 0x7fffffff) return RN_EINVAL;
+    Q8Args qa;
+    qa.add_scale = add_scale;
+    qa.out_inv_scale = out_inv_scale;
+    hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, reinterpret_cast<const unsigned char *>(x),
+                       reinterpret_cast<const unsigned char *>(w), reinterpret_cast<unsigned char *>(y), scale, shift,
+                       reinterpret_cast<const unsigned char *>(add), qa);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+int rn_fp8_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, float add_scale,
+                             float out_inv_scale, hipStream_t stream) {
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    Q8Args qa;
+    qa.add_scale = add_scale;
+    qa.out_inv_scale = out_inv_scale;
+    hipLaunchKernelGGL(conv_igemm_fp8_p8_grouped_kernel, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *g, reinterpret_cast<const unsigned char *>(w),
+                       scale, shift, qa);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

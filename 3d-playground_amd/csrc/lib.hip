@@ -55,7 +55,7 @@ static const struct { const char *env; int dflt, max; } g_opt_def[RN_OPT_COUNT] 
     {"RN_SPLITK", 1, 1},        {"RN_DETERMINISTIC", 0, 1},  {"RN_MF16", 1, 1},         {"RN_MF16_MIN", 1, INT_MAX},
     {"RN_MF16_NARROW", 0, 1},   {"RN_BIG_TILE", 0, 3},       {"RN_BIG_TILE_MIN", 200, INT_MAX}, {"RN_WGRAD_ONCE", 1, 1},
     {"RN_PERSIST", 0, 1},       {"RN_PERSIST_MAX_K", 640, INT_MAX}, {"RN_PERSIST_WGS", 0, 1 << 20},
-    {"RN_BF16_P8", 1, 2},
+    {"RN_BF16_P8", 1, 2},       {"RN_FP8_P8", 1, 2},
 };
 extern "C" int rn_get_option(int option) {
     if (option < 0 || option >= RN_OPT_COUNT) return -1;

@@ -193,7 +193,7 @@ def _w_operand(w_packed):
 
 # RN_OPT_* of include/retinanet_mi355x.h
 OPT_SPLITK, OPT_DETERMINISTIC, OPT_MF16, OPT_MF16_MIN, OPT_MF16_NARROW, OPT_BIG_TILE, OPT_BIG_TILE_MIN, OPT_WGRAD_ONCE, \
-    OPT_PERSIST, OPT_PERSIST_MAX_K, OPT_PERSIST_WGS, OPT_BF16_P8 = range(12)
+    OPT_PERSIST, OPT_PERSIST_MAX_K, OPT_PERSIST_WGS, OPT_BF16_P8, OPT_FP8_P8 = range(13)
 
 
 def set_option(option, value):
@@ -828,12 +828,13 @@ def conv_igemm_fp8_grouped(problems, wq, scale, shift=None, act=ACT_NONE, out_sc
     for i, pr in enumerate(problems):
         x = pr["x"]
         assert x.dtype == torch.uint8 and (pr["y"].dtype == torch.float32) == yf32
-        d = _make_desc(x, pr["geom"], act, 0, (0, 0), 0, False, None, pr.get("y_batch_stride"), None, None)
-        g.d[i] = d
-        M = d.N * d.Ho * d.Wo
-        total += ((M + 127) // 128) * ((d.Cout + 127) // 128)
-        g.tile_end[i] = total
+        g.d[i] = _make_desc(x, pr["geom"], act, 0, (0, 0), 0, False, None, pr.get("y_batch_stride"), None, None)
         g.x[i], g.y[i], g.add[i], g.mask[i] = x.data_ptr(), pr["y"].data_ptr(), None, None
+    trm, trn = divmod(lib.rn_conv_igemm_fp8_tile_rows(ctypes.byref(g), int(yf32)), 1000)    # the launcher's tile for this group
+    for i in range(g.n):
+        d = g.d[i]
+        total += ((d.N * d.Ho * d.Wo + trm - 1) // trm) * ((d.Cout + trn - 1) // trn)
+        g.tile_end[i] = total
     kind = "conv_igemm_fp8" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_fp8_grouped(
         ctypes.byref(g), wq.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), 1.0, 1.0 / float(out_scale), _hip.stream()))

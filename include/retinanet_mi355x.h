@@ -307,7 +307,8 @@ int rn_set_fp32_mfma(int mode);
  *   RN_OPT_PERSIST_WGS    (RN_PERSIST_WGS, >= 0, default 0 = two per CU)  workgroups of a persistent launch (rounded up to a multiple
  *                         of 8); a launch takes the persistent form only when it has more tiles than that.
  *   RN_OPT_BF16_P8        (RN_BF16_P8, 0..2, default 1)  the bf16 engine's stride-1 same-size convolutions on the eight-wave 256 x 256 x 64
- *                         tile with the phased K loop (csrc/conv_bf16_p8.hip): 0 never, 1 where it measured faster, 2 wherever legal. */
+ *                         tile with the phased K loop (csrc/conv_bf16_p8.hip): 0 never, 1 where it measured faster, 2 wherever legal.
+ *   RN_OPT_FP8_P8         (RN_FP8_P8, 0..2, default 1)  the same for the fp8 inference engine (csrc/conv_fp8_p8.hip, 256 x 256 x 128). */
 #define RN_OPT_SPLITK 0
 #define RN_OPT_DETERMINISTIC 1
 #define RN_OPT_MF16 2
@@ -320,7 +321,8 @@ int rn_set_fp32_mfma(int mode);
 #define RN_OPT_PERSIST_MAX_K 9
 #define RN_OPT_PERSIST_WGS 10
 #define RN_OPT_BF16_P8 11
-#define RN_OPT_COUNT 12
+#define RN_OPT_FP8_P8 12
+#define RN_OPT_COUNT 13
 int rn_get_option(int option);
 int rn_set_option(int option, int value);
 /* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (64; environment RN_FP32_SPLIT_MIN_K);
@@ -426,7 +428,10 @@ int rn_fp8_quantize_rows(const float *w_packed, void *w_q, float *row_scale, int
 int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, void *y, int y_is_f32, const float *scale,
                       const float *shift, const void *add_q, float add_scale, float out_inv_scale, void *stream);
 /* The pyramid levels of a head layer as one launch (rn_conv_igemm_grouped's form; the group's x / y / add are e4m3 -- y: or fp32 --
- * behind the float-typed fields, one input scale for the whole group folded into scale[c]). */
+ * behind the float-typed fields, one input scale for the whole group folded into scale[c]).  tile_end[i] = running sum of
+ * ceil(N*Ho*Wo / rows) * ceil(Cout / cols) with the tile rn_conv_igemm_fp8_tile_rows reports for the group (rows * 1000 + cols:
+ * 128128, or 256256 where RN_OPT_FP8_P8 selects csrc/conv_fp8_p8.hip). */
+int rn_conv_igemm_fp8_tile_rows(const rn_conv_group *g, int y_is_f32);
 int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q, int y_is_f32, const float *scale, const float *shift,
                               float add_scale, float out_inv_scale, void *stream);
 
