@@ -383,8 +383,8 @@ int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *
                      float add_scale, float out_inv_scale, hipStream_t stream);
 int rn_fp8_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, float add_scale,
                              float out_inv_scale, hipStream_t stream);
-// RN_OPT_FP8_P8: 0 never, 1 (default) and 2: wherever legal -- on BASELINE configs[4]'s layers it is faster or equal on every shape it
-// can compute, the short reductions and partial channel tiles included (profiles/r04_fp8_p8_by_shape.txt: 1x1 256 -> 1024 2.4x,
+// RN_OPT_FP8_P8: 0 never, 2 wherever legal, 1 (default): wherever legal but the 3x3 layers with at most 64 output channels -- on BASELINE
+// configs[4]'s layers it is faster or equal on every other shape it can compute, the short reductions and partial channel tiles included (profiles/r04_fp8_p8_by_shape.txt: 1x1 256 -> 1024 2.4x,
 // 3x3 256 -> 256 1.6x, the whole forward pass 35.6 -> 24.5 ms).  RN_FP8_P8_MIN_K / RN_FP8_P8_MIN_TILES restrict mode 1 for A/B runs.
 static inline bool fp8_p8_pick(const rn_conv_desc *d, int y_is_f32, int64_t tiles_in_launch) {
     const int mode = rn_get_option(RN_OPT_FP8_P8);
@@ -392,6 +392,7 @@ static inline bool fp8_p8_pick(const rn_conv_desc *d, int y_is_f32, int64_t tile
     if (mode == 2) return true;
     static const int min_k = [] { const char *e = getenv("RN_FP8_P8_MIN_K"); return e ? atoi(e) : 0; }();
     static const int min_tiles = [] { const char *e = getenv("RN_FP8_P8_MIN_TILES"); return e ? atoi(e) : 0; }();
+    if (d->Cout <= 64 && d->kh * d->kw > 1) return false;      // a quarter of the 256-channel tile on a long reduction: 3x3 64 -> 64 measured 1.25 -> 1.54 ms
     return d->kh * d->kw * d->Cin >= min_k && tiles_in_launch >= min_tiles;
 }
 static inline bool fp8_group_is_p8(const rn_conv_group *g, int y_is_f32) {

@@ -100,6 +100,10 @@ __device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_c
     }
 }
 
+// HALF: Cin is a multiple of 64 only -- the two 64-channel halves of a 128-wide K-tile may belong to different filter taps (or the second
+// lie past the end of the reduction: zero-filled on both sides).  A lane always stages the same half (its logical chunk >> 2), so the
+// tap is a per-lane choice between two wave-uniform shifts.
+template <bool HALF>
 __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned char *__restrict__ x, const unsigned char *__restrict__ w,
                                         unsigned char *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
                                         const unsigned char *__restrict__ add, const Q8Args qa, const int tile, char *lds) {
@@ -110,7 +114,7 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
     const int m0 = (tile / ntn) * Q8_BM, n0 = (tile % ntn) * Q8_BN;
     const int HoWo = d.Ho * d.Wo;
     const int M = d.N * HoWo;                    // < 2^31 - 256 (launcher)
-    const int Cin = d.Cin, K = d.kh * d.kw * Cin, nkt = K / Q8_BK;
+    const int Cin = d.Cin, K = d.kh * d.kw * Cin, nkt = (K + Q8_BK - 1) / Q8_BK;
 
     // descriptors.  Pixels: the flat [M][Cin] tensor from `halo` rows in front of the tile (the farthest a tap reaches back).
     const int ab = d.b < 0 ? -d.b : d.b;
@@ -125,7 +129,8 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
     // the weights; the swizzle of the row (its bits 1, 2) does not depend on i
     const int row0 = 8 * wave + (lane >> 3);
     const int chunk = (lane & 7) ^ q8_swz(row0);
-    const unsigned voff_a = (unsigned)((m0 - base_row + row0) * Cin + chunk * 16);
+    const bool hi_lane = (chunk & 4) != 0;       // HALF: this lane stages the K-tile's second 64 channels
+    const unsigned voff_a = (unsigned)((m0 - base_row + row0) * Cin + (HALF ? chunk & 3 : chunk) * 16);
     const unsigned voff_b = (unsigned)((n0 + row0) * K + chunk * 16);       // rows past Cout: past the descriptor's range
     unsigned pk = 0;                             // bits 8 j + r: filter row r of pixel row j reads inside the image; 8 j + 4 + s: column s
 #pragma unroll
@@ -150,19 +155,37 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
     // instruction i of this wave for K-tile kt (at tap tp).  live = false (past the last K-tile): every lane sends the out-of-range
     // offset -- zeros into a buffer nobody reads -- instead of a branch around the instruction: with branches in the K loop the compiler
     // sank the MFMAs of three phases below them (every operand live at once, nine accumulators spilled)
-    auto dma = [&](const int i, const Q8Tap &tp, const int kt, const int buf, const bool live) {
+    auto next_half = [&](Q8Tap &tp) {                            // selects, not branches (see dma)
+        const int c2 = tp.c + 64;
+        const bool wc_ = c2 == Cin;
+        const int s2 = tp.s + (wc_ ? 1 : 0);
+        const bool ws_ = s2 == d.kw;
+        tp.c = wc_ ? 0 : c2;
+        tp.s = ws_ ? 0 : s2;
+        tp.r += ws_ ? 1 : 0;
+    };
+    auto dma = [&](const int i, const Q8Tap &tp, const Q8Tap &th, const int kt, const int buf, const bool live) {   // th: the tap of the second half
         const unsigned dst = lds0 + (unsigned)(buf * Q8_BUFB + (wave_u + 8 * i) * 1024);
+        const bool hi_live = live && kt * Q8_BK + 64 < K;        // HALF: the second half of the last K-tile may lie past K
         if (i < 4) {
             const int sh = __builtin_amdgcn_readfirstlane(((d.p + tp.r * d.b) * d.Wi + d.p_w + tp.s * d.b + 64 * i) * Cin + tp.c);
             const unsigned ok = (pk >> (8 * i + (tp.r & 3))) & (pk >> (8 * i + 4 + (tp.s & 3))) & (live ? 1u : 0u);
-            dma16(uni(rs_a), dst, ok ? voff_a + (unsigned)sh : 0x80000000u, 0u);
+            if constexpr (HALF) {
+                const int sh_hi = __builtin_amdgcn_readfirstlane(((d.p + th.r * d.b) * d.Wi + d.p_w + th.s * d.b + 64 * i) * Cin + th.c);
+                const unsigned ok_hi = (pk >> (8 * i + (th.r & 3))) & (pk >> (8 * i + 4 + (th.s & 3))) & (hi_live ? 1u : 0u);
+                const unsigned okl = hi_lane ? ok_hi : ok;
+                dma16(uni(rs_a), dst, okl ? voff_a + (unsigned)(hi_lane ? sh_hi : sh) : 0x80000000u, 0u);
+            } else {
+                dma16(uni(rs_a), dst, ok ? voff_a + (unsigned)sh : 0x80000000u, 0u);
+            }
         } else {
-            dma16(uni(rs_b), dst, live ? voff_b : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane(live ? kt * Q8_BK + (i - 4) * 64 * K : 0));
+            const bool okb = HALF ? (hi_lane ? hi_live : live) : live;
+            dma16(uni(rs_b), dst, okb ? voff_b : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane(live ? kt * Q8_BK + (i - 4) * 64 * K : 0));
         }
     };
-    auto next_tap = [&](Q8Tap &tp) {
-        tp.c += Q8_BK;
-        if (tp.c == Cin) { tp.c = 0; if (++tp.s == d.kw) { tp.s = 0; ++tp.r; } }
+    auto next_tap = [&](Q8Tap &tp) {                            // a whole K-tile further
+        next_half(tp);
+        next_half(tp);
     };
 
     // ---- fragments: block (16 rows) of this wave's 128 pixel rows / 64 weight rows; the lane's 32 K values = chunks 2 lg, 2 lg + 1
@@ -210,12 +233,16 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
 
     // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1 (all 8 instructions each); wait for tile 0, read its first fragments
     Q8Tap t2 = {0, 0, 0};
+    Q8Tap t2h = t2;
+    next_half(t2h);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma(i, t2, 0, 0, true);
+    for (int i = 0; i < 8; ++i) dma(i, t2, t2h, 0, 0, true);
     next_tap(t2);
+    next_tap(t2h);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma(i, t2, 1, 1, nkt > 1);
-    next_tap(t2);                                                // now the tap of K-tile t + 2 (in iteration t)
+    for (int i = 0; i < 8; ++i) dma(i, t2, t2h, 1, 1, nkt > 1);
+    next_tap(t2);
+    next_tap(t2h);                                               // now the tap of K-tile t + 2 (in iteration t)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     read_a(A[0], lds, 0);
@@ -250,12 +277,13 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
         for (int g = 0; g < 4; ++g) {
             const int i = g >> 1, j = g & 1;
             acc[6 + i][2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B1[j], A[1][i], acc[6 + i][2 + j], 0, 0, 0, one, 0, one);
-            dma(2 * g, t2, t + 2, t & 1, stage);
-            dma(2 * g + 1, t2, t + 2, t & 1, stage);
+            dma(2 * g, t2, t2h, t + 2, t & 1, stage);
+            dma(2 * g + 1, t2, t2h, t + 2, t & 1, stage);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         next_tap(t2);
+        if constexpr (HALF) next_tap(t2h);
     }
 
     const bool relu = d.act == 1, has_add = d.add_mode == 1;
@@ -265,15 +293,17 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
 #undef Q8_EPI
 }
 
+template <bool HALF>
 __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
                                                                   const unsigned char *__restrict__ w, unsigned char *__restrict__ y,
                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
                                                                   const unsigned char *__restrict__ add, const Q8Args qa) {
     extern __shared__ __attribute__((aligned(16))) char q8_lds[];
-    q8_tile(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), q8_lds);
+    q8_tile<HALF>(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), q8_lds);
 }
 
 // Grouped launch (rn_conv_igemm_fp8_grouped): the pyramid levels of a head layer as ONE grid; a workgroup finds its problem by tile id.
+template <bool HALF>
 __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_grouped_kernel(const rn_conv_group g, const unsigned char *__restrict__ w,
                                                                           const float *__restrict__ scale, const float *__restrict__ shift,
                                                                           const Q8Args qa) {
@@ -284,16 +314,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_grouped_kernel(const
     for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
     p = __builtin_amdgcn_readfirstlane(p);
     const int first = p > 0 ? g.tile_end[p - 1] : 0;
-    q8_tile(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
+    q8_tile<HALF>(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
             reinterpret_cast<const unsigned char *>(g.add[p]), qa, tile - first, q8_lds);
 }
 
 // ---------------------------------------------------------------------------------------------- host side (used by conv_fp8.hip)
 // What the kernel can compute: a stride-1 convolution whose output plane is the input plane, batch-dense NHWC operands, Cin a multiple of
-// the 128-channel K-tile, at most 4 x 4 taps, a dense e4m3 result, no sigmoid, no upsampled addend.
+// 64 (half a K-tile), at most 4 x 4 taps, a dense e4m3 result, no sigmoid, no upsampled addend.
 bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32) {
     if (y_is_f32 || d->a != 1 || d->div_shift != 0 || d->Hi != d->Ho || d->Wi != d->Wo || d->act == 2) return false;
-    if (d->Cin < 128 || (d->Cin & 127) || (d->Cout & 15) || d->kh > 4 || d->kw > 4) return false;
+    if (d->Cin < 64 || (d->Cin & 63) || (d->Cout & 15) || d->kh > 4 || d->kw > 4) return false;
     const int64_t plane = (int64_t)d->Hi * d->Wi;
     if (d->x_batch_stride != plane * d->Cin || d->y_batch_stride != plane * d->Cout) return false;
     if (d->os != 1 || d->oo_h != 0 || d->oo_w != 0 || d->Hy != d->Ho || d->Wy != d->Wo || d->add_mode == 2) return false;
@@ -306,7 +336,10 @@ bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32) {
 }
 int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift, const void *add,
                      float add_scale, float out_inv_scale, hipStream_t stream) {
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+    static const hipError_t attr = [] {
+        const hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+    }();
     if (attr != hipSuccess) return (int)attr;
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     const int64_t tiles = ((M + 255) / 256) * ((d->Cout + 255) / 256);
@@ -314,21 +347,33 @@ int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *
     Q8Args qa;
     qa.add_scale = add_scale;
     qa.out_inv_scale = out_inv_scale;
-    hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, reinterpret_cast<const unsigned char *>(x),
-                       reinterpret_cast<const unsigned char *>(w), reinterpret_cast<unsigned char *>(y), scale, shift,
-                       reinterpret_cast<const unsigned char *>(add), qa);
+    if (d->Cin & 127)
+        hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<true>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, reinterpret_cast<const unsigned char *>(x),
+                           reinterpret_cast<const unsigned char *>(w), reinterpret_cast<unsigned char *>(y), scale, shift,
+                           reinterpret_cast<const unsigned char *>(add), qa);
+    else
+        hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<false>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, reinterpret_cast<const unsigned char *>(x),
+                           reinterpret_cast<const unsigned char *>(w), reinterpret_cast<unsigned char *>(y), scale, shift,
+                           reinterpret_cast<const unsigned char *>(add), qa);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
 int rn_fp8_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, float add_scale,
                              float out_inv_scale, hipStream_t stream) {
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+    static const hipError_t attr = [] {
+        const hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_grouped_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_grouped_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+    }();
     if (attr != hipSuccess) return (int)attr;
     Q8Args qa;
     qa.add_scale = add_scale;
     qa.out_inv_scale = out_inv_scale;
-    hipLaunchKernelGGL(conv_igemm_fp8_p8_grouped_kernel, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *g, reinterpret_cast<const unsigned char *>(w),
-                       scale, shift, qa);
+    if (g->d[0].Cin & 127)
+        hipLaunchKernelGGL(conv_igemm_fp8_p8_grouped_kernel<true>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *g,
+                           reinterpret_cast<const unsigned char *>(w), scale, shift, qa);
+    else
+        hipLaunchKernelGGL(conv_igemm_fp8_p8_grouped_kernel<false>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *g,
+                           reinterpret_cast<const unsigned char *>(w), scale, shift, qa);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -49,6 +49,9 @@ CASES = [  # cin, cout, k, pad, N, H, W
     (128, 320, 3, 1, 2, 9, 15),          # one K-tile per tap; a ragged second channel tile; an image boundary inside the tile
     (1024, 256, 1, 0, 2, 9, 11),         # 1x1, eight K-tiles
     (384, 64, 3, 1, 1, 16, 16),          # three K-tiles per tap (not a power of two); a quarter of a channel tile
+    (64, 256, 1, 0, 2, 15, 17),          # Cin = 64: ONE K-tile whose second half lies past the reduction (zero-filled on both sides)
+    (64, 64, 3, 1, 2, 13, 17),           # Cin = 64, 3x3: the halves of a K-tile are two different taps; 4.5 K-tiles
+    (192, 128, 3, 1, 1, 9, 15),          # Cin = 192: the K-tiles straddle the taps at alternating positions
 ]
 
 
@@ -84,7 +87,7 @@ def test_identical_to_the_other_kernel_on_exact_operands(cv, dev, case):
     assert float(got.abs().max()) > 0
 
 
-@pytest.mark.parametrize("case", CASES[:3])
+@pytest.mark.parametrize("case", CASES[:3] + CASES[4:6])
 def test_random_operands_bias_relu_residual(cv, dev, case):
     cin, cout, k, pad, N, H, W = case
     x = F.relu(rnd((N, cin, H, W), 5))
@@ -139,5 +142,6 @@ def test_grouped_pyramid_launch_and_the_default_rule(cv, dev):
     assert launcher_tile(cv, (16, 68, 120, 1024), 256, 1, 1, 0) == 256256
     assert launcher_tile(cv, (16, 135, 240, 256), 80, 3, 1, 1) == 256256
     assert launcher_tile(cv, (16, 68, 120, 256), 256, 3, 2, 1) == 128128      # strided
+    assert launcher_tile(cv, (16, 270, 480, 64), 256, 1, 1, 0) == 256256       # Cin = 64: half K-tiles
     assert launcher_tile(cv, (16, 68, 120, 32), 256, 3, 1, 1) == 128128       # Cin not a multiple of 64
     cv.set_option(cv.OPT_FP8_P8, 2)
