@@ -13,6 +13,8 @@
 // Epilogue: two exchange levels (v_permlane16_swap, then v_permlane32_swap) give a lane SIXTEEN consecutive channels of one pixel --
 // 16-byte e4m3 stores and addend loads, as in conv_fp8.hip.
 // Roofline: MFMA (~5 PFLOP/s dense fp8).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -103,25 +105,25 @@ __device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_c
 // HALF: Cin is a multiple of 64 only -- the two 64-channel halves of a 128-wide K-tile may belong to different filter taps (or the second
 // lie past the end of the reduction: zero-filled on both sides).  A lane always stages the same half (its logical chunk >> 2), so the
 // tap is a per-lane choice between two wave-uniform shifts.
-template <bool HALF>
+// PERSIST: the workgroup computes tiles tile, tile + tile_step, ... < tile_end; the first two K-tiles of the NEXT tile are staged before
+// the epilogue of the current one (after the last barrier of a K loop no wave reads LDS any more), so a tile's load latency and its
+// epilogue overlap with its neighbours' -- what the short reductions (1x1 layers: one to eight K-tiles) are made of.
+template <bool HALF, bool PERSIST>
 __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned char *__restrict__ x, const unsigned char *__restrict__ w,
                                         unsigned char *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
-                                        const unsigned char *__restrict__ add, const Q8Args qa, const int tile, char *lds) {
+                                        const unsigned char *__restrict__ add, const Q8Args qa, int tile, const int tile_step,
+                                        const int tile_end, char *lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave >> 2, wc = wave & 3;     // rows wr * 128, columns wc * 64 of the tile
     const int ntn = (d.Cout + Q8_BN - 1) / Q8_BN;
-    const int m0 = (tile / ntn) * Q8_BM, n0 = (tile % ntn) * Q8_BN;
     const int HoWo = d.Ho * d.Wo;
     const int M = d.N * HoWo;                    // < 2^31 - 256 (launcher)
     const int Cin = d.Cin, K = d.kh * d.kw * Cin, nkt = (K + Q8_BK - 1) / Q8_BK;
 
-    // descriptors.  Pixels: the flat [M][Cin] tensor from `halo` rows in front of the tile (the farthest a tap reaches back).
+    // Pixels' descriptor: the flat [M][Cin] tensor from `halo` rows in front of the tile (the farthest a tap reaches back).
     const int ab = d.b < 0 ? -d.b : d.b;
     const int halo = ((d.p < 0 ? -d.p : d.p) + (d.kh - 1) * ab) * d.Wi + (d.p_w < 0 ? -d.p_w : d.p_w) + (d.kw - 1) * ab;
-    const int base_row = m0 > halo ? m0 - halo : 0;
-    const int64_t a_bytes = ((int64_t)M - base_row) * Cin;
-    const v4i32 rs_a = make_rsrc(x + (int64_t)base_row * Cin, (unsigned)(a_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : a_bytes));
     const v4i32 rs_b = make_rsrc(w, (unsigned)((int64_t)d.Cout * K));
     const unsigned lds0 = lds_addr(lds);
 
@@ -130,22 +132,34 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
     const int row0 = 8 * wave + (lane >> 3);
     const int chunk = (lane & 7) ^ q8_swz(row0);
     const bool hi_lane = (chunk & 4) != 0;       // HALF: this lane stages the K-tile's second 64 channels
-    const unsigned voff_a = (unsigned)((m0 - base_row + row0) * Cin + (HALF ? chunk & 3 : chunk) * 16);
-    const unsigned voff_b = (unsigned)((n0 + row0) * K + chunk * 16);       // rows past Cout: past the descriptor's range
+    // per-tile staging state (set_tile): the tile's origin, the pixels' descriptor, the lane's offsets and validity bits
+    int m0 = 0, n0 = 0;
+    v4i32 rs_a = rs_b;
+    unsigned voff_a = 0, voff_b = 0;
     unsigned pk = 0;                             // bits 8 j + r: filter row r of pixel row j reads inside the image; 8 j + 4 + s: column s
+    auto set_tile = [&](const int tl) {
+        m0 = (tl / ntn) * Q8_BM;
+        n0 = (tl % ntn) * Q8_BN;
+        const int base_row = m0 > halo ? m0 - halo : 0;
+        const int64_t a_bytes = ((int64_t)M - base_row) * Cin;
+        rs_a = make_rsrc(x + (int64_t)base_row * Cin, (unsigned)(a_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : a_bytes));
+        voff_a = (unsigned)((m0 - base_row + row0) * Cin + (HALF ? chunk & 3 : chunk) * 16);
+        voff_b = (unsigned)((n0 + row0) * K + chunk * 16);       // rows past Cout: past the descriptor's range
+        pk = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + row0 + 64 * j;
-        if (m < M) {
-            const unsigned rem = (unsigned)m % (unsigned)HoWo;
-            const int oh = (int)(rem / (unsigned)d.Wo), ow = (int)(rem - (unsigned)oh * (unsigned)d.Wo);
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + row0 + 64 * j;
+            if (m < M) {
+                const unsigned rem = (unsigned)m % (unsigned)HoWo;
+                const int oh = (int)(rem / (unsigned)d.Wo), ow = (int)(rem - (unsigned)oh * (unsigned)d.Wo);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < d.kh && (unsigned)(oh + d.p + t * d.b) < (unsigned)d.Hi) pk |= 1u << (8 * j + t);
-                if (t < d.kw && (unsigned)(ow + d.p_w + t * d.b) < (unsigned)d.Wi) pk |= 1u << (8 * j + 4 + t);
+                for (int t = 0; t < 4; ++t) {
+                    if (t < d.kh && (unsigned)(oh + d.p + t * d.b) < (unsigned)d.Hi) pk |= 1u << (8 * j + t);
+                    if (t < d.kw && (unsigned)(ow + d.p_w + t * d.b) < (unsigned)d.Wi) pk |= 1u << (8 * j + 4 + t);
+                }
             }
         }
-    }
+    };
     auto uni = [](const v4i32 r) {
         v4i32 o;
         o.x = __builtin_amdgcn_readfirstlane(r.x); o.y = __builtin_amdgcn_readfirstlane(r.y);
@@ -231,20 +245,32 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
         __builtin_amdgcn_sched_barrier(0);                       // phases stay in this order (the reads of all of them in front of the
     };                                                           // MFMAs of all of them is what the compiler prefers)
 
-    // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1 (all 8 instructions each); wait for tile 0, read its first fragments
-    Q8Tap t2 = {0, 0, 0};
-    Q8Tap t2h = t2;
-    next_half(t2h);
+    // ---- a tile's prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1 (all 8 instructions each)
+    Q8Tap t2 = {0, 0, 0}, t2h = {0, 0, 0};
+    auto stage_first_two = [&]() {
+        t2 = Q8Tap{0, 0, 0};
+        t2h = t2;
+        next_half(t2h);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma(i, t2, t2h, 0, 0, true);
-    next_tap(t2);
-    next_tap(t2h);
+        for (int i = 0; i < 8; ++i) dma(i, t2, t2h, 0, 0, true);
+        next_tap(t2);
+        next_tap(t2h);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma(i, t2, t2h, 1, 1, nkt > 1);
-    next_tap(t2);
-    next_tap(t2h);                                               // now the tap of K-tile t + 2 (in iteration t)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        for (int i = 0; i < 8; ++i) dma(i, t2, t2h, 1, 1, nkt > 1);
+        next_tap(t2);
+        next_tap(t2h);                                           // now the tap of K-tile t + 2 (in iteration t)
+    };
+    set_tile(tile);
+    stage_first_two();
+  for (;;) {
+    // wait for K-tile 0 (a persistent workgroup: for everything, the last tile's stores included -- its loads were issued an epilogue ago)
+    if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     read_a(A[0], lds, 0);
     read_b(B0, lds, 0);
 
@@ -286,11 +312,22 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
         if constexpr (HALF) next_tap(t2h);
     }
 
+    // ---- the next tile's first two K-tiles go out before this tile's epilogue
+    const int em0 = m0, en0 = n0;
+    const int next = tile + tile_step;
+    const bool has_next = PERSIST && next < tile_end;
+    if (has_next) {
+        set_tile(next);
+        stage_first_two();
+    }
     const bool relu = d.act == 1, has_add = d.add_mode == 1;
-#define Q8_EPI(RELU, ADD) q8_epilogue<RELU, ADD>(acc, d, y, scale, shift, add, qa, m0 + wr * 128, n0 + wc * 64, M, lane)
+#define Q8_EPI(RELU, ADD) q8_epilogue<RELU, ADD>(acc, d, y, scale, shift, add, qa, em0 + wr * 128, en0 + wc * 64, M, lane)
     if (has_add) { if (relu) Q8_EPI(true, true); else Q8_EPI(false, true); }
     else { if (relu) Q8_EPI(true, false); else Q8_EPI(false, false); }
 #undef Q8_EPI
+    if (!has_next) break;
+    tile = next;
+  }
 }
 
 template <bool HALF>
@@ -299,7 +336,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_kernel(const rn_conv
                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
                                                                   const unsigned char *__restrict__ add, const Q8Args qa) {
     extern __shared__ __attribute__((aligned(16))) char q8_lds[];
-    q8_tile<HALF>(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), q8_lds);
+    q8_tile<HALF, false>(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), 0, 0, q8_lds);
+}
+
+// Persistent form: gridDim.x (a multiple of 8) workgroups share ntiles tiles.  The workgroups of an XCD (blockIdx & 7) own one contiguous
+// range of the tiles (xcd_remap's partition) and walk it together: in pass i workgroup (x, slot) takes tile lo_x + i * gridDim.x / 8 + slot.
+template <bool HALF>
+__global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_persist_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
+                                                                          const unsigned char *__restrict__ w, unsigned char *__restrict__ y,
+                                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                          const unsigned char *__restrict__ add, const Q8Args qa, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char q8_lds[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, hi = lo + q + (xcd < r ? 1 : 0);
+    if (lo + slot >= hi) return;
+    q8_tile<HALF, true>(d, x, w, y, scale, shift, add, qa, lo + slot, per, hi, q8_lds);
 }
 
 // Grouped launch (rn_conv_igemm_fp8_grouped): the pyramid levels of a head layer as ONE grid; a workgroup finds its problem by tile id.
@@ -314,8 +366,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_grouped_kernel(const
     for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
     p = __builtin_amdgcn_readfirstlane(p);
     const int first = p > 0 ? g.tile_end[p - 1] : 0;
-    q8_tile<HALF>(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
-            reinterpret_cast<const unsigned char *>(g.add[p]), qa, tile - first, q8_lds);
+    q8_tile<HALF, false>(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
+                         reinterpret_cast<const unsigned char *>(g.add[p]), qa, tile - first, 0, 0, q8_lds);
 }
 
 // ---------------------------------------------------------------------------------------------- host side (used by conv_fp8.hip)
@@ -337,24 +389,38 @@ bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32) {
 int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift, const void *add,
                      float add_scale, float out_inv_scale, hipStream_t stream) {
     static const hipError_t attr = [] {
-        const hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
-        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+        return e;
     }();
     if (attr != hipSuccess) return (int)attr;
+    // persistent form: one workgroup per CU (a multiple of 8) once every workgroup has at least two tiles; RN_P8_PERSIST=0: never (A/B)
+    static const int n_wg = [] {
+        const char *e = getenv("RN_P8_PERSIST");
+        if (e && atoi(e) == 0) return 0;
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+        return v / 8 * 8;
+    }();
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
     const int64_t tiles = ((M + 255) / 256) * ((d->Cout + 255) / 256);
     if (tiles > 0x7fffffff) return RN_EINVAL;
     Q8Args qa;
     qa.add_scale = add_scale;
     qa.out_inv_scale = out_inv_scale;
-    if (d->Cin & 127)
-        hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<true>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, reinterpret_cast<const unsigned char *>(x),
-                           reinterpret_cast<const unsigned char *>(w), reinterpret_cast<unsigned char *>(y), scale, shift,
-                           reinterpret_cast<const unsigned char *>(add), qa);
-    else
-        hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<false>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, reinterpret_cast<const unsigned char *>(x),
-                           reinterpret_cast<const unsigned char *>(w), reinterpret_cast<unsigned char *>(y), scale, shift,
-                           reinterpret_cast<const unsigned char *>(add), qa);
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(x), *wb = reinterpret_cast<const unsigned char *>(w);
+    const unsigned char *ab = reinterpret_cast<const unsigned char *>(add);
+    unsigned char *yb = reinterpret_cast<unsigned char *>(y);
+    const bool half = (d->Cin & 127) != 0;
+    if (n_wg > 0 && tiles >= 2 * (int64_t)n_wg) {
+        if (half) hipLaunchKernelGGL(conv_igemm_fp8_p8_persist_kernel<true>, dim3((unsigned)n_wg), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa, (int)tiles);
+        else hipLaunchKernelGGL(conv_igemm_fp8_p8_persist_kernel<false>, dim3((unsigned)n_wg), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa, (int)tiles);
+    } else {
+        if (half) hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<true>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa);
+        else hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<false>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa);
+    }
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -145,3 +145,29 @@ def test_grouped_pyramid_launch_and_the_default_rule(cv, dev):
     assert launcher_tile(cv, (16, 270, 480, 64), 256, 1, 1, 0) == 256256       # Cin = 64: half K-tiles
     assert launcher_tile(cv, (16, 68, 120, 32), 256, 3, 1, 1) == 128128       # Cin not a multiple of 64
     cv.set_option(cv.OPT_FP8_P8, 2)
+
+
+@pytest.mark.parametrize("case", [(64, 256, 1, 0, 2, 270, 261), (128, 320, 3, 1, 1, 259, 257), (256, 256, 3, 1, 3, 150, 301)])
+def test_persistent_form_identical_on_exact_operands(cv, dev, case):
+    """Launches with at least two tiles per CU run as persistent workgroups that stage the next tile's first K-tiles before the current
+    tile's epilogue (conv_fp8_p8.hip: PERSIST): 550 / 522 / 530 tiles here, ragged last row tiles, a ragged channel tile -- byte-identical
+    to the 128 x 128 kernel on exact operands, residual + ReLU epilogue included."""
+    cin, cout, k, pad, N, H, W = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randint(-4, 5, (N, H, W, cin), generator=g).float()
+    w = (torch.randint(-4, 5, (cout, cin, k, k), generator=g).float() / 2)
+    res = torch.randint(-4, 5, (N, H, W, cout), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    xq, rq = cv.fp8_quantize(x.to(dev), 1.0), cv.fp8_quantize(res.to(dev), 1.0)
+    wq = cv.fp8_quantize(cv.pack_weights(w.to(dev), 0, presplit=False), 1.0)
+    geom = (H, W, cout, k, k, 1, 1, -pad, 0)
+    scale = torch.full((cout,), 2.0 ** -6, device=dev)
+    outs = []
+    for mode in (2, 0):
+        cv.set_option(cv.OPT_FP8_P8, mode)
+        y = torch.zeros((N, H, W, cout), dtype=torch.uint8, device=dev)
+        cv.conv_igemm_fp8(xq, wq, y, geom, scale, shift=b.to(dev), add=rq, add_mode=1, act=cv.ACT_RELU, out_scale=0.5)
+        outs.append(y)
+    cv.set_option(cv.OPT_FP8_P8, 2)
+    assert torch.equal(outs[0], outs[1])
+    assert 0.2 < float((outs[0] > 0).float().mean()) < 0.95
