@@ -34,71 +34,78 @@ __device__ __forceinline__ int q8_pack4(float a, float b, float c, float d) {   
     return __builtin_amdgcn_cvt_pk_fp8_f32(q8_clamp(c), q8_clamp(d), lo, true);
 }
 
+#ifndef Q8_ABL
+#define Q8_ABL 0                                 // knock-outs for profiles/ (bits): 1 no stores, 2 no addend loads, 4 no staging after a tile's first two K-tiles, 8 no MFMAs
+#endif
 struct Q8Tap { int r, s, c; };                   // filter row, filter column, first channel of a K-tile (wave-uniform)
 struct Q8Args { float add_scale, out_inv_scale; };   // conv_fp8.hip: Fp8Args
 
-// ---- epilogue: u = acc * scale[c] + shift[c]; u += add * add_scale; [ReLU]; y = e4m3(u * out_inv_scale) (conv_fp8.hip's arithmetic).
-// acc[rb][cb][e]: pixel row rb * 16 + lr, channel cb * 16 + 4 lg + e of the wave's 128 x 64.  Level 1 (conv_bf16_p8.hip): a lane holds
-// channels 8 k8 .. + 7 of block (2 pr + half), half = lg & 1, k8 = lg >> 1.  Level 2, v_permlane32_swap(X, Y) with X / Y the pr = 0 / 1
-// values (the upper 32 lanes of X change places with the lower 32 of Y): a lower lane (k8 = 0) then holds [own X, the X of lane + 32] =
-// channels 0 .. 15 of block `half`, an upper lane [the Y of lane - 32, own Y] = channels 0 .. 15 of block 2 + half.
+// ---- epilogue: u = acc * scale[c] + shift[c]; u += add * add_scale; [ReLU]; y = e4m3(u * out_inv_scale) (conv_fp8.hip's arithmetic,
+// with out_inv_scale -- positive -- folded into the three factors: the ReLU commutes with it; results identical on exact operands).
+// acc[rb][cb][e]: pixel row rb * 16 + lr, channel cb * 16 + 4 lg + e of the wave's 128 x 64 (lr = lane & 15, lg = lane >> 4): a lane holds
+// four consecutive channels of each of the four 16-channel blocks.  The arithmetic runs IN that layout, two channels per instruction
+// (v_pk_fma_f32, v_cvt_pk_f32_fp8, v_cvt_pk_fp8_f32; v_med3_f32 is the ReLU and the e4m3 clamp in one), and only the packed e4m3 dwords
+// change lanes: the four lanes of a pixel transpose their 4 x 4 dwords (lane L ends with dwords j = 0..3 of block L = 16 consecutive
+// channels, one 16-byte store) in four instructions -- v_permlane16_swap on (P0,P1), (P2,P3), then v_permlane32_swap on (Q0,Q2), (Q1,Q3).
+// The transposition is its own inverse: the addend, loaded as the 16 bytes of block `lg`, goes through the same four instructions to
+// arrive as the lane's four channels of every block.  (The first version exchanged fp32 values, 24 instructions per 16 channels, and
+// did every operation per channel: ~9 VALU instructions per element, 5 us per tile -- more than a 1x1 layer's K loop.)
+__device__ __forceinline__ void q8_transpose4(unsigned (&p)[4]) {
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(p[0], p[1], false, false), b = __builtin_amdgcn_permlane16_swap(p[2], p[3], false, false);
+    const u32x2 c = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false), e = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    p[0] = c[0]; p[1] = e[0]; p[2] = c[1]; p[3] = e[1];
+}
 template <bool RELU, bool ADD>
 __device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_conv_desc &d, unsigned char *__restrict__ y,
                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                             const unsigned char *__restrict__ add, const Q8Args qa, const int mw, const int nw, const int M,
                                             const int lane) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lr = lane & 15, lg = lane >> 4;
-    const int col_raw = nw + (2 * (lg >> 1) + (lg & 1)) * 16;
-    const bool col_ok = col_raw < d.Cout;                        // Cout % 16 == 0 (launcher): a chunk is inside or outside
+    const int col_raw = nw + lg * 16;                            // the block this lane stores (and loads the addend of)
+    const bool col_ok = col_raw < d.Cout;                        // Cout % 16 == 0 (launcher): a block is inside or outside
     const int col = col_ok ? col_raw : 0;                        // loads stay inside the tensors; nothing is stored
-    float sc[16], sh[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 s4 = (col_ok && scale != nullptr) ? *reinterpret_cast<const float4 *>(scale + col + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 h4 = (col_ok && shift != nullptr) ? *reinterpret_cast<const float4 *>(shift + col + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
-        sh[4 * q] = h4.x; sh[4 * q + 1] = h4.y; sh[4 * q + 2] = h4.z; sh[4 * q + 3] = h4.w;
-    }
     const float is = qa.out_inv_scale;
+    const f32x2 as2 = {qa.add_scale * is, qa.add_scale * is};
+    f32x2 sc[4][2], sh[4][2];                                    // the lane's four channels of each block, scaled by 1 / out scale
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int c0 = nw + cb * 16 + 4 * lg;
+        const bool ok = c0 < d.Cout;
+        const float4 s4 = (ok && scale != nullptr) ? *reinterpret_cast<const float4 *>(scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 h4 = (ok && shift != nullptr) ? *reinterpret_cast<const float4 *>(shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[cb][0] = f32x2{s4.x * is, s4.y * is}; sc[cb][1] = f32x2{s4.z * is, s4.w * is};
+        sh[cb][0] = f32x2{h4.x * is, h4.y * is}; sh[cb][1] = f32x2{h4.z * is, h4.w * is};
+    }
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
         const int m = mw + rb * 16 + lr;
         const bool row_ok = m < M;
         const int64_t off = (int64_t)(row_ok ? m : M - 1) * d.Cout + col;
-        i32x4 aq = {0, 0, 0, 0};
-        if constexpr (ADD) aq = *reinterpret_cast<const i32x4 *>(add + off);
-        unsigned x1[2][8];                                       // level 1: [pr][8 channels]
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[rb][2 * pr][e]), __float_as_uint(acc[rb][2 * pr + 1][e]), false, false);
-                x1[pr][e] = r[0];
-                x1[pr][4 + e] = r[1];
+        unsigned aq[4] = {0u, 0u, 0u, 0u};
+        if constexpr (ADD) {
+            if (!(Q8_ABL & 2)) {
+                const i32x4 t = *reinterpret_cast<const i32x4 *>(add + off);
+                aq[0] = (unsigned)t[0]; aq[1] = (unsigned)t[1]; aq[2] = (unsigned)t[2]; aq[3] = (unsigned)t[3];
             }
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x2 r = __builtin_amdgcn_permlane32_swap(x1[0][j], x1[1][j], false, false);
-            v[j] = __uint_as_float(r[0]);
-            v[8 + j] = __uint_as_float(r[1]);
+            q8_transpose4(aq);                                   // -> the lane's four channels of block cb in aq[cb]
         }
+        unsigned o[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float u = v[j] * sc[j] + sh[j];
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x2 u0 = f32x2{acc[rb][cb][0], acc[rb][cb][1]} * sc[cb][0] + sh[cb][0];
+            f32x2 u1 = f32x2{acc[rb][cb][2], acc[rb][cb][3]} * sc[cb][1] + sh[cb][1];
             if constexpr (ADD) {
-                const int word = aq[j >> 2];
-                const float a = (j & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8(word, 0) : (j & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8(word, 1)
-                              : (j & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8(word, 2) : __builtin_amdgcn_cvt_f32_fp8(word, 3);
-                u += a * qa.add_scale;
+                u0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)aq[cb], false) * as2 + u0;
+                u1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)aq[cb], true) * as2 + u1;
             }
-            if constexpr (RELU) u = fmaxf(u, 0.f);
-            v[j] = u * is;
+            const float lo = RELU ? 0.f : -Q8_MAX;
+            const int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(u0.x, lo, Q8_MAX), __builtin_amdgcn_fmed3f(u0.y, lo, Q8_MAX), 0, false);
+            o[cb] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(u1.x, lo, Q8_MAX), __builtin_amdgcn_fmed3f(u1.y, lo, Q8_MAX), w0, true);
         }
-        i32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = q8_pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        if (row_ok && col_ok) *reinterpret_cast<i32x4 *>(y + off) = o;
+        q8_transpose4(o);                                        // -> dwords 0..3 of block lg
+        const i32x4 ov = {(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+        if ((Q8_ABL & 1) ? (ov[0] == 0x12345678 && row_ok && col_ok) : (row_ok && col_ok)) *reinterpret_cast<i32x4 *>(y + off) = ov;
     }
 }
 
