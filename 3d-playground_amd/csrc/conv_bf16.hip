@@ -642,7 +642,8 @@ __device__ __forceinline__ bf16x8 wg_operand(const char *img, unsigned a_rd0, un
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16Args p) {
+// bid: the workgroup's id within ITS problem's range of the grid (a grouped launch holds several problems' ranges one after the other)
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WgradBf16Args &p, const int bid) {
     constexpr int BM = 128, BN = 128, WK = WG_WK;
     constexpr int TB = 256 / WK;                             // K-steps per pixel-table batch: one entry per thread
     constexpr int IA = WK / 4 / 4, IB = WK / 4 / 4;          // DMA instructions per wave per K-step: 4 rows each, 4 waves
@@ -657,12 +658,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
     // algorithmic bytes fetched (profiles/r02_pmc_conv_bf16.txt); conv_wgrad.hip does the same for its many-tile shapes.
     int slice, tile;
     if (p.xcd_map) {
-        const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+        const int xcd = bid & 7, wi = bid >> 3;                // a problem's range starts at a multiple of 8: bid & 7 is the XCD
         slice = (wi / p.tiles) * 8 + xcd;
         tile = wi % p.tiles;
     } else {
-        slice = blockIdx.x / p.tiles;
-        tile = blockIdx.x % p.tiles;
+        slice = bid / p.tiles;
+        tile = bid % p.tiles;
     }
     if (slice >= p.splits) return;                           // padding of the last group of 8 slices
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
@@ -814,6 +815,59 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16
         }
 }
 
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const WgradBf16Args p) { conv_wgrad_bf16_body(p, (int)blockIdx.x); }
+
+// Grouped launch: the pyramid levels of a head layer (D/model.py:110-205: one weight tensor convolves all five levels, so its gradient
+// is the SUM over the levels) as ONE grid accumulating into one dw / colsum.  Alone, the small levels are launches of a few dozen
+// microseconds at 60-270 TFLOP/s (8 x 9 x 15 ... 8 x 34 x 60 pixels); here they ride along with the big ones.
+struct WgradBf16Group {
+    int n;
+    int block_end[RN_MAX_GROUP];         // running sum of the problems' workgroup counts (each a multiple of 8)
+    WgradBf16Args p[RN_MAX_GROUP];
+};
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_grouped_kernel(const WgradBf16Group g) {
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < RN_MAX_GROUP - 1; ++j) i += (j + 1 < g.n && (int)blockIdx.x >= g.block_end[j]) ? 1 : 0;
+    i = __builtin_amdgcn_readfirstlane(i);
+    conv_wgrad_bf16_body(g.p[i], (int)blockIdx.x - (i > 0 ? g.block_end[i - 1] : 0));
+}
+
+// Geometry, K slices and grid size of one weight-gradient problem; target_wgs: the workgroups it should bring to the grid.
+// Returns the number of workgroups (> 0) or -RN_EINVAL.
+static int64_t wgrad_bf16_fill(WgradBf16Args &a, const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi,
+                               int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int target_wgs, bool pad8) {
+    a.dy = reinterpret_cast<const __bf16 *>(dy); a.x = reinterpret_cast<const __bf16 *>(x); a.dw = dw; a.colsum = colsum; a.ldy = ldy;
+    a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.Kflat = kh * kw * Cin;
+    a.Kpad = (a.Kflat + 31) / 32 * 32;
+    a.pixels = (int64_t)N * Ho * Wo;
+    const int tiles_m = (Cout + 127) / 128;
+    a.tiles_n = (a.Kflat + 127) / 128;
+    a.tiles = tiles_m * a.tiles_n;
+    int64_t splits = (target_wgs + a.tiles - 1) / a.tiles;
+    const int64_t max_splits = (a.pixels + 16 * WG_WK - 1) / (16 * WG_WK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const int64_t HoWo = (int64_t)Ho * Wo, img_bytes = (int64_t)Hi * Wi * Cin * 2;
+    for (;;) {
+        a.per_split = ((a.pixels + splits - 1) / splits + WG_WK - 1) / WG_WK * WG_WK;
+        const int64_t span_imgs = (a.per_split + HoWo - 2) / HoWo + 1;
+        if ((a.per_split + WG_WK) * ldy * 2 <= 0x7FFFFFFF && span_imgs * img_bytes <= 0x7FFFFFFF) break;
+        if (a.per_split <= WG_WK || splits >= 65535) return -RN_EINVAL;
+        splits = splits * 2 > 65535 ? 65535 : splits * 2;
+    }
+    splits = (a.pixels + a.per_split - 1) / a.per_split;
+    a.splits = (int)splits;
+    static const int xcd_env = [] { const char *e = getenv("RN_WGRAD_BF16_XCD"); return e ? atoi(e) : 1; }();
+    a.xcd_map = xcd_env != 0 && a.tiles >= 4 && splits >= 8;
+    int64_t blocks = a.tiles * (a.xcd_map ? (splits + 7) / 8 * 8 : splits);
+    if (pad8 && !a.xcd_map) blocks = (blocks + 7) / 8 * 8;      // grouped: every problem's range starts at a multiple of 8 (surplus ids: slice >= splits)
+    return blocks;
+}
+
 // The eight-wave 256 x 256 tile over 64-pixel K-tiles (conv_wgrad_bf16_p8.hip) for stride-1 same-size layers with Cin, Cout % 256 == 0.
 bool rn_wgrad_bf16_p8_legal(int ldy, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad);
 int rn_wgrad_bf16_p8_launch(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int H, int W, int Cin, int Cout,
@@ -832,40 +886,50 @@ extern "C" int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float 
         if ((rn_get_option(RN_OPT_BF16_P8) == 2 || wp8_env == 1) && rn_wgrad_bf16_p8_legal(ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad))
             return rn_wgrad_bf16_p8_launch(dy, ldy, x, dw, colsum, N, Hi, Wi, Cin, Cout, kh, pad, (hipStream_t)stream);
     }
-    WgradBf16Args a;
-    a.dy = reinterpret_cast<const __bf16 *>(dy); a.x = reinterpret_cast<const __bf16 *>(x); a.dw = dw; a.colsum = colsum; a.ldy = ldy;
-    a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
-    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
-    a.Kflat = kh * kw * Cin;
-    a.Kpad = (a.Kflat + 31) / 32 * 32;
-    a.pixels = (int64_t)N * Ho * Wo;
-    const int tiles_m = (Cout + 127) / 128;
-    a.tiles_n = (a.Kflat + 127) / 128;
-    a.tiles = tiles_m * a.tiles_n;
     static const int target_wgs = [] { const char *e = getenv("RN_WGRAD_BF16_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
     // K slices for ~768 workgroups = ONE resident round at three per CU.  Every slice ends in tile-sized fp32 atomics
     // (Cout x Kflat x slices of them per launch, ~1.3 TB/s chip-wide), and with the MFMAs eight times shorter than in the
     // fp32 kernel that tail weighs more: measured per training step (all weight gradients) 512: 11.6 ms, 768: 11.1,
     // 1024: 13.5, 1536: 13.2, 2048: 14.6, 3072: 15.2 (the fp32 kernel's optimum is 2048).  RN_WGRAD_BF16_WGS overrides.
-    int64_t splits = (target_wgs + a.tiles - 1) / a.tiles;
-    const int64_t max_splits = (a.pixels + 16 * WG_WK - 1) / (16 * WG_WK);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    const int64_t HoWo = (int64_t)Ho * Wo, img_bytes = (int64_t)Hi * Wi * Cin * 2;
-    for (;;) {
-        a.per_split = ((a.pixels + splits - 1) / splits + WG_WK - 1) / WG_WK * WG_WK;
-        const int64_t span_imgs = (a.per_split + HoWo - 2) / HoWo + 1;
-        if ((a.per_split + WG_WK) * ldy * 2 <= 0x7FFFFFFF && span_imgs * img_bytes <= 0x7FFFFFFF) break;
-        if (a.per_split <= WG_WK || splits >= 65535) return RN_EINVAL;
-        splits = splits * 2 > 65535 ? 65535 : splits * 2;
+    WgradBf16Args a;
+    const int64_t blocks = wgrad_bf16_fill(a, dy, ldy, x, dw, colsum, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, target_wgs, false);
+    if (blocks <= 0) return RN_EINVAL;
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// The weight gradients of n <= RN_MAX_GROUP problems that share ONE weight tensor (the pyramid levels of a head layer) as one launch:
+// dw / colsum accumulate the sum over the problems.  Per problem i: dy[i] [N, H[i], W[i], ldy] and x[i] [N, H[i], W[i], Cin] (stride-1
+// same-size geometry is NOT required: Ho / Wo follow from H, W, k, stride, pad as in rn_conv_wgrad_bf16).
+extern "C" int rn_conv_wgrad_bf16_grouped(int n, const void *const *dy, int ldy, const void *const *x, float *dw, float *colsum, int N,
+                                          const int *Hi, const int *Wi, int Cin, int Cout, int kh, int kw, int stride, int pad, void *stream) {
+    if (n < 1 || n > RN_MAX_GROUP || N <= 0 || Cout <= 0 || Cin < 8 || (Cin & 7) || (ldy & 7) || ldy < Cout) return RN_EINVAL;
+    static const int target_wgs = [] { const char *e = getenv("RN_WGRAD_BF16_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    int Ho[RN_MAX_GROUP], Wo[RN_MAX_GROUP];
+    int64_t total_pixels = 0;
+    for (int i = 0; i < n; ++i) {
+        if (Hi[i] <= 0 || Wi[i] <= 0 || ((uintptr_t)dy[i] & 15) || ((uintptr_t)x[i] & 15)) return RN_EINVAL;
+        Ho[i] = (Hi[i] + 2 * pad - kh) / stride + 1;
+        Wo[i] = (Wi[i] + 2 * pad - kw) / stride + 1;
+        if (Ho[i] <= 0 || Wo[i] <= 0) return RN_EINVAL;
+        total_pixels += (int64_t)N * Ho[i] * Wo[i];
     }
-    splits = (a.pixels + a.per_split - 1) / a.per_split;
-    a.splits = (int)splits;
-    static const int xcd_env = [] { const char *e = getenv("RN_WGRAD_BF16_XCD"); return e ? atoi(e) : 1; }();
-    a.xcd_map = xcd_env != 0 && a.tiles >= 4 && splits >= 8;
-    const int64_t grid_slices = a.xcd_map ? (splits + 7) / 8 * 8 : splits;
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(a.tiles * grid_slices)), dim3(256), 0, (hipStream_t)stream, a);
+    WgradBf16Group g;
+    g.n = n;
+    int64_t end = 0;
+    for (int i = 0; i < n; ++i) {
+        // the problem's share of one resident round, by its pixels (at least one slice per tile: wgrad_bf16_fill)
+        const int share = (int)((int64_t)target_wgs * ((int64_t)N * Ho[i] * Wo[i]) / total_pixels);
+        const int64_t blocks = wgrad_bf16_fill(g.p[i], dy[i], ldy, x[i], dw, colsum, N, Hi[i], Wi[i], Cin, Ho[i], Wo[i], Cout, kh, kw, stride, pad,
+                                               share, true);
+        if (blocks <= 0) return RN_EINVAL;
+        end += blocks;
+        if (end > 0x7fffffff) return RN_EINVAL;
+        g.block_end[i] = (int)end;
+    }
+    for (int i = n; i < RN_MAX_GROUP; ++i) g.block_end[i] = (int)end;
+    hipLaunchKernelGGL(conv_wgrad_bf16_grouped_kernel, dim3((unsigned)end), dim3(256), 0, (hipStream_t)stream, g);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

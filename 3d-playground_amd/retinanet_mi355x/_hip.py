@@ -150,6 +150,8 @@ SIGNATURES.update({
     "rn_conv_igemm_fp8": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp]),
     "rn_conv_igemm_fp8_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp]),
     "rn_conv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 11 + [c_vp]),
+    "rn_conv_wgrad_bf16_grouped": (c_i32, [c_i32, ctypes.POINTER(c_vp), c_i32, ctypes.POINTER(c_vp), c_vp, c_vp, c_i32,
+                                           ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)] + [c_i32] * 6 + [c_vp]),
     "rn_maxpool_fwd_bf16out": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
     "rn_maxpool_bwd_bf16in": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
     "rn_upsample_add_bwd_bf16": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),

@@ -679,6 +679,27 @@ def wgrad_bf16(dy, x, dw, cout, k, stride, pad, flops=0.0, colsum=None):
     return dw
 
 
+def wgrad_bf16_grouped(dys, xs, dw, cout, k, stride, pad, flops=0.0, colsum=None):
+    """rn_conv_wgrad_bf16_grouped: dw[Cout][Kpad] (fp32) += the SUM over several problems that share one weight tensor (the pyramid
+    levels of a head layer) of wgrad(dy_i, x_i), as ONE launch; colsum[Cout] += the column sums of every dy_i."""
+    lib = _hip.load()
+    n = len(dys)
+    assert n == len(xs) and 1 <= n <= 5 and dw.dtype == torch.float32
+    ld, N, cin = dys[0].shape[3], xs[0].shape[0], xs[0].shape[3]
+    for g, x in zip(dys, xs):
+        assert g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_contiguous() and x.is_contiguous()
+        assert g.shape[3] == ld and x.shape[0] == N and g.shape[0] == N and x.shape[3] == cin
+        _hip.need_gpu(g, x)
+    PA = ctypes.c_void_p * n
+    IA = ctypes.c_int * n
+    dy_p, x_p = PA(*[g.data_ptr() for g in dys]), PA(*[x.data_ptr() for x in xs])
+    hi, wi = IA(*[x.shape[1] for x in xs]), IA(*[x.shape[2] for x in xs])
+    kind = "conv_wgrad_bf16" + (" grouped %d->%d k%d" % (cin, cout, k) if prof.BY_SHAPE else "")
+    rc = prof.timed(kind, flops, lambda: lib.rn_conv_wgrad_bf16_grouped(
+        n, dy_p, ld, x_p, dw.data_ptr(), _hip.ptr(colsum), N, hi, wi, cin, cout, k, k, stride, pad, _hip.stream()))
+    _hip.check(rc, "rn_conv_wgrad_bf16_grouped")
+
+
 def dgrad_any_bf16(dy, w_packed_dgrad, in_hw, cin, k, stride, pad, **kw):
     """Data gradient, generic form (every tap tried at every input pixel; for stride 2 three of four fail the divisibility
     test): used for the 1x1 stride-2 shortcuts, whose single tap makes the waste irrelevant."""

@@ -27,6 +27,8 @@ from . import _hip, arch, conv as cv, ops, prof
 # The two input-side transforms of an output gradient (for the weight gradient and for the data gradient of a Winograd layer) in
 # one pass over it; RN_WINO_FUSE_DY=0 keeps the two separate launches (A/B).
 FUSE_DY = os.environ.get("RN_WINO_FUSE_DY", "1") != "0"
+# bf16 engine: the weight gradient of a head layer over its five pyramid levels as ONE launch (rn_conv_wgrad_bf16_grouped); 0: one per level (A/B)
+GROUPED_WGRAD_BF16 = os.environ.get("RN_GROUPED_WGRAD_BF16", "1") != "0"
 
 
 class Layer:
@@ -312,6 +314,14 @@ class Layer:
             du, self.du = getattr(self, "du", None), None
             self.dy_v = cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY)
             self.saved_v = None
+            return
+        if self.bf16 and GROUPED_WGRAD_BF16 and 1 < len(gs) <= 5 and all(g.is_contiguous() and x.is_contiguous() for g, x in zip(gs, xs)) \
+                and len({g.shape[3] for g in gs}) == 1:
+            if self.dw is None:
+                self.dw = torch.zeros_like(self.wf)
+                self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
+            fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
+            cv.wgrad_bf16_grouped(gs, xs, self.dw, s.cout, s.k, s.stride, s.pad, flops=fl, colsum=self.cs)
             return
         for g, x in zip(gs, xs):
             self.bwd_params(g, x)

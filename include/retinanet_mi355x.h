@@ -439,6 +439,11 @@ int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q, int y_is_
  * and bf16 x [N,Hi,Wi,Cin]; colsum (may be NULL) += column sums of dy.  Cin % 8 == 0, ldy % 8 == 0. */
 int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi, int Cin,
                        int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream);
+/* The same for n <= RN_MAX_GROUP problems that share ONE weight tensor -- the pyramid levels of a head layer (D/model.py:110-205), whose
+ * weight gradient is the sum over the levels -- as one launch: dy[i] [N, Ho_i, Wo_i, ldy], x[i] [N, Hi[i], Wi[i], Cin]; dw / colsum
+ * accumulate the sum.  The small levels, launches of tens of microseconds on their own, ride along with the big ones. */
+int rn_conv_wgrad_bf16_grouped(int n, const void *const *dy, int ldy, const void *const *x, float *dw, float *colsum, int N,
+                               const int *Hi, const int *Wi, int Cin, int Cout, int kh, int kw, int stride, int pad, void *stream);
 
 /* Non-convolution steps of the schedule with bf16 activations (elementwise_bf16.hip): the same operations as
  * rn_maxpool_fwd / rn_maxpool_bwd / rn_upsample_add_bwd / rn_sigmoid_bwd_pad with bf16 storage on the activation side.

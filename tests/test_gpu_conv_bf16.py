@@ -196,3 +196,39 @@ def test_bf16_dominant_layer_1080p(cv, dev):
     dw = torch.zeros((C, 9 * C), device=dev)
     cv.wgrad_bf16(gb, xb, dw, C, 3, 1, 1)
     close_f32(dw.view(C, 3, 3, C).permute(0, 3, 1, 2), wr.grad, tol=1e-4)
+
+
+def test_grouped_weight_gradient_over_pyramid_levels(cv, dev):
+    """rn_conv_wgrad_bf16_grouped: the levels of a head layer share one weight tensor, so its gradient is the SUM over the levels
+    (D/model.py:110-205) -- one launch against torch's autograd over all levels and against the per-level launches."""
+    cin, cout, ld, k, N = 64, 72, 80, 3, 2                      # dy rows wider than Cout (the head outputs' padded gradient slices)
+    sizes = [(19, 23), (10, 12), (5, 6), (3, 3), (2, 2)]
+    w = rnd((cout, cin, k, k), 31, 0.05)
+    wr = r16(w).requires_grad_(True)
+    xs, gs = [], []
+    for i, (H, W) in enumerate(sizes):
+        x, g = rnd((N, cin, H, W), 32 + i), rnd((N, ld, H, W), 42 + i)
+        F.conv2d(r16(x), wr, None, 1, 1).backward(r16(g)[:, :cout])
+        xs.append(cv.to_bf16(nhwc(x).to(dev)))
+        gs.append(cv.to_bf16(nhwc(g).to(dev)))
+    kp = (k * k * cin + 31) // 32 * 32
+    dw, cs = torch.zeros((cout, kp), device=dev), torch.zeros(cout, device=dev)
+    cv.wgrad_bf16_grouped(gs, xs, dw, cout, k, 1, 1, colsum=cs)
+    dw1, cs1 = torch.zeros((cout, kp), device=dev), torch.zeros(cout, device=dev)
+    for g, x in zip(gs, xs):
+        cv.wgrad_bf16(g, x, dw1, cout, k, 1, 1, colsum=cs1)
+    close_f32(dw, dw1, tol=2e-5)
+    close_f32(cs, cs1, tol=2e-5)
+    close_f32(dw[:, :k * k * cin].view(cout, k, k, cin).permute(0, 3, 1, 2), wr.grad, tol=5e-5)
+    want_cs = sum(r16(nchw(g.float().cpu()))[:, :cout].sum(dim=(0, 2, 3)) for g in gs)
+    close_f32(cs, want_cs, tol=5e-5)
+    # a 256 -> 256 layer at larger levels: the K-slice placement by XCD (tiles >= 4, >= 8 slices) inside a grouped grid
+    cin = cout = 256
+    sizes = [(34, 60), (17, 30), (9, 15)]
+    xs = [cv.to_bf16(nhwc(rnd((N, cin, H, W), 52 + i)).to(dev)) for i, (H, W) in enumerate(sizes)]
+    gs = [cv.to_bf16(nhwc(rnd((N, cout, H, W), 62 + i)).to(dev)) for i, (H, W) in enumerate(sizes)]
+    dw, dw1 = torch.zeros((cout, 9 * cin), device=dev), torch.zeros((cout, 9 * cin), device=dev)
+    cv.wgrad_bf16_grouped(gs, xs, dw, cout, 3, 1, 1)
+    for g, x in zip(gs, xs):
+        cv.wgrad_bf16(g, x, dw1, cout, 3, 1, 1)
+    close_f32(dw, dw1, tol=2e-5)
