@@ -628,6 +628,14 @@ def pack_weights_bf16(weight, mode=0, scale=None, c_pad=None, taps=None):
     return to_bf16(pack_weights(weight, mode, scale=scale, c_pad=c_pad, taps=taps, presplit=False))
 
 
+def _p8_suffix(fn_name, d, yf32):
+    """"_p8" when the launcher takes the eight-wave 256 x 256 kernel for this problem (profiling only: the kernel families are timed apart)."""
+    g = _hip.ConvGroup()
+    g.n = 1
+    g.d[0] = d
+    return "_p8" if getattr(_hip.load(), fn_name)(ctypes.byref(g), int(yf32)) == 256256 and os.environ.get("RN_BF16_BIG_TILE", "0") in ("", "0") else ""
+
+
 def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
                     mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, flops=0.0, out_map=None, sign=False):
     """rn_conv_igemm_bf16: x [N,Hi,Wi,Cin] bf16, w_packed bf16, y bf16 or fp32 (its dtype decides); geom as conv_igemm.
@@ -639,6 +647,8 @@ def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_
     bits = _sign_words(y, sign and y_batch_stride is None and out_map is None and y.dtype == torch.bfloat16)
     d.sign_out = None if bits is None else bits.data_ptr()
     kind = "conv_igemm_bf16"
+    if prof.ACTIVE is not None:
+        kind += _p8_suffix("rn_conv_igemm_bf16_tile_rows", d, y.dtype == torch.float32)
     if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
         kind += " %dx%dx%d %d->%d k%d a%d b%d ds%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh, d.a, d.b, d.div_shift)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16(
@@ -781,7 +791,8 @@ def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_
         M = d.N * d.Ho * d.Wo
         total += ((M + trm - 1) // trm) * ((d.Cout + trn - 1) // trn)
         g.tile_end[i] = total
-    kind = "conv_igemm_bf16" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
+    kind = "conv_igemm_bf16" + ("_p8" if (trm, trn) == (256, 256) and os.environ.get("RN_BF16_BIG_TILE", "0") in ("", "0") else "") \
+        + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16_grouped(
         ctypes.byref(g), w_packed.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm_bf16_grouped")
@@ -827,6 +838,8 @@ def conv_igemm_fp8(xq, wq, y, geom, scale, shift=None, add=None, add_mode=0, add
     assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and y.dtype in (torch.uint8, torch.float32)
     d = _make_desc(xq, geom, act, add_mode, add_hw, 0, False, None, y_batch_stride, None, None)
     kind = "conv_igemm_fp8"
+    if prof.ACTIVE is not None:
+        kind += _p8_suffix("rn_conv_igemm_fp8_tile_rows", d, y.dtype == torch.float32)
     if prof.BY_SHAPE:
         kind += " %dx%dx%d %d->%d k%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_fp8(
@@ -856,7 +869,7 @@ def conv_igemm_fp8_grouped(problems, wq, scale, shift=None, act=ACT_NONE, out_sc
         d = g.d[i]
         total += ((d.N * d.Ho * d.Wo + trm - 1) // trm) * ((d.Cout + trn - 1) // trn)
         g.tile_end[i] = total
-    kind = "conv_igemm_fp8" + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
+    kind = "conv_igemm_fp8" + ("_p8" if (trm, trn) == (256, 256) else "") + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_fp8_grouped(
         ctypes.byref(g), wq.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), 1.0, 1.0 / float(out_scale), _hip.stream()))
     _hip.check(rc, "rn_conv_igemm_fp8_grouped")

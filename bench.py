@@ -700,11 +700,12 @@ def main():
                         kernels[kind]["traffic_over_algorithmic"] = round(kernels[kind]["traffic"] / kernels[kind]["algorithmic_bytes"], 3)
                     continue
                 tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12 if a["ms_total"] > 0 else 0.0
-                peak = PEAK_BF16_MFMA_TF if kind.endswith("_bf16") else conv_peak
+                is_bf16 = "_bf16" in kind                                        # conv_igemm_bf16, conv_igemm_bf16_p8, conv_wgrad_bf16
+                peak = PEAK_BF16_MFMA_TF if is_bf16 else conv_peak
                 kernels[kind] = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                  "frac": round(tf / peak, 4), "launches_per_step": a["launches"] // args.steps,
                                  "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
-                if split and not kind.endswith("_bf16"):
+                if split and not is_bf16:
                     # achieved = fp32 FLOPs of the convolution; the kernel executes 6 bf16 MFMA FLOPs for each of them
                     kernels[kind]["peak_note"] = "2500 TF dense bf16 MFMA / 6 MFMAs per fp32 product"
                     kernels[kind]["frac_of_fp32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TF, 4)
