@@ -537,6 +537,14 @@ extern "C" int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32
     return 128 * 1000 + 128;
 }
 
+// The tile a SINGLE launch (rn_conv_igemm_bf16) takes: rows * 1000 + cols, + 1 000 000 for the eight-wave phased kernel (profiling / tests).
+extern "C" int rn_conv_igemm_bf16_tile(const rn_conv_desc *d, int y_is_f32) {
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    if (bf16_p8_pick(d, y_is_f32, ((M + 255) / 256) * ((d->Cout + 255) / 256))) return 1000000 + 256 * 1000 + 256;
+    if (bf16_big_tile(((M + 255) / 256) * ((d->Cout + 255) / 256), d->Cout, d->kh * d->kw * d->Cin, y_is_f32)) return 256 * 1000 + 256;
+    return 128 * 1000 + 128;                                  // (or 256 x 128 for long dense launches: rn_conv_igemm_bf16)
+}
+
 extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_packed, int y_is_f32, const float *scale,
                                           const float *shift, void *stream) {
     if (g->n < 1 || g->n > RN_MAX_GROUP || ((uintptr_t)w_packed & 15)) return RN_EINVAL;

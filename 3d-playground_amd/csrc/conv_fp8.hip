@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_fp8_grouped_kernel(const rn
 
 // The eight-wave 256 x 256 x 128 tile with the phased K loop (conv_fp8_p8.hip) for stride-1 same-size layers.
 bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32);
+bool rn_fp8_p8_group_ok(const rn_conv_desc *d);
 int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift, const void *add,
                      float add_scale, float out_inv_scale, hipStream_t stream);
 int rn_fp8_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, float add_scale,
@@ -399,13 +400,19 @@ static inline bool fp8_group_is_p8(const rn_conv_group *g, int y_is_f32) {
     int64_t t = 0;
     for (int i = 0; i < g->n; ++i) t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 255) / 256);
     for (int i = 0; i < g->n; ++i)
-        if (!fp8_p8_pick(&g->d[i], y_is_f32, t)) return false;
+        if (!rn_fp8_p8_group_ok(&g->d[i]) || !fp8_p8_pick(&g->d[i], y_is_f32, t)) return false;
     return true;
 }
 // Tile shape rn_conv_igemm_fp8_grouped will use for this group (rows * 1000 + cols): the caller builds tile_end with it.
 extern "C" int rn_conv_igemm_fp8_tile_rows(const rn_conv_group *g, int y_is_f32) {
     if (g->n < 1 || g->n > RN_MAX_GROUP) return 0;
     return fp8_group_is_p8(g, y_is_f32) ? 256 * 1000 + 256 : 128 * 1000 + 128;
+}
+
+// The tile a SINGLE launch (rn_conv_igemm_fp8) takes for this problem, rows * 1000 + cols (profiling / tests; the grouped form has fewer instances).
+extern "C" int rn_conv_igemm_fp8_tile(const rn_conv_desc *d, int y_is_f32) {
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    return fp8_p8_pick(d, y_is_f32, ((M + 255) / 256) * ((d->Cout + 255) / 256)) ? 256 * 1000 + 256 : 128 * 1000 + 128;
 }
 
 static int check_desc_fp8(const rn_conv_desc *d, int y_is_f32) {

@@ -115,7 +115,10 @@ __device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_c
 // PERSIST: the workgroup computes tiles tile, tile + tile_step, ... < tile_end; the first two K-tiles of the NEXT tile are staged before
 // the epilogue of the current one (after the last barrier of a K loop no wave reads LDS any more), so a tile's load latency and its
 // epilogue overlap with its neighbours' -- what the short reductions (1x1 layers: one to eight K-tiles) are made of.
-template <bool HALF, bool PERSIST>
+// ROWS: the general stride-a geometry (a strided layer, or an output plane that is not the input plane): the pixel rows of a tile are no
+// flat sequence of the input, so the lane keeps one byte offset per pixel row (four) instead of one plus a uniform 64-row advance; taps
+// stay uniform shifts.
+template <bool HALF, bool PERSIST, bool ROWS>
 __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned char *__restrict__ x, const unsigned char *__restrict__ w,
                                         unsigned char *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
                                         const unsigned char *__restrict__ add, const Q8Args qa, int tile, const int tile_step,
@@ -143,26 +146,35 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
     int m0 = 0, n0 = 0;
     v4i32 rs_a = rs_b;
     unsigned voff_a = 0, voff_b = 0;
+    unsigned vrow[4] = {0u, 0u, 0u, 0u};         // ROWS: the byte offset of the lane's pixel row j (without tap)
     unsigned pk = 0;                             // bits 8 j + r: filter row r of pixel row j reads inside the image; 8 j + 4 + s: column s
     auto set_tile = [&](const int tl) {
         m0 = (tl / ntn) * Q8_BM;
         n0 = (tl % ntn) * Q8_BN;
-        const int base_row = m0 > halo ? m0 - halo : 0;
-        const int64_t a_bytes = ((int64_t)M - base_row) * Cin;
-        rs_a = make_rsrc(x + (int64_t)base_row * Cin, (unsigned)(a_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : a_bytes));
-        voff_a = (unsigned)((m0 - base_row + row0) * Cin + (HALF ? chunk & 3 : chunk) * 16);
+        const int n_first = ROWS ? m0 / HoWo : 0;              // ROWS: the descriptor starts at the tile's first image
+        if constexpr (ROWS) {
+            const int64_t a_bytes = (int64_t)(d.N - n_first) * d.x_batch_stride;
+            rs_a = make_rsrc(x + (int64_t)n_first * d.x_batch_stride, (unsigned)(a_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : a_bytes));
+        } else {
+            const int base_row = m0 > halo ? m0 - halo : 0;
+            const int64_t a_bytes = ((int64_t)M - base_row) * Cin;
+            rs_a = make_rsrc(x + (int64_t)base_row * Cin, (unsigned)(a_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : a_bytes));
+            voff_a = (unsigned)((m0 - base_row + row0) * Cin + (HALF ? chunk & 3 : chunk) * 16);
+        }
         voff_b = (unsigned)((n0 + row0) * K + chunk * 16);       // rows past Cout: past the descriptor's range
         pk = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + row0 + 64 * j;
             if (m < M) {
-                const unsigned rem = (unsigned)m % (unsigned)HoWo;
+                const unsigned img = (unsigned)m / (unsigned)HoWo, rem = (unsigned)m - img * (unsigned)HoWo;
                 const int oh = (int)(rem / (unsigned)d.Wo), ow = (int)(rem - (unsigned)oh * (unsigned)d.Wo);
+                if constexpr (ROWS)
+                    vrow[j] = (unsigned)(((int)img - n_first) * (int)d.x_batch_stride + (oh * d.a * d.Wi + ow * d.a) * Cin + (HALF ? chunk & 3 : chunk) * 16);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (t < d.kh && (unsigned)(oh + d.p + t * d.b) < (unsigned)d.Hi) pk |= 1u << (8 * j + t);
-                    if (t < d.kw && (unsigned)(ow + d.p_w + t * d.b) < (unsigned)d.Wi) pk |= 1u << (8 * j + 4 + t);
+                    if (t < d.kh && (unsigned)(oh * d.a + d.p + t * d.b) < (unsigned)d.Hi) pk |= 1u << (8 * j + t);
+                    if (t < d.kw && (unsigned)(ow * d.a + d.p_w + t * d.b) < (unsigned)d.Wi) pk |= 1u << (8 * j + 4 + t);
                 }
             }
         }
@@ -189,15 +201,16 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
         const unsigned dst = lds0 + (unsigned)(buf * Q8_BUFB + (wave_u + 8 * i) * 1024);
         const bool hi_live = live && kt * Q8_BK + 64 < K;        // HALF: the second half of the last K-tile may lie past K
         if (i < 4) {
-            const int sh = __builtin_amdgcn_readfirstlane(((d.p + tp.r * d.b) * d.Wi + d.p_w + tp.s * d.b + 64 * i) * Cin + tp.c);
+            const unsigned va = ROWS ? vrow[i] : voff_a;
+            const int sh = __builtin_amdgcn_readfirstlane(((d.p + tp.r * d.b) * d.Wi + d.p_w + tp.s * d.b + (ROWS ? 0 : 64 * i)) * Cin + tp.c);
             const unsigned ok = (pk >> (8 * i + (tp.r & 3))) & (pk >> (8 * i + 4 + (tp.s & 3))) & (live ? 1u : 0u);
             if constexpr (HALF) {
-                const int sh_hi = __builtin_amdgcn_readfirstlane(((d.p + th.r * d.b) * d.Wi + d.p_w + th.s * d.b + 64 * i) * Cin + th.c);
+                const int sh_hi = __builtin_amdgcn_readfirstlane(((d.p + th.r * d.b) * d.Wi + d.p_w + th.s * d.b + (ROWS ? 0 : 64 * i)) * Cin + th.c);
                 const unsigned ok_hi = (pk >> (8 * i + (th.r & 3))) & (pk >> (8 * i + 4 + (th.s & 3))) & (hi_live ? 1u : 0u);
                 const unsigned okl = hi_lane ? ok_hi : ok;
-                dma16(uni(rs_a), dst, okl ? voff_a + (unsigned)(hi_lane ? sh_hi : sh) : 0x80000000u, 0u);
+                dma16(uni(rs_a), dst, okl ? va + (unsigned)(hi_lane ? sh_hi : sh) : 0x80000000u, 0u);
             } else {
-                dma16(uni(rs_a), dst, ok ? voff_a + (unsigned)sh : 0x80000000u, 0u);
+                dma16(uni(rs_a), dst, ok ? va + (unsigned)sh : 0x80000000u, 0u);
             }
         } else {
             const bool okb = HALF ? (hi_lane ? hi_live : live) : live;
@@ -337,18 +350,18 @@ __device__ __forceinline__ void q8_tile(const rn_conv_desc &d, const unsigned ch
   }
 }
 
-template <bool HALF>
+template <bool HALF, bool ROWS>
 __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
                                                                   const unsigned char *__restrict__ w, unsigned char *__restrict__ y,
                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
                                                                   const unsigned char *__restrict__ add, const Q8Args qa) {
     extern __shared__ __attribute__((aligned(16))) char q8_lds[];
-    q8_tile<HALF, false>(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), 0, 0, q8_lds);
+    q8_tile<HALF, false, ROWS>(d, x, w, y, scale, shift, add, qa, xcd_remap(blockIdx.x, gridDim.x), 0, 0, q8_lds);
 }
 
 // Persistent form: gridDim.x (a multiple of 8) workgroups share ntiles tiles.  The workgroups of an XCD (blockIdx & 7) own one contiguous
 // range of the tiles (xcd_remap's partition) and walk it together: in pass i workgroup (x, slot) takes tile lo_x + i * gridDim.x / 8 + slot.
-template <bool HALF>
+template <bool HALF, bool ROWS>
 __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_persist_kernel(const rn_conv_desc d, const unsigned char *__restrict__ x,
                                                                           const unsigned char *__restrict__ w, unsigned char *__restrict__ y,
                                                                           const float *__restrict__ scale, const float *__restrict__ shift,
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_persist_kernel(const
     const int q = ntiles >> 3, r = ntiles & 7;
     const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, hi = lo + q + (xcd < r ? 1 : 0);
     if (lo + slot >= hi) return;
-    q8_tile<HALF, true>(d, x, w, y, scale, shift, add, qa, lo + slot, per, hi, q8_lds);
+    q8_tile<HALF, true, ROWS>(d, x, w, y, scale, shift, add, qa, lo + slot, per, hi, q8_lds);
 }
 
 // Grouped launch (rn_conv_igemm_fp8_grouped): the pyramid levels of a head layer as ONE grid; a workgroup finds its problem by tile id.
@@ -373,21 +386,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_fp8_p8_grouped_kernel(const
     for (int i = 0; i < RN_MAX_GROUP - 1; ++i) p += (i + 1 < g.n && tile >= g.tile_end[i]) ? 1 : 0;
     p = __builtin_amdgcn_readfirstlane(p);
     const int first = p > 0 ? g.tile_end[p - 1] : 0;
-    q8_tile<HALF, false>(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
+    q8_tile<HALF, false, false>(g.d[p], reinterpret_cast<const unsigned char *>(g.x[p]), w, reinterpret_cast<unsigned char *>(g.y[p]), scale, shift,
                          reinterpret_cast<const unsigned char *>(g.add[p]), qa, tile - first, 0, 0, q8_lds);
 }
 
 // ---------------------------------------------------------------------------------------------- host side (used by conv_fp8.hip)
 // What the kernel can compute: a stride-1 convolution whose output plane is the input plane, batch-dense NHWC operands, Cin a multiple of
 // 64 (half a K-tile), at most 4 x 4 taps, a dense e4m3 result, no sigmoid, no upsampled addend.
+static inline bool q8_same_size(const rn_conv_desc *d) { return d->a == 1 && d->Hi == d->Ho && d->Wi == d->Wo; }
+bool rn_fp8_p8_group_ok(const rn_conv_desc *d) { return q8_same_size(d); }
 bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32) {
-    if (y_is_f32 || d->a != 1 || d->div_shift != 0 || d->Hi != d->Ho || d->Wi != d->Wo || d->act == 2) return false;
+    if (y_is_f32 || d->a < 1 || d->a > 2 || d->div_shift != 0 || d->act == 2) return false;
     if (d->Cin < 64 || (d->Cin & 63) || (d->Cout & 15) || d->kh > 4 || d->kw > 4) return false;
-    const int64_t plane = (int64_t)d->Hi * d->Wi;
-    if (d->x_batch_stride != plane * d->Cin || d->y_batch_stride != plane * d->Cout) return false;
+    const int64_t plane = (int64_t)d->Hi * d->Wi, oplane = (int64_t)d->Ho * d->Wo;
+    if (d->x_batch_stride != plane * d->Cin || d->y_batch_stride != oplane * d->Cout) return false;
+    if (!q8_same_size(d) && ((int64_t)d->N * plane * d->Cin > 0x7fffffffLL || (d->b < 0))) return false;   // general geometry: offsets from the tile's first image
     if (d->os != 1 || d->oo_h != 0 || d->oo_w != 0 || d->Hy != d->Ho || d->Wy != d->Wo || d->add_mode == 2) return false;
     if (d->add_mode == 1 && d->add_batch_stride != d->y_batch_stride) return false;
-    const int64_t K = (int64_t)d->kh * d->kw * d->Cin, M = (int64_t)d->N * plane;
+    const int64_t K = (int64_t)d->kh * d->kw * d->Cin, M = (int64_t)d->N * oplane;
     const int64_t ab = d->b < 0 ? -d->b : d->b;
     const int64_t halo = (llabs((long long)d->p) + (d->kh - 1) * ab) * d->Wi + llabs((long long)d->p_w) + (d->kw - 1) * ab;
     if (M + 256 > 0x7fffffffLL || (256 + 2 * halo + 64) * d->Cin > 0x7fffffffLL || ((int64_t)d->Cout + 256) * K > 0x7fffffffLL) return false;
@@ -396,11 +412,15 @@ bool rn_fp8_p8_legal(const rn_conv_desc *d, int y_is_f32) {
 int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *y, const float *scale, const float *shift, const void *add,
                      float add_scale, float out_inv_scale, hipStream_t stream) {
     static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
-        return e;
+        const void *ks[] = {(const void *)conv_igemm_fp8_p8_kernel<false, false>, (const void *)conv_igemm_fp8_p8_kernel<true, false>,
+                            (const void *)conv_igemm_fp8_p8_kernel<false, true>, (const void *)conv_igemm_fp8_p8_kernel<true, true>,
+                            (const void *)conv_igemm_fp8_p8_persist_kernel<false, false>, (const void *)conv_igemm_fp8_p8_persist_kernel<true, false>,
+                            (const void *)conv_igemm_fp8_p8_persist_kernel<false, true>, (const void *)conv_igemm_fp8_p8_persist_kernel<true, true>};
+        for (const void *k : ks) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }();
     if (attr != hipSuccess) return (int)attr;
     // persistent form: one workgroup per CU (a multiple of 8) once every workgroup has at least two tiles; RN_P8_PERSIST=0: never (A/B)
@@ -420,19 +440,24 @@ int rn_fp8_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void *
     const unsigned char *xb = reinterpret_cast<const unsigned char *>(x), *wb = reinterpret_cast<const unsigned char *>(w);
     const unsigned char *ab = reinterpret_cast<const unsigned char *>(add);
     unsigned char *yb = reinterpret_cast<unsigned char *>(y);
-    const bool half = (d->Cin & 127) != 0;
+    const bool half = (d->Cin & 127) != 0, rows = !q8_same_size(d);
+    const dim3 blk(512);
+#define Q8_GO(K, H, R, G, ...) hipLaunchKernelGGL((K<H, R>), dim3((unsigned)(G)), blk, Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa, ##__VA_ARGS__)
     if (n_wg > 0 && tiles >= 2 * (int64_t)n_wg) {
-        if (half) hipLaunchKernelGGL(conv_igemm_fp8_p8_persist_kernel<true>, dim3((unsigned)n_wg), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa, (int)tiles);
-        else hipLaunchKernelGGL(conv_igemm_fp8_p8_persist_kernel<false>, dim3((unsigned)n_wg), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa, (int)tiles);
+        if (half) { if (rows) Q8_GO(conv_igemm_fp8_p8_persist_kernel, true, true, n_wg, (int)tiles); else Q8_GO(conv_igemm_fp8_p8_persist_kernel, true, false, n_wg, (int)tiles); }
+        else { if (rows) Q8_GO(conv_igemm_fp8_p8_persist_kernel, false, true, n_wg, (int)tiles); else Q8_GO(conv_igemm_fp8_p8_persist_kernel, false, false, n_wg, (int)tiles); }
     } else {
-        if (half) hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<true>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa);
-        else hipLaunchKernelGGL(conv_igemm_fp8_p8_kernel<false>, dim3((unsigned)tiles), dim3(512), Q8_LDS, stream, *d, xb, wb, yb, scale, shift, ab, qa);
+        if (half) { if (rows) Q8_GO(conv_igemm_fp8_p8_kernel, true, true, tiles); else Q8_GO(conv_igemm_fp8_p8_kernel, true, false, tiles); }
+        else { if (rows) Q8_GO(conv_igemm_fp8_p8_kernel, false, true, tiles); else Q8_GO(conv_igemm_fp8_p8_kernel, false, false, tiles); }
     }
+#undef Q8_GO
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
 int rn_fp8_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, float add_scale,
                              float out_inv_scale, hipStream_t stream) {
+    for (int i = 0; i < g->n; ++i)
+        if (!q8_same_size(&g->d[i])) return RN_EINVAL;          // the grouped form has the same-size instances only (rn_fp8_p8_group_ok)
     static const hipError_t attr = [] {
         const hipError_t e = hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_grouped_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);
         return e != hipSuccess ? e : hipFuncSetAttribute((const void *)conv_igemm_fp8_p8_grouped_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q8_LDS);

@@ -144,6 +144,8 @@ SIGNATURES.update({
     "rn_conv_igemm_bf16_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_i32, c_vp, c_vp, c_vp]),
     "rn_conv_igemm_bf16_tile_rows": (c_i32, [ctypes.POINTER(ConvGroup), c_i32]),
     "rn_conv_igemm_fp8_tile_rows": (c_i32, [ctypes.POINTER(ConvGroup), c_i32]),
+    "rn_conv_igemm_fp8_tile": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "rn_conv_igemm_bf16_tile": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "rn_fp8_quantize": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "rn_fp8_dequantize": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "rn_fp8_quantize_rows": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

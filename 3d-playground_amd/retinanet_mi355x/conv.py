@@ -629,11 +629,9 @@ def pack_weights_bf16(weight, mode=0, scale=None, c_pad=None, taps=None):
 
 
 def _p8_suffix(fn_name, d, yf32):
-    """"_p8" when the launcher takes the eight-wave 256 x 256 kernel for this problem (profiling only: the kernel families are timed apart)."""
-    g = _hip.ConvGroup()
-    g.n = 1
-    g.d[0] = d
-    return "_p8" if getattr(_hip.load(), fn_name)(ctypes.byref(g), int(yf32)) == 256256 and os.environ.get("RN_BF16_BIG_TILE", "0") in ("", "0") else ""
+    """"_p8" when a single launch takes the eight-wave 256 x 256 kernel for this problem (profiling only: the kernel families are timed apart)."""
+    t = getattr(_hip.load(), fn_name)(ctypes.byref(d), int(yf32))
+    return "_p8" if t == 256256 and fn_name.endswith("fp8_tile") or t >= 1000000 else ""
 
 
 def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
@@ -648,7 +646,7 @@ def conv_igemm_bf16(x, w_packed, y, geom, scale=None, shift=None, add=None, add_
     d.sign_out = None if bits is None else bits.data_ptr()
     kind = "conv_igemm_bf16"
     if prof.ACTIVE is not None:
-        kind += _p8_suffix("rn_conv_igemm_bf16_tile_rows", d, y.dtype == torch.float32)
+        kind += _p8_suffix("rn_conv_igemm_bf16_tile", d, y.dtype == torch.float32)
     if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
         kind += " %dx%dx%d %d->%d k%d a%d b%d ds%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh, d.a, d.b, d.div_shift)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16(
@@ -839,7 +837,7 @@ def conv_igemm_fp8(xq, wq, y, geom, scale, shift=None, add=None, add_mode=0, add
     d = _make_desc(xq, geom, act, add_mode, add_hw, 0, False, None, y_batch_stride, None, None)
     kind = "conv_igemm_fp8"
     if prof.ACTIVE is not None:
-        kind += _p8_suffix("rn_conv_igemm_fp8_tile_rows", d, y.dtype == torch.float32)
+        kind += _p8_suffix("rn_conv_igemm_fp8_tile", d, y.dtype == torch.float32)
     if prof.BY_SHAPE:
         kind += " %dx%dx%d %d->%d k%d" % (d.N, d.Ho, d.Wo, d.Cin, d.Cout, d.kh)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_fp8(

@@ -432,6 +432,10 @@ int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, v
  * ceil(N*Ho*Wo / rows) * ceil(Cout / cols) with the tile rn_conv_igemm_fp8_tile_rows reports for the group (rows * 1000 + cols:
  * 128128, or 256256 where RN_OPT_FP8_P8 selects csrc/conv_fp8_p8.hip). */
 int rn_conv_igemm_fp8_tile_rows(const rn_conv_group *g, int y_is_f32);
+/* The tile a SINGLE launch takes for this problem (profiling and tests): rows * 1000 + cols; rn_conv_igemm_bf16_tile adds 1 000 000 when
+ * the eight-wave phased kernel (csrc/conv_bf16_p8.hip) runs; for fp8, 256256 is csrc/conv_fp8_p8.hip. */
+int rn_conv_igemm_fp8_tile(const rn_conv_desc *d, int y_is_f32);
+int rn_conv_igemm_bf16_tile(const rn_conv_desc *d, int y_is_f32);
 int rn_conv_igemm_fp8_grouped(const rn_conv_group *g, const void *w_q, int y_is_f32, const float *scale, const float *shift,
                               float add_scale, float out_inv_scale, void *stream);
 

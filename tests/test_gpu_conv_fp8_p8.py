@@ -38,10 +38,8 @@ def launcher_tile(cv, x_shape, cout, k, stride, pad):
     from retinanet_mi355x import _hip
     N, H, W, cin = x_shape
     Ho, Wo = cv.out_size(H, k, stride, pad), cv.out_size(W, k, stride, pad)
-    g = _hip.ConvGroup()
-    g.n = 1
-    g.d[0] = cv._make_desc(torch.empty(x_shape, device="meta"), (Ho, Wo, cout, k, k, stride, 1, -pad, 0), 0, 0, (0, 0), 0, False, None, None, None, None)
-    return _hip.load().rn_conv_igemm_fp8_tile_rows(ctypes.byref(g), 0)
+    d = cv._make_desc(torch.empty(x_shape, device="meta"), (Ho, Wo, cout, k, k, stride, 1, -pad, 0), 0, 0, (0, 0), 0, False, None, None, None, None)
+    return _hip.load().rn_conv_igemm_fp8_tile(ctypes.byref(d), 0)
 
 
 CASES = [  # cin, cout, k, pad, N, H, W
@@ -141,7 +139,7 @@ def test_grouped_pyramid_launch_and_the_default_rule(cv, dev):
     assert launcher_tile(cv, (16, 135, 240, 256), 256, 3, 1, 1) == 256256
     assert launcher_tile(cv, (16, 68, 120, 1024), 256, 1, 1, 0) == 256256
     assert launcher_tile(cv, (16, 135, 240, 256), 80, 3, 1, 1) == 256256
-    assert launcher_tile(cv, (16, 68, 120, 256), 256, 3, 2, 1) == 128128      # strided
+    assert launcher_tile(cv, (16, 68, 120, 256), 256, 3, 2, 1) == 256256      # strided: the general-geometry instances
     assert launcher_tile(cv, (16, 270, 480, 64), 256, 1, 1, 0) == 256256       # Cin = 64: half K-tiles
     assert launcher_tile(cv, (16, 68, 120, 32), 256, 3, 1, 1) == 128128       # Cin not a multiple of 64
     cv.set_option(cv.OPT_FP8_P8, 2)
@@ -171,3 +169,33 @@ def test_persistent_form_identical_on_exact_operands(cv, dev, case):
     cv.set_option(cv.OPT_FP8_P8, 2)
     assert torch.equal(outs[0], outs[1])
     assert 0.2 < float((outs[0] > 0).float().mean()) < 0.95
+
+
+@pytest.mark.parametrize("case", [(256, 512, 1, 2, 0, 2, 18, 22), (128, 128, 3, 2, 1, 2, 21, 18), (64, 144, 1, 2, 0, 3, 15, 17),
+                                  (64, 64, 3, 2, 1, 1, 17, 19), (128, 256, 3, 1, 0, 2, 12, 14)])
+def test_strided_and_valid_geometries_identical_on_exact_operands(cv, dev, case):
+    """The general geometry (a per-lane byte offset for each of the lane's four pixel rows instead of one flat sequence): stride-2 1x1
+    shortcuts and 3x3 layers, Cin = 64 halves, an unpadded 3x3 -- byte-identical to the 128 x 128 kernel, and the function itself against
+    torch's fp64 convolution of the same exact operands."""
+    cin, cout, k, stride, pad, N, H, W = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-4, 5, (N, cin, H, W), generator=g).float()
+    w = torch.randint(-4, 5, (cout, cin, k, k), generator=g).float() / 2
+    Ho, Wo = cv.out_size(H, k, stride, pad), cv.out_size(W, k, stride, pad)
+    xq = cv.fp8_quantize(nhwc(x).to(dev), 1.0)
+    wq = cv.fp8_quantize(cv.pack_weights(w.to(dev), 0, presplit=False), 1.0)
+    geom = (Ho, Wo, cout, k, k, stride, 1, -pad, 0)
+    scale = torch.full((cout,), 2.0 ** -6, device=dev)
+    outs = []
+    for mode in (2, 0):
+        cv.set_option(cv.OPT_FP8_P8, mode)
+        assert launcher_tile(cv, xq.shape, cout, k, stride, pad) == (256256 if mode else 128128)
+        y = torch.zeros((N, Ho, Wo, cout), dtype=torch.uint8, device=dev)
+        cv.conv_igemm_fp8(xq, wq, y, geom, scale, act=cv.ACT_RELU, out_scale=1.0)
+        outs.append(y)
+    cv.set_option(cv.OPT_FP8_P8, 2)
+    assert torch.equal(outs[0], outs[1])
+    want = F.relu(F.conv2d(x.double(), w.double(), None, stride, pad)) * 2.0 ** -6
+    got = cv.fp8_dequantize(outs[0], 1.0).permute(0, 3, 1, 2).cpu().double()
+    assert float((got - want).abs().max()) <= 2.0 ** -4 * float(want.abs().max())
+    assert float(got.max()) > 0
