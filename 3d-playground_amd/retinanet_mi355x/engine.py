@@ -29,6 +29,8 @@ from . import _hip, arch, conv as cv, ops, prof
 FUSE_DY = os.environ.get("RN_WINO_FUSE_DY", "1") != "0"
 # bf16 engine: the weight gradient of a head layer over its five pyramid levels as ONE launch (rn_conv_wgrad_bf16_grouped); 0: one per level (A/B)
 GROUPED_WGRAD_BF16 = os.environ.get("RN_GROUPED_WGRAD_BF16", "1") != "0"
+# bf16 engine: the data gradient of a 1x1 stride-2 shortcut computed on its output grid and stored at the even input positions; 0: the generic form (A/B)
+S2_SHORTCUT_COMPACT = os.environ.get("RN_S2_SHORTCUT_COMPACT", "1") != "0"
 
 
 class Layer:
@@ -334,6 +336,20 @@ class Layer:
                       flops=self.flops(g.shape[0], g.shape[1], g.shape[2]))
             if s.stride == 2 and s.k > 1:
                 return cv.dgrad_s2_classes_bf16(g, self.dgrad_weights16(), in_hw, s.cin, s.k, s.pad, **kw)
+            if s.stride == 2 and s.k == 1 and s.pad == 0 and mask is None and S2_SHORTCUT_COMPACT:
+                # 1x1 stride-2 shortcut (D/model.py:265-270): its gradient exists at the EVEN input positions only.  One launch on the
+                # output grid, stored at those positions (out_map) of a zeroed tensor -- or of the addend itself, in place (the caller
+                # hands over the lateral gradient and does not use it again): a quarter of the generic form's rows (which tried its one
+                # tap at every input pixel and failed the divisibility test at three of four).
+                Hi, Wi = in_hw
+                N, Ho, Wo, _ = g.shape
+                if add is None:
+                    dx = torch.zeros((N, Hi, Wi, s.cin), dtype=torch.bfloat16, device=g.device)
+                else:
+                    assert add.shape == (N, Hi, Wi, s.cin) and add.dtype == torch.bfloat16 and add.is_contiguous()
+                    dx = add
+                return cv.conv_igemm_bf16(g, self.dgrad_weights16(), dx, (Ho, Wo, s.cin, 1, 1, 1, -1, 0, 0), out_map=(2, 0, 0, Hi, Wi),
+                                          add=add, add_mode=1 if add is not None else 0, flops=kw["flops"])
             return cv.dgrad_any_bf16(g, self.dgrad_weights16(), in_hw, s.cin, s.k, s.stride, s.pad, **kw)
         if self.wino_active and add2 is None and g.shape[3] == s.cout and g.is_contiguous():
             ready, self.dy_v = getattr(self, "dy_v", None), None

@@ -232,3 +232,26 @@ def test_grouped_weight_gradient_over_pyramid_levels(cv, dev):
     for g, x in zip(gs, xs):
         cv.wgrad_bf16(g, x, dw1, cout, 3, 1, 1)
     close_f32(dw, dw1, tol=2e-5)
+
+
+@pytest.mark.parametrize("with_add", [False, True])
+def test_stride2_shortcut_gradient_on_the_output_grid(cv, dev, with_add):
+    """The bf16 engine's data gradient of a 1x1 stride-2 shortcut (D/model.py:265-270; engine.py: Layer.bwd_data): one launch on the
+    OUTPUT grid stored at the even input positions of a zeroed tensor -- or of the addend, in place -- against the generic form that
+    tries the tap at every input pixel: the same products in the same order, so the two must agree bit for bit; odd sizes included."""
+    cin, cout, N, H, W = 64, 128, 2, 19, 23
+    Ho, Wo = cv.out_size(H, 1, 2, 0), cv.out_size(W, 1, 2, 0)
+    w = rnd((cout, cin, 1, 1), 71, 0.1)
+    g = cv.to_bf16(nhwc(rnd((N, cout, Ho, Wo), 72)).to(dev))
+    add = cv.to_bf16(nhwc(rnd((N, cin, H, W), 73)).to(dev)) if with_add else None
+    wd = cv.pack_weights_bf16(w.to(dev), 1)
+    kw = dict(add=add, add_mode=1) if with_add else {}
+    want = cv.dgrad_any_bf16(g, wd, (H, W), cin, 1, 2, 0, **kw)
+    dx = add.clone() if with_add else torch.zeros((N, H, W, cin), dtype=torch.bfloat16, device=dev)
+    cv.conv_igemm_bf16(g, wd, dx, (Ho, Wo, cin, 1, 1, 1, -1, 0, 0), out_map=(2, 0, 0, H, W), add=dx if with_add else None,
+                       add_mode=1 if with_add else 0)
+    assert torch.equal(dx, want)
+    ref = F.conv_transpose2d(r16(nchw(g.float().cpu())), r16(w), stride=2, output_padding=(H - 1 - 2 * (Ho - 1), W - 1 - 2 * (Wo - 1)))
+    if with_add:
+        ref = ref + nchw(add.float().cpu())
+    close_bf16(nchw(dx.float()), ref)
