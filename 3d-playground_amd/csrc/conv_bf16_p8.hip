@@ -177,12 +177,23 @@ __device__ __forceinline__ void p8_tile(const rn_conv_desc &d, const __bf16 *__r
         o.z = __builtin_amdgcn_readfirstlane(r.z); o.w = __builtin_amdgcn_readfirstlane(r.w);
         return o;
     };
-    auto dma = [&](const int i, const P8Tap &tp, const int kt, const int buf) {   // instruction i of this wave for K-tile kt (at tap tp)
+    // The pixel offsets of the four staging instructions AT THE CURRENT TAP (validity applied): recomputed when the staging cursor enters
+    // a new tap (every Cin / 64 K-tiles), so that a K-tile's staging is four buffer loads with a scalar channel offset and no vector
+    // arithmetic.  (Counters, profiles/r04_pmc_p8.txt: 2.1 VALU instructions per MFMA -- with the MFMA's own 8 issue cycles that fills
+    // the 16-cycle slot; the per-instruction offset arithmetic was a fifth of them.)
+    unsigned va[4];
+    auto set_tap = [&](const P8Tap &tp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sh = __builtin_amdgcn_readfirstlane((((d.p + tp.r * d.b) * d.Wi + d.p_w + tp.s * d.b + 64 * i) * Cin) * 2);
+            const unsigned ok = (P8_ABL & 2) ? 1u : (pk >> (8 * i + (tp.r & 3))) & (pk >> (8 * i + 4 + (tp.s & 3))) & 1u;
+            va[i] = ok ? voff_a + (unsigned)sh : 0x80000000u;
+        }
+    };
+    auto dma = [&](const int i, const P8Tap &tp, const int kt, const int buf) {   // instruction i of this wave for K-tile kt (at tap tp: set_tap)
         const unsigned dst = lds0 + (unsigned)(buf * P8_BUFB + (wave_u + 8 * i) * 1024);
         if (i < 4) {
-            const int sh = __builtin_amdgcn_readfirstlane((((d.p + tp.r * d.b) * d.Wi + d.p_w + tp.s * d.b + 64 * i) * Cin + tp.c) * 2);
-            const unsigned ok = (P8_ABL & 2) ? 1u : (pk >> (8 * i + tp.r)) & (pk >> (8 * i + 4 + tp.s)) & 1u;
-            dma16(uni(rs_a), dst, ok ? voff_a + (unsigned)sh : 0x80000000u, 0u);
+            dma16(uni(rs_a), dst, va[i], (unsigned)__builtin_amdgcn_readfirstlane(tp.c * 2));
         } else {
             dma16(uni(rs_b), dst, voff_b, (unsigned)__builtin_amdgcn_readfirstlane((kt * P8_BK + (i - 4) * 64 * K) * 2));
         }
@@ -232,10 +243,12 @@ __device__ __forceinline__ void p8_tile(const rn_conv_desc &d, const __bf16 *__r
 
     // ---- prologue: K-tile 0 -> buffer 0, K-tile 1 -> buffer 1 (all 8 instructions each); wait for tile 0, read its first fragments
     P8Tap t1 = {0, 0, 0};
+    set_tap(t1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma(i, t1, 0, 0);
     next_tap(t1);
     if (nkt > 1) {
+        if (t1.c == 0) set_tap(t1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dma(i, t1, 1, 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -244,6 +257,7 @@ __device__ __forceinline__ void p8_tile(const rn_conv_desc &d, const __bf16 *__r
     }
     P8Tap t2 = t1;                                              // the tap of K-tile t + 2 (in body(t))
     next_tap(t2);
+    if (t2.c == 0 && nkt > 2) set_tap(t2);                      // va[] always belongs to t2's tap from here on
     asm volatile("s_barrier" ::: "memory");
     read_a(fa0, lds, 0);
     read_b(fb0, lds, 0);
@@ -297,6 +311,7 @@ __device__ __forceinline__ void p8_tile(const rn_conv_desc &d, const __bf16 *__r
             }
         }
         next_tap(t2);
+        if (t2.c == 0 && t + 3 < nkt) set_tap(t2);              // the staging cursor entered a new tap
     };
     if (P8_STAGGER == 2 && wr) {
         for (int t = 0; t < nkt; t += 2) {
