@@ -49,6 +49,20 @@ def detector(dev):
     return net.to(dev).eval()
 
 
+def set_dtype(net, dtype, dev):
+    """--dtype bf16: DESIGN.md 4.5; --dtype fp8: DESIGN.md 4.7 (e4m3 activations / weights; the per-tensor scales are calibrated here on
+    two noise frames drawn like the benchmark's, through the fp32 engine).  Both opt-in, neither the reference's arithmetic."""
+    if dtype == "bf16":
+        net.set_compute_dtype("bf16")
+    elif dtype == "fp8":
+        from retinanet_mi355x import ops
+        g = torch.Generator().manual_seed(11)
+        f = torch.randint(0, 256, (2, H, W, 3), generator=g, dtype=torch.uint8).to(dev).float() / 255.0
+        mean = torch.tensor(ops.IMAGENET_MEAN, device=dev).view(1, 1, 1, 3)
+        std = torch.tensor(ops.IMAGENET_STD, device=dev).view(1, 1, 1, 3)
+        net.calibrate_fp8(((f - mean) / std).permute(0, 3, 1, 2).contiguous(), margin=1.25)
+
+
 def tracker(dev, names):
     P, Hm = synth.camera_matrices(len(names), seed=5)
     P2, H2 = synth.camera_matrices(len(names), seed=55)
@@ -89,8 +103,7 @@ def sharded(args, rank, local, world):
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     net = detector(dev)
-    if args.dtype == "bf16":
-        net.set_compute_dtype("bf16")
+    set_dtype(net, args.dtype, dev)
     names = multicam.CAMERAS[:args.cams] if args.cams <= 18 else ["cam%d" % i for i in range(args.cams)]
     mine = multicam.shard(args.cams, world, rank)
     me = tracker(dev, names)
@@ -183,7 +196,8 @@ def main():
     ap.add_argument("--cams", type=int, default=18)
     ap.add_argument("--batch", type=int, default=3, help="cameras per detector call (18 cameras over 8 GPUs: 2-3 each)")
     ap.add_argument("--iters", type=int, default=5, help="time steps (one frame from every camera each)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="bf16: DESIGN.md 4.5 (opt-in, not the reference's arithmetic)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp8"],
+                    help="bf16: DESIGN.md 4.5, fp8: DESIGN.md 4.7 (opt-in, not the reference's arithmetic)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
@@ -194,8 +208,7 @@ def main():
         return sharded(args, rank, local, world)
     dev = torch.device("cuda:0")
     net = detector(dev)
-    if args.dtype == "bf16":
-        net.set_compute_dtype("bf16")
+    set_dtype(net, args.dtype, dev)
     names = ["p%dc%d" % (p, c) for p in (1, 2, 3) for c in range(1, 7)][:args.cams]
     me = tracker(dev, names)
     g = torch.Generator().manual_seed(7)

@@ -35,6 +35,7 @@ if [ "$part" = 3 ]; then
   timeout -k 10 300 python3 tools/bench_infer.py --sharded >> "$O/infer_cfg4.txt" 2>&1
   RN_REHEARSE_ONE_GPU=1 timeout -k 10 400 python3 tools/bench_infer.py --gpus 2 --iters 3 >> "$O/infer_cfg4.txt" 2>&1
   timeout -k 10 300 python3 tools/bench_infer.py --dtype bf16 >> "$O/infer_cfg4.txt" 2>&1
+  timeout -k 10 300 python3 tools/bench_infer.py --dtype fp8 >> "$O/infer_cfg4.txt" 2>&1
   timeout -k 10 500 bash tools/rehearse_ddp.sh > "$O/ddp_rehearsal.txt" 2>&1
   RN_REHEARSE_ONE_GPU=1 timeout -k 10 500 python3 tools/train_ddp.py --gpus 2 --epochs 2 --iters 3 --batch 2 --out "$O/train_ddp_ck" > "$O/train_ddp_rehearsal.txt" 2>&1
   rm -rf "$O/train_ddp_ck"
