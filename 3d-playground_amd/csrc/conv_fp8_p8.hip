@@ -77,6 +77,15 @@ __device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_c
         sc[cb][0] = f32x2{s4.x * is, s4.y * is}; sc[cb][1] = f32x2{s4.z * is, s4.w * is};
         sh[cb][0] = f32x2{h4.x * is, h4.y * is}; sh[cb][1] = f32x2{h4.z * is, h4.w * is};
     }
+    // all eight pixel blocks' addends are requested before the first is used (a residual 1x1 layer's tile is mostly this round trip)
+    i32x4 aqs[8];
+    if constexpr (ADD) {
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {
+            const int m = mw + rb * 16 + lr;
+            aqs[rb] = *reinterpret_cast<const i32x4 *>(add + (int64_t)(m < M ? m : M - 1) * d.Cout + col);
+        }
+    }
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
         const int m = mw + rb * 16 + lr;
@@ -85,7 +94,7 @@ __device__ __forceinline__ void q8_epilogue(const f32x4 (&acc)[8][4], const rn_c
         unsigned aq[4] = {0u, 0u, 0u, 0u};
         if constexpr (ADD) {
             if (!(Q8_ABL & 2)) {
-                const i32x4 t = *reinterpret_cast<const i32x4 *>(add + off);
+                const i32x4 t = aqs[rb];
                 aq[0] = (unsigned)t[0]; aq[1] = (unsigned)t[1]; aq[2] = (unsigned)t[2]; aq[3] = (unsigned)t[3];
             }
             q8_transpose4(aq);                                   // -> the lane's four channels of block cb in aq[cb]
