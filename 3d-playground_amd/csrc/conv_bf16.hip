@@ -442,15 +442,15 @@ int rn_bf16_p8_launch(const rn_conv_desc *d, const void *x, const void *w, void 
 int rn_bf16_p8_launch_grouped(const rn_conv_group *g, int tiles, const void *w, const float *scale, const float *shift, hipStream_t stream);
 // RN_OPT_BF16_P8: 0 never, 2 wherever legal, 1 (default): full 256-channel tiles (Cout % 256 == 0), at least 200 tiles in the launch
 // (RN_BF16_P8_MIN_TILES; one workgroup per CU: below ~a round of the 256 CUs the 128 x 128 tile's four workgroups per CU win), and either a
-// reduction of at least 1024 (RN_BF16_P8_MIN_K) or NO mask operand: the short reductions are all epilogue, and the kernel requests every
+// reduction of at least 256 (RN_BF16_P8_MIN_K) or NO mask operand: the short reductions are all epilogue, and the kernel requests every
 // addend of a tile up front when there is no mask (the bottlenecks' conv3 + identity + ReLU: 1x1 64 -> 256 1.34 -> 0.96 ms per step, 128 ->
-// 512 0.81 -> 0.60, 256 -> 1024 0.70 -> 0.53) but operand pair by operand pair when there is one (their data gradients: 5-20 % slower
-// than the 128 x 128 kernel).  Measured per layer shape in profiles/r04_bf16_p8_by_shape.txt and r04_bf16_p8_short_k.txt.
+// 512 0.81 -> 0.60, 256 -> 1024 0.70 -> 0.53) and both operands of two pixel blocks at a time when there is one (their data gradients:
+// equal to the 128 x 128 kernel at K = 64 / 128, 5 % faster at K = 256).  Per layer shape: profiles/r04_bf16_p8_by_shape.txt, r04_bf16_p8_short_k.txt.
 static inline bool bf16_p8_pick(const rn_conv_desc *d, int y_is_f32, int64_t tiles_in_launch) {
     const int mode = rn_get_option(RN_OPT_BF16_P8);
     if (mode == 0 || !rn_bf16_p8_legal(d, y_is_f32)) return false;
     if (mode == 2) return true;
-    static const int min_k = [] { const char *e = getenv("RN_BF16_P8_MIN_K"); return e ? atoi(e) : 1024; }();
+    static const int min_k = [] { const char *e = getenv("RN_BF16_P8_MIN_K"); return e ? atoi(e) : 256; }();
     static const int min_tiles = [] { const char *e = getenv("RN_BF16_P8_MIN_TILES"); return e ? atoi(e) : 200; }();
     if ((d->Cout & 255) != 0 || tiles_in_launch < min_tiles) return false;
     return d->kh * d->kw * d->Cin >= min_k || d->mask_mode == 0;

@@ -73,33 +73,39 @@ __device__ __forceinline__ void p8_epilogue(const f32x4 (&acc)[8][4], const rn_c
     // A residual layer without a mask (the bottleneck's conv3 + identity + ReLU, D/utils.py:60-80): all sixteen addend chunks of the lane
     // are requested before the first is used -- 64 registers the K loop no longer needs; requested pair by pair they were sixteen
     // serialized round trips per tile (conv_fp8_p8.hip: the same change took its residual 1x1 layers from 2.8 to 3.6 TB/s).
-    bf16x8 ads[8][2];
-    if constexpr (MM == 0) {
-        if (has_add) {
-#pragma unroll
-            for (int rb = 0; rb < 8; ++rb) {
-                const int m = mw + rb * 16 + lr;
-                const int64_t rowoff = (int64_t)(m < M ? m : M - 1) * d.Cout;
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) ads[rb][pr] = *reinterpret_cast<const bf16x8 *>(add + rowoff + col[pr]);
-            }
-        }
-    }
+    // With a mask operand (data gradients) both operands are requested for TWO pixel blocks at a time -- four round trips per tile, 32
+    // registers -- instead of pair by pair.
+    constexpr int RB_AHEAD = MM == 0 ? 8 : 2;                    // pixel blocks whose operands are in flight together
+    bf16x8 ads[RB_AHEAD][2], mks[MM == 0 ? 1 : RB_AHEAD][2];
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
+        if (rb % RB_AHEAD == 0) {
+#pragma unroll
+            for (int r2 = 0; r2 < RB_AHEAD; ++r2) {
+                const int m = mw + (rb + r2) * 16 + lr;
+                const int64_t rowoff = (int64_t)(m < M ? m : M - 1) * d.Cout;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    if constexpr (MM != 0) {
+                        if (!mbits) mks[r2][pr] = *reinterpret_cast<const bf16x8 *>(mask + rowoff + col[pr]);
+                    }
+                    if (has_add) ads[r2][pr] = *reinterpret_cast<const bf16x8 *>(add + rowoff + col[pr]);
+                }
+            }
+        }
         const int m = mw + rb * 16 + lr;
         const bool row_ok = m < M;
         const int64_t rowoff = (int64_t)(row_ok ? m : M - 1) * d.Cout;
         unsigned mk[2];                                          // MM != 0: bit j = the mask of channel j of the pair's chunk
         bf16x8 ad[2];
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {                         // both pairs' operands requested before either is finished
+        for (int pr = 0; pr < 2; ++pr) {
             const int64_t off = rowoff + col[pr];
             if constexpr (MM != 0) {
                 if (mbits) {
                     mk[pr] = rn_sign_bits(mask, off, 8);
                 } else {
-                    const bf16x8 t = *reinterpret_cast<const bf16x8 *>(mask + off);
+                    const bf16x8 t = mks[rb % RB_AHEAD][pr];
                     unsigned b = 0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) b |= (unsigned)((float)t[j] > 0.f) << j;
@@ -107,8 +113,7 @@ __device__ __forceinline__ void p8_epilogue(const f32x4 (&acc)[8][4], const rn_c
                 }
             }
             const bf16x8 zero = {};
-            if constexpr (MM == 0) ad[pr] = has_add ? ads[rb][pr] : zero;
-            else ad[pr] = has_add ? *reinterpret_cast<const bf16x8 *>(add + off) : zero;
+            ad[pr] = has_add ? ads[rb % RB_AHEAD][pr] : zero;
         }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
