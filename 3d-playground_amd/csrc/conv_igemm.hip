@@ -92,6 +92,7 @@ extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_pack
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < g->n; ++i)
         if (g->d[i].w_format != d0.w_format) return RN_EINVAL;
+    if (d0.w_format == 2) return RN_EINVAL;                                          // one-term products: single launches only
     if (d0.w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;   // the pre-split form is an operand of the split kernels only
     if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d0.w_format == 1 || d0.kh * d0.kw * d0.Cin >= rn_fp32_split_min_k()))
         return rn_igemm_split_grouped_launch(narrow, (unsigned)prev, g, w_packed, scale, shift, s);
@@ -124,6 +125,12 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
     const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0 &&
                      d->sign_out == nullptr;
+    if (d->w_format == 2) {
+        // pre-split weights, products from the first bf16 terms only: whatever the fp32 product mode (it is not fp32 arithmetic),
+        // narrow instances only, no input ReLU (rn_igemm_split_launch)
+        if (!narrow || d->in_relu) return RN_EINVAL;
+        return rn_igemm_split_launch(dense ? 2 : 3, (unsigned)tiles, d, x, w_packed, y, scale, shift, add, mask, add2, s);
+    }
     if (d->w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;
     if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d->w_format == 1 || d->kh * d->kw * d->Cin >= rn_fp32_split_min_k()))
         return rn_igemm_split_launch(raw ? 0 : (d->in_relu ? 1 : (narrow ? (dense ? 2 : 3) : (dense ? 4 : 5))), (unsigned)tiles, d, x,

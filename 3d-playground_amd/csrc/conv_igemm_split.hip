@@ -16,13 +16,13 @@
 // four (13-18 spilled registers) the implicit-GEMM family takes 46.3 instead of 42.6 ms per training step.
 #include "conv_igemm_tile.h"
 
-template <int WM, int WN, bool GENERAL, bool RELU, bool RAW, int SPLIT, int BK = 16>
+template <int WM, int WN, bool GENERAL, bool RELU, bool RAW, int SPLIT, int BK = 16, int TERMS = 3>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                                   const float *__restrict__ w, float *__restrict__ y,
                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
                                                                   const float *__restrict__ add, const float *__restrict__ mask,
                                                                   const float *__restrict__ add2) {
-    conv_igemm_tile<WM, WN, GENERAL, BK, RELU, RAW, SPLIT>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_igemm_tile<WM, WN, GENERAL, BK, RELU, RAW, SPLIT, TERMS>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 template <int WM, int WN, int SPLIT, int BK = 16>
@@ -72,6 +72,15 @@ static int dbg_dyn_lds(const void *fn) {                  // occupancy experimen
 int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, const float *x, const float *w, float *y,
                           const float *scale, const float *shift, const float *add, const float *mask, const float *add2,
                           hipStream_t s) {
+    if (d->w_format == 2) {
+        // pre-split weights, products from the first bf16 terms only (the fp32 stem of the bf16 / fp8 engines): the narrow instances
+        const dim3 grid1(tiles), block1(256);
+        if (variant == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<4, 1, false, false, false, 2, 16, 1>), grid1, block1, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else if (variant == 3) hipLaunchKernelGGL((conv_igemm_split_kernel<4, 1, true, false, false, 2, 16, 1>), grid1, block1, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+        else return RN_EINVAL;
+        RN_LAUNCH_CHECK();
+        return RN_OK;
+    }
     {
         int rc = RN_OK;
         if (rn_igemm_big_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;

@@ -140,7 +140,9 @@ __device__ __forceinline__ int lds_swz(int row) {
 //            vector ALU work of SPLIT 1.  Within a plane the two 16-byte chunks of a row swap places in rows 16-31 of
 //            every 32 (position 2*row + (chunk ^ ((row >> 4) & 1))), which makes the ds_read_b128 of [row = lane & 31]
 //            [chunk = lane >> 5] conflict-free (16 distinct 16-byte bank groups per servicing group of 16 lanes).
-template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false, int SPLIT = 0>
+// TERMS 1 (SPLIT 2 only; rn_conv_desc.w_format 2): products from the operands' FIRST bf16 terms only -- one MFMA instead of six: the
+// arithmetic of the bf16 / fp8 engines (their fp32 stem), not of the fp32 path.
+template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false, int SPLIT = 0, int TERMS = 3>
 __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const float *__restrict__ x,
                                                 const float *__restrict__ w, float *__restrict__ y,
                                                 const float *__restrict__ scale, const float *__restrict__ shift,
@@ -160,6 +162,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     constexpr int STEP = SPLIT == 3 ? 3 * (APL + BPL) : (SPLIT == 2 ? BM * BK + SUB * 3 * BPL : (BM + BN) * BK);   // floats per buffer: A rows (planes), then B rows (planes)
     constexpr int UPT = BM * 2 / 256;                      // SPLIT 3: (row, 8-value half) units of the A tile per thread
     static_assert(SPLIT != 3 || (BK == 16 && UPT == 1), "SPLIT 3: 16-wide K-steps, 128-row tiles");
+    static_assert(TERMS == 3 || SPLIT == 2, "one-term products: the pre-split-weights form only");
     constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
 #ifndef RN_SPLIT_NBUF
 #define RN_SPLIT_NBUF 2
@@ -425,7 +428,10 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+                    for (int tn = 0; tn < 2; ++tn) {
+                        if constexpr (TERMS == 1) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[tm].h, sb[tn].h, acc[tm][tn], 0, 0, 0);
+                        else RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+                    }
             }
             return;
         }
@@ -718,7 +724,7 @@ static inline int check_desc(const rn_conv_desc *d) {
     if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0 || (d->add2_mode != 0 && d->add2_mode != 3)) return RN_EINVAL;
     if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
     if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
-    if (d->w_format < 0 || d->w_format > 1) return RN_EINVAL;
+    if (d->w_format < 0 || d->w_format > 2) return RN_EINVAL;
     if (d->w_batch_stride < 0 || (d->w_batch_stride != 0 && ((int64_t)d->Ho * d->Wo) % 256 != 0)) return RN_EINVAL;
     return RN_OK;
 }

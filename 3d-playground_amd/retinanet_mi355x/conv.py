@@ -75,7 +75,7 @@ def _mask_operand(mask, mask_mode):
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
                mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0,
-               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False):
+               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False, bf16_products=False):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift) with p an int or (p_rows, p_cols).
     out_map = (os, oo_h, oo_w, Hy, Wy) stores output pixel (oh,ow) at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
@@ -108,6 +108,11 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
         _hip.check(rc, "rn_conv_igemm_splitk")
         return y
     wptr, d.w_format = _w_operand(w_packed)
+    if bf16_products:                      # the fp32 stem of the bf16 / fp8 engines: products from the first bf16 terms (w_format 2)
+        ws = getattr(w_packed, "_rn_split", None)
+        if ws is None:
+            ws = split_weights(w_packed)._rn_split
+        wptr, d.w_format = ws.data_ptr(), 2
     nb = 0.0
     if prof.ACTIVE is not None:            # algorithmic bytes: every operand once (the split kernels read weights as 6-byte terms)
         out_el = N * Ho * Wo * Cout

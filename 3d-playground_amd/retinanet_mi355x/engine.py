@@ -31,6 +31,8 @@ FUSE_DY = os.environ.get("RN_WINO_FUSE_DY", "1") != "0"
 GROUPED_WGRAD_BF16 = os.environ.get("RN_GROUPED_WGRAD_BF16", "1") != "0"
 # bf16 engine: the data gradient of a 1x1 stride-2 shortcut computed on its output grid and stored at the even input positions; 0: the generic form (A/B)
 S2_SHORTCUT_COMPACT = os.environ.get("RN_S2_SHORTCUT_COMPACT", "1") != "0"
+# bf16 / fp8 engines: the fp32 stem's FORWARD products from the first bf16 terms only; 0: the fp32 path's split / native products (A/B)
+STEM_BF16_PRODUCTS = os.environ.get("RN_STEM_BF16_PRODUCTS", "1") != "0"
 
 
 class Layer:
@@ -168,7 +170,8 @@ class Layer:
             out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.float32, device=x.device)
         cv.conv_igemm(x, self.wf, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0), scale=self.scale,
                       shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
-                      y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo), sign=sign)
+                      y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo), sign=sign,
+                      bf16_products=getattr(self, "bf16_products", False))
         self._tap(out if y_batch_stride is None else None)
         return out
 
@@ -459,6 +462,9 @@ class Engine:
         for spec, role, pre in arch.backbone_convs(arch_name):
             if role == "stem":
                 self.layers[spec.name] = Layer(spec, kw_pad=8, cin_pad=4)
+                # bf16 / fp8 engines: the stem's tensors stay fp32 (3-channel input, max-pool boundary) but its products are formed from
+                # the first bf16 terms of both operands (rn_conv_desc.w_format 2): the engine's arithmetic, one MFMA instead of six
+                self.layers[spec.name].bf16_products = (self.bf16 or self.fp8) and STEM_BF16_PRODUCTS
                 continue
             self.layers[spec.name] = Layer(spec, bf16=self.bf16, fp8=self.fp8)
             if cur is None or cur[0] != pre:
@@ -647,9 +653,10 @@ class Engine:
 
         presplit = cv.PRESPLIT and cv.get_fp32_mfma() == "split" and not self.bf16
 
-        def split_job(src):
-            """split mode: the pre-split twin of a packed fp32 buffer (cv.split_weights' attribute), filled by launch 2."""
-            if not presplit or src.shape[-1] < _hip.load().rn_fp32_split_min_k():
+        def split_job(src, force=False):
+            """split mode: the pre-split twin of a packed fp32 buffer (cv.split_weights' attribute), filled by launch 2.
+            force: the stem of the bf16 / fp8 engines, whose one-term products read the twin's first plane in every mode."""
+            if not force and (not presplit or src.shape[-1] < _hip.load().rn_fp32_split_min_k()):
                 return
             dst = torch.empty(src.numel() * 6, dtype=torch.uint8, device=dev)
             j = _hip.PrepJob()
@@ -680,7 +687,7 @@ class Engine:
             b = bufs[name] = {}
             b["wf"] = torch.empty((cout, (kh * L.kw_pad * L.cin_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
             add(0, pack_job(w, b["wf"], 0, L.kw_pad, L.cin_pad, None), b["wf"].numel())
-            split_job(b["wf"])
+            split_job(b["wf"], force=getattr(L, "bf16_products", False))
             if L.bf16:
                 b["wf16"] = cast_job(b["wf"])
             scale = None

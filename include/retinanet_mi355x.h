@@ -261,7 +261,10 @@ typedef struct rn_conv_desc {
                                       independent GEMMs in one launch (the 36 positions of the Winograd path); Ho*Wo must then
                                       be a multiple of 256 so that no tile spans two images */
     int w_format;                  /* 0: w_packed is the fp32 tensor of rn_pack_weights; 1: its pre-split form (rn_split_weights),
-                                      accepted in RN_FP32_SPLIT mode only (RN_EINVAL otherwise; not by the split-K form) */
+                                      accepted in RN_FP32_SPLIT mode only (RN_EINVAL otherwise; not by the split-K form);
+                                      2 (round 4): the pre-split form, and the products are formed from the operands' FIRST bf16
+                                      terms only (one MFMA instead of six) -- bf16 arithmetic on fp32 tensors, for the fp32 stem of
+                                      the bf16 / fp8 engines; layers with at most 64 output channels, single launches */
     void *sign_out;                /* NULL, or uint32 words that receive the SIGN BITS of the result: bit (e & 31) of word (e >> 5)
                                       = (y[e] > 0) for every stored element at float offset e -- what the backward pass needs of a ReLU
                                       output (D/utils.py:60-80), at 1/32 of the bytes.  Needs Cout % 32 == 0 and y_batch_stride % 32

@@ -255,3 +255,25 @@ def test_stride2_shortcut_gradient_on_the_output_grid(cv, dev, with_add):
     if with_add:
         ref = ref + nchw(add.float().cpu())
     close_bf16(nchw(dx.float()), ref)
+
+
+@pytest.mark.parametrize("case", [(4, 64, 7, 2, 3, 2, 45, 61), (4, 64, 7, 2, 3, 1, 128, 96), (32, 48, 3, 1, 1, 2, 17, 19)])
+def test_fp32_tensors_with_bf16_products(cv, dev, case):
+    """rn_conv_desc.w_format 2 (the fp32 stem of the bf16 / fp8 engines, D/model.py:208-232): fp32 activations and packed fp32 weights,
+    products formed from their FIRST bf16 terms only -- exactly the fp32 convolution of the bf16-rounded operands (products of bf16 values
+    are exact in fp32, only the summation order differs: the 2e-5 of the other fp32-result tests), with the folded batch norm and ReLU."""
+    cin, cout, k, stride, pad, N, H, W = case
+    x, w = rnd((N, cin, H, W), 81), rnd((cout, cin, k, k), 82, (2.0 / (k * k * cin)) ** 0.5)
+    scale, shift = rnd((cout,), 83, 0.3) + 1.0, rnd((cout,), 84, 0.2)
+    kw_pad = 8 if k == 7 else k
+    wp = cv.pack_weights(w.to(dev), 0, kw_pad=kw_pad, c_pad=(cin + 3) // 4 * 4)
+    Ho, Wo = cv.out_size(H, k, stride, pad), cv.out_size(W, k, stride, pad)
+    y = torch.empty((N, Ho, Wo, cout), device=dev)
+    cv.conv_igemm(nhwc(x).to(dev), wp, y, (Ho, Wo, cout, k, kw_pad, stride, 1, -pad, 0), scale=scale.to(dev), shift=shift.to(dev),
+                  act=cv.ACT_RELU, bf16_products=True)
+    want = F.relu(F.conv2d(r16(x), r16(w), None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    close_f32(nchw(y), want)
+    # and it is NOT the fp32 path's result: the operands' second and third terms are missing
+    y32 = torch.empty_like(y)
+    cv.conv_igemm(nhwc(x).to(dev), wp, y32, (Ho, Wo, cout, k, kw_pad, stride, 1, -pad, 0), scale=scale.to(dev), shift=shift.to(dev), act=cv.ACT_RELU)
+    assert float((y - y32).abs().max()) > 1e-4 * float(y32.abs().max())
