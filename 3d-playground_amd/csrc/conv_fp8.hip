@@ -282,6 +282,16 @@ __device__ __forceinline__ void conv_igemm_fp8_tile(const rn_conv_desc &d, const
     const bool col_ok = col < d.Cout;
     unsigned char *yq = reinterpret_cast<unsigned char *>(yv);
     float *yf = reinterpret_cast<float *>(yv);
+    // the lane's CH scale / shift values once per tile (they were re-read per row and element), and a dense result without the pixel
+    // decomposition (round 4: the layers this kernel keeps -- 3x3 with <= 64 output channels, the fp32 head outputs -- are all epilogue)
+    float scv[CH], shv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        scv[j] = (col_ok && scale != nullptr) ? scale[col + j] : 1.f;
+        shv[j] = (col_ok && shift != nullptr) ? shift[col + j] : 0.f;
+    }
+    const bool dense = d.os == 1 && d.oo_h == 0 && d.oo_w == 0 && d.Hy == d.Ho && d.Wy == d.Wo && d.y_batch_stride == (int64_t)HoWo * d.Cout &&
+                       d.add_mode != 2 && (d.add_mode == 0 || d.add_batch_stride == d.y_batch_stride);
 #pragma unroll 1
     for (int pass = 0; pass < BM / RP; ++pass) {
         if (pass) __syncthreads();
@@ -300,16 +310,21 @@ __device__ __forceinline__ void conv_igemm_fp8_tile(const rn_conv_desc &d, const
         for (int r = tid / CPR; r < RP; r += RPP) {
             const int64_t m = (int64_t)m0 + pass * RP + r;
             if (m >= M) break;
-            const unsigned mu = (unsigned)m;
-            const int n = (int)(mu / (unsigned)HoWo);
-            const int rem = (int)(mu - (unsigned)n * (unsigned)HoWo);
-            const int oh = (int)((unsigned)rem / (unsigned)d.Wo), ow = rem - oh * d.Wo;
-            const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
-            const int64_t pix = (int64_t)ph * d.Wy + pw;
-            const int64_t off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
-            int64_t aoff = -1;
-            if (d.add_mode == 1) aoff = (int64_t)n * d.add_batch_stride + pix * d.Cout + col;
-            else if (d.add_mode == 2) aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col;
+            int64_t off, aoff = -1;
+            if (dense) {
+                off = m * d.Cout + col;
+                if (d.add_mode == 1) aoff = off;
+            } else {
+                const unsigned mu = (unsigned)m;
+                const int n = (int)(mu / (unsigned)HoWo);
+                const int rem = (int)(mu - (unsigned)n * (unsigned)HoWo);
+                const int oh = (int)((unsigned)rem / (unsigned)d.Wo), ow = rem - oh * d.Wo;
+                const int ph = oh * d.os + d.oo_h, pw = ow * d.os + d.oo_w;
+                const int64_t pix = (int64_t)ph * d.Wy + pw;
+                off = (int64_t)n * d.y_batch_stride + pix * d.Cout + col;
+                if (d.add_mode == 1) aoff = (int64_t)n * d.add_batch_stride + pix * d.Cout + col;
+                else if (d.add_mode == 2) aoff = (int64_t)n * d.add_batch_stride + ((int64_t)(oh >> 1) * d.Wa + (ow >> 1)) * d.Cout + col;
+            }
             float v[CH];
 #pragma unroll
             for (int q = 0; q < CH / 4; ++q) {
@@ -323,8 +338,7 @@ __device__ __forceinline__ void conv_igemm_fp8_tile(const rn_conv_desc &d, const
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const float sc = scale != nullptr ? scale[col + j] : 1.f, sh = shift != nullptr ? shift[col + j] : 0.f;
-                float u = v[j] * sc + sh;
+                float u = v[j] * scv[j] + shv[j];
                 if (aoff >= 0) {
                     const int word = aq[j >> 2];
                     const float a = (j & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8(word, 0) : (j & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8(word, 1)
