@@ -67,6 +67,42 @@ extern "C" int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float s
     return RN_OK;
 }
 
+// 3x3 / stride 2 / pad 1 max-pool of the fp32 stem output, written as e4m3 with one scale: what max-pool followed by rn_fp8_quantize
+// computes (bit for bit), without the fp32 pooled tensor in between (D/model.py:232: the boundary where the fp8 engine's fp32 stem ends).
+__global__ void maxpool_fwd_fp8out_kernel(const float4 *__restrict__ x, int *__restrict__ y, int H, int W, int C4, int Ho, int Wo,
+                                          float inv_scale, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*Ho*Wo*C4
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int64_t n = t / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int ih = oh * 2 - 1 + r;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            const int iw = ow * 2 - 1 + s_;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const float4 v = x[((n * H + ih) * W + iw) * C4 + c];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    y[i] = f8_pack4(m.x * inv_scale, m.y * inv_scale, m.z * inv_scale, m.w * inv_scale);
+}
+extern "C" int rn_maxpool_fwd_fp8out(const float *x, void *y, int N, int H, int W, int C, int Ho, int Wo, float inv_scale, void *stream) {
+    if (N <= 0 || (C & 3) || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1 || ((uintptr_t)x & 15) || ((uintptr_t)y & 3)) return RN_EINVAL;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_fp8out_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<int *>(y), H, W, C / 4, Ho, Wo, inv_scale, total);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 // Packed fp32 weight rows [rows][Kpad] (rn_pack_weights) -> fp8 rows [rows][Kpad64] (Kpad rounded up to 64: a K-step reads 64
 // bytes of a row) with one scale per row: row_scale[r] = max|row| / 448 (1 for an all-zero row), dst = fp8(src / row_scale[r]).
 // One workgroup per row.

@@ -143,6 +143,7 @@ SIGNATURES.update({
     "rn_conv_igemm_bf16": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm_bf16_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_i32, c_vp, c_vp, c_vp]),
     "rn_conv_igemm_bf16_tile_rows": (c_i32, [ctypes.POINTER(ConvGroup), c_i32]),
+    "rn_maxpool_fwd_fp8out": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_f32, c_vp]),
     "rn_conv_igemm_fp8_tile_rows": (c_i32, [ctypes.POINTER(ConvGroup), c_i32]),
     "rn_conv_igemm_fp8_tile": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "rn_conv_igemm_bf16_tile": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),

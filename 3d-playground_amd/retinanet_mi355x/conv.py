@@ -816,6 +816,20 @@ def fp8_quantize(t, scale):
     return out
 
 
+def maxpool_fwd_fp8(x, scale):
+    """fp32 stem output [N,H,W,C] -> e4m3 pooled activations (3x3 / 2 / pad 1 max-pool, then q = fp8(max / scale)): one pass instead of
+    maxpool_fwd + fp8_quantize, the same bytes."""
+    x = _hip.f32c(x)
+    _hip.need_gpu(x)
+    N, H, W, C = x.shape
+    Ho, Wo = out_size(H, 3, 2, 1), out_size(W, 3, 2, 1)
+    out = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    _hip.check(_hip.load().rn_maxpool_fwd_fp8out(x.data_ptr(), out.data_ptr(), N, H, W, C, Ho, Wo, 1.0 / float(scale), _hip.stream()),
+               "rn_maxpool_fwd_fp8out")
+    out._rn_scale = float(scale)
+    return out
+
+
 def fp8_dequantize(q, scale=None):
     scale = q._rn_scale if scale is None else scale
     out = torch.empty(q.shape, dtype=torch.float32, device=q.device)

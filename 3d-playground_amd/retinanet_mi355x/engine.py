@@ -859,15 +859,19 @@ class Engine:
         S = {} if save else None
         stem = Ls["conv1"].fwd(x4, act=cv.ACT_RELU)
         pool = cv.maxpool_fwd_bf16 if self.bf16 else cv.maxpool_fwd       # bf16 mode: the fp32 stem ends here
-        if save:
-            x, pool_arg = pool(stem, want_argmax=True)
-            S["x4"], S["stem"], S["pool_arg"] = x4, stem, pool_arg
+        if self.fp8 and not save and getattr(self, "calib", None) is None:
+            # fp8 mode: the fp32 stem ends here -- max-pool and quantisation in one pass (no fp32 pooled tensor)
+            x = cv.maxpool_fwd_fp8(stem, max(self.fp8_scales.get("pool", 0.0), 1e-30) / cv.FP8_MAX)
         else:
-            x = pool(stem)
-        if getattr(self, "calib", None) is not None:
-            self.calib["pool"] = max(self.calib.get("pool", 0.0), float(x.abs().max()))
-        if self.fp8:                                        # fp8 mode: the fp32 stem + pool end here
-            x = cv.fp8_quantize(x, max(self.fp8_scales.get("pool", 0.0), 1e-30) / cv.FP8_MAX)
+            if save:
+                x, pool_arg = pool(stem, want_argmax=True)
+                S["x4"], S["stem"], S["pool_arg"] = x4, stem, pool_arg
+            else:
+                x = pool(stem)
+            if getattr(self, "calib", None) is not None:
+                self.calib["pool"] = max(self.calib.get("pool", 0.0), float(x.abs().max()))
+            if self.fp8:                                    # (a saving or calibrating pass: pool, then quantise)
+                x = cv.fp8_quantize(x, max(self.fp8_scales.get("pool", 0.0), 1e-30) / cv.FP8_MAX)
         if save:
             S["blocks"] = []
         feats = {}

@@ -426,6 +426,9 @@ int rn_conv_igemm_bf16_tile_rows(const rn_conv_group *g, int y_is_f32);
  *                                   x_scale * row_scale[c] * bn_scale[c] into scale[c]; stored as e4m3(y * out_inv_scale)
  *                                   (Cout % 16 == 0) or as fp32 (y_is_f32: head outputs). */
 int rn_fp8_quantize(const float *src, void *dst, int64_t n, float inv_scale, void *stream);
+/* The 3x3 / stride 2 / pad 1 max-pool of an fp32 NHWC tensor written as e4m3 with one scale (y = fp8(max * inv_scale)): max-pool followed by
+ * rn_fp8_quantize, bit for bit, in one pass (the fp8 engine's stem boundary). */
+int rn_maxpool_fwd_fp8out(const float *x, void *y, int N, int H, int W, int C, int Ho, int Wo, float inv_scale, void *stream);
 int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float scale, void *stream);
 int rn_fp8_quantize_rows(const float *w_packed, void *w_q, float *row_scale, int64_t rows, int Kpad, void *stream);
 int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, void *y, int y_is_f32, const float *scale,

@@ -95,3 +95,15 @@ def test_random_operands_bias_relu_residual_and_fp8_output(dev, case):
         got_q = cv.fp8_dequantize(yq).permute(0, 3, 1, 2).cpu().double()
         err = (got_q - want_dq).abs()
         assert float((err - (2.0 ** -4) * want_dq.abs()).max()) <= 2.0 ** -9 * 448 * sy + 1e-4 * float(want_dq.abs().max())   # half an ulp + the subnormal step
+
+
+def test_maxpool_straight_to_fp8(dev):
+    """rn_maxpool_fwd_fp8out (the fp8 engine's stem boundary, D/model.py:232): max-pool then quantisation in one pass = the two-step path,
+    byte for byte; odd sizes (the clipped windows at the borders)."""
+    from retinanet_mi355x import conv as cv
+    x = F.relu(rnd((2, 64, 37, 45), 91)).permute(0, 2, 3, 1).contiguous().to(dev)
+    scale = float(x.max()) / cv.FP8_MAX
+    got = cv.maxpool_fwd_fp8(x, scale)
+    want = cv.fp8_quantize(cv.maxpool_fwd(x), scale)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert got._rn_scale == want._rn_scale
