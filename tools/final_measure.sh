@@ -31,6 +31,9 @@ if [ "$part" = 3 ]; then
   timeout -k 10 300 python3 tools/bench_conv.py --mfma split > "$O/conv_microbench_split.txt" 2>&1
   timeout -k 10 300 python3 tools/profile_layers.py --dtype fp32 > "$O/fp32_step_by_shape.txt" 2>&1
   timeout -k 10 300 python3 tools/profile_layers.py > "$O/bf16_step_by_shape.txt" 2>&1
+  timeout -k 10 300 python3 tools/profile_fp8_layers.py > "$O/fp8_forward_by_shape.txt" 2>&1
+  timeout -k 10 300 python3 tools/bench_conv_bf16.py --no-fp32 > "$O/conv_microbench_bf16.txt" 2>&1
+  timeout -k 10 300 python3 tools/bench_conv_fp8.py > "$O/conv_microbench_fp8.txt" 2>&1
   timeout -k 10 300 python3 tools/bench_infer.py > "$O/infer_cfg4.txt" 2>&1
   timeout -k 10 300 python3 tools/bench_infer.py --sharded >> "$O/infer_cfg4.txt" 2>&1
   RN_REHEARSE_ONE_GPU=1 timeout -k 10 400 python3 tools/bench_infer.py --gpus 2 --iters 3 >> "$O/infer_cfg4.txt" 2>&1
