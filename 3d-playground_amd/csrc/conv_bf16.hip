@@ -604,7 +604,11 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     const int64_t tall_tiles = ((M + 255) / 256) * ((d->Cout + 127) / 128);
     const bool tall_ok = !big && !y_is_f32 && bf16_desc_is_dense(d) && (d->Cout & 127) == 0;
     const bool tall = tall_ok && (tall_env == 1 || (tall_env != 0 && d->kh * d->kw * d->Cin >= 1024 && tall_tiles >= 512));
-    const int TR = big ? 256 : 128, TRM = (big || tall) ? 256 : 128;
+    // 256 x 64 tile (4 x 1 waves of 64 x 64) for dense bf16 results with at most 64 output channels: the 128 x 128 tile computes half of
+    // its columns for nothing there (3x3 64 -> 64, 1x1 256 -> 64 and their data gradients).  RN_BF16_NARROW_TILE=0 turns it off (A/B).
+    static const int narrow_env = [] { const char *e = getenv("RN_BF16_NARROW_TILE"); return e ? atoi(e) : 1; }();
+    const bool narrow = narrow_env != 0 && !big && !tall && !y_is_f32 && d->Cout <= 64 && bf16_desc_is_dense(d);
+    const int TR = big ? 256 : (narrow ? 64 : 128), TRM = (big || tall || narrow) ? 256 : 128;
     const int64_t tiles = ((M + TRM - 1) / TRM) * ((d->Cout + TR - 1) / TR);
     if (tiles > 0x7fffffff) return RN_EINVAL;
     const dim3 grid((unsigned)tiles), block(big ? 1024 : 256);
@@ -612,6 +616,7 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     const __bf16 *ab = reinterpret_cast<const __bf16 *>(add), *mb = reinterpret_cast<const __bf16 *>(mask);
     if (big) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 4, 4, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (tall) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true, 4>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    else if (narrow) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 4, 1, true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_kernel<true, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (bf16_desc_is_dense(d)) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);

@@ -62,6 +62,9 @@ CASES = [  # cin, cout, k, stride, pad, N, H, W
     (256, 108, 3, 1, 1, 1, 9, 15),       # head output: Cout % 4 == 0 only (fp32 result)
     (40, 72, 3, 1, 1, 1, 7, 9),          # Cin % 8 == 0 but not a multiple of the K-step: general staging path
     (512, 128, 3, 1, 1, 3, 5, 7),        # long K, several images inside one tile
+    (64, 64, 3, 1, 1, 2, 19, 23),        # at most 64 output channels: the 256 x 64 tile (round 4), a ragged last row tile
+    (256, 64, 1, 1, 0, 3, 9, 13),        # the same, 1x1, images inside the tile
+    (64, 40, 3, 1, 1, 1, 17, 16),        # the same with a ragged channel tile (Cout = 40)
 ]
 
 
