@@ -885,24 +885,13 @@ static int64_t wgrad_bf16_fill(WgradBf16Args &a, const void *dy, int ldy, const 
     return blocks;
 }
 
-// The eight-wave 256 x 256 tile over 64-pixel K-tiles (conv_wgrad_bf16_p8.hip) for stride-1 same-size layers with Cin, Cout % 256 == 0.
-bool rn_wgrad_bf16_p8_legal(int ldy, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad);
-int rn_wgrad_bf16_p8_launch(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int H, int W, int Cin, int Cout,
-                            int k, int pad, hipStream_t stream);
-
 extern "C" int rn_conv_wgrad_bf16(const void *dy, int ldy, const void *x, float *dw, float *colsum, int N, int Hi, int Wi,
                                   int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, void *stream) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 8 || (Cin & 7) || (ldy & 7) || ldy < Cout)
         return RN_EINVAL;
     if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return RN_EINVAL;
-    // The 256 x 256 form (conv_wgrad_bf16_p8.hip) is correct and SLOWER than this kernel on every layer but one (head tower 3x3:
-    // 0.51 ms against 0.40; profiles/r04_wgrad_p8_knockouts.txt has the breakdown): it runs only where RN_OPT_BF16_P8 = 2 forces it
-    // (its parity tests) or RN_WGRAD_P8=1 asks for it.
-    {
-        static const int wp8_env = [] { const char *e = getenv("RN_WGRAD_P8"); return e ? atoi(e) : 0; }();
-        if ((rn_get_option(RN_OPT_BF16_P8) == 2 || wp8_env == 1) && rn_wgrad_bf16_p8_legal(ldy, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad))
-            return rn_wgrad_bf16_p8_launch(dy, ldy, x, dw, colsum, N, Hi, Wi, Cin, Cout, kh, pad, (hipStream_t)stream);
-    }
+    // (A 256 x 256 eight-wave form of this reduction was built in round 4, correct and slower -- 0.51 against 0.40 ms on the head tower
+    // layer, profiles/r04_wgrad_p8_knockouts.txt -- and now lives in tools/probes/quarantine_r05/.)
     static const int target_wgs = [] { const char *e = getenv("RN_WGRAD_BF16_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
     // K slices for ~768 workgroups = ONE resident round at three per CU.  Every slice ends in tile-sized fp32 atomics
     // (Cout x Kflat x slices of them per launch, ~1.3 TB/s chip-wide), and with the MFMAs eight times shorter than in the

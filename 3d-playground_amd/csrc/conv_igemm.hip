@@ -93,8 +93,9 @@ extern "C" int rn_conv_igemm_grouped(const rn_conv_group *g, const float *w_pack
     for (int i = 0; i < g->n; ++i)
         if (g->d[i].w_format != d0.w_format) return RN_EINVAL;
     if (d0.w_format == 2) return RN_EINVAL;                                          // one-term products: single launches only
-    if (d0.w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;   // the pre-split form is an operand of the split kernels only
-    if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d0.w_format == 1 || d0.kh * d0.kw * d0.Cin >= rn_fp32_split_min_k()))
+    const bool split_mode = rn_get_fp32_mfma() != RN_FP32_NATIVE;                    // RN_FP32_SPLIT or RN_FP32_SPLIT3
+    if (d0.w_format != 0 && !split_mode) return RN_EINVAL;                           // the pre-split forms are operands of the split kernels only
+    if (split_mode && (d0.w_format != 0 || d0.kh * d0.kw * d0.Cin >= rn_fp32_split_min_k()))
         return rn_igemm_split_grouped_launch(narrow, (unsigned)prev, g, w_packed, scale, shift, s);
     if (narrow) hipLaunchKernelGGL((conv_igemm_grouped_kernel<4, 1, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
     else hipLaunchKernelGGL((conv_igemm_grouped_kernel<2, 2, 16>), grid, block, 0, s, *g, w_packed, scale, shift);
@@ -124,15 +125,16 @@ extern "C" int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float 
     // K-step 16 (34-41 KB of LDS, four workgroups per CU) everywhere: with the operands arriving by direct-to-LDS loads it
     // ties or beats K-step 32 at two workgroups per CU on every layer shape (measured).
     const bool raw = dense && !narrow && !d->in_relu && !scale && !shift && d->add_mode == 0 && d->mask_mode == 0 && d->act == 0 &&
-                     d->sign_out == nullptr;
+                     d->sign_out == nullptr && d->y_amax == nullptr;
     if (d->w_format == 2) {
         // pre-split weights, products from the first bf16 terms only: whatever the fp32 product mode (it is not fp32 arithmetic),
         // narrow instances only, no input ReLU (rn_igemm_split_launch)
         if (!narrow || d->in_relu) return RN_EINVAL;
         return rn_igemm_split_launch(dense ? 2 : 3, (unsigned)tiles, d, x, w_packed, y, scale, shift, add, mask, add2, s);
     }
-    if (d->w_format == 1 && rn_get_fp32_mfma() != RN_FP32_SPLIT) return RN_EINVAL;
-    if (rn_get_fp32_mfma() == RN_FP32_SPLIT && (d->w_format == 1 || d->kh * d->kw * d->Cin >= rn_fp32_split_min_k()))
+    const bool split_mode = rn_get_fp32_mfma() != RN_FP32_NATIVE;                    // RN_FP32_SPLIT or RN_FP32_SPLIT3
+    if (d->w_format != 0 && !split_mode) return RN_EINVAL;
+    if (split_mode && (d->w_format != 0 || d->kh * d->kw * d->Cin >= rn_fp32_split_min_k()))
         return rn_igemm_split_launch(raw ? 0 : (d->in_relu ? 1 : (narrow ? (dense ? 2 : 3) : (dense ? 4 : 5))), (unsigned)tiles, d, x,
                                      w_packed, y, scale, shift, add, mask, add2, s);
     if (raw) {                                                           // a plain GEMM: the Winograd stage

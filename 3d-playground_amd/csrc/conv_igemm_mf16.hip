@@ -30,7 +30,15 @@
 //   * the epilogue is wave-private: a wave transposes its accumulators through a 16-row strip of LDS of its own and stores whole
 //     512-byte rows; no workgroup barrier after the K loop.
 // 132 registers.  Conditions (the launcher's): pre-split weights, Cin a multiple of 32, div_shift 0, kh * kw <= 24, Cout a multiple
-// of 4 and > 64 (a 128 x 64 instance for narrower layers measured neutral: opt-in), no input ReLU.
+// of 4 and > 64 (a 128 x 64 instance for narrower layers measured neutral in round 3 and was removed in round 5), no input ReLU.
+//
+// TERMS = 2 (round 5, RN_FP32_SPLIT3; mfma_split.h, second half): the same kernel on v_mfma_f32_16x16x32_f16 with TWO fp16 terms per
+// operand and THREE MFMAs per product.  The weight image has two planes (rn_split_weights_f16: 64-byte records, the row's own
+// power-of-two scale), the activation values are multiplied by the tensor's power-of-two scale (from its amax word, one scalar load per
+// workgroup) inside the split, and the epilogue multiplies every column by the two inverse scales (folded into the batch-norm scale it
+// multiplies by anyway; one extra multiplication per element in the plain-GEMM form).  32 KB of weight planes instead of 48.
+#include <type_traits>
+
 #include "conv_igemm_tile.h"
 #include "conv_wgrad_geom.h"
 
@@ -47,18 +55,21 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
     } while (0)
 
-template <bool GENERAL, bool RAW, int BN>
+template <bool GENERAL, bool RAW, int TERMS>
 __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
                                                float *__restrict__ y, const float *__restrict__ scale,
                                                const float *__restrict__ shift, const float *__restrict__ add,
                                                const float *__restrict__ mask, const float *__restrict__ add2, const int tile) {
-    constexpr int BK = 32, BM = 128, NSN = BN / 16;        // BN = 128, or 64 for layers with at most 64 output channels
-    constexpr int BPL = BN * 16;                           // floats' worth of one bf16 plane: rows x 64 bytes
-    constexpr int BSTEP = 3 * BPL;                         // one buffer: B planes h, m, l
-    constexpr int NBI = 3 * BN / 16, IB = NBI / 4;         // direct-to-LDS instructions (16 rows x 64 bytes each) per step / per wave
+    constexpr int BK = 32, BM = 128, BN = 128, NSN = BN / 16;
+    constexpr bool HALF = TERMS == 2;                      // two fp16 terms / three MFMAs instead of three bf16 terms / six
+    constexpr int REC = 32 * TERMS, EB = 2 * TERMS;        // bytes of a pre-split record (16 values) / per weight element
+    constexpr int BPL = BN * 16;                           // floats' worth of one 16-bit plane: rows x 64 bytes
+    constexpr int BSTEP = TERMS * BPL;                     // one buffer: B planes h, m, l (TERMS 3) or hi, lo (TERMS 2)
+    constexpr int NBI = TERMS * BN / 16, IB = NBI / 4;     // direct-to-LDS instructions (16 rows x 64 bytes each) per step / per wave
     constexpr int LDT = BN + 4;
-    static_assert(NBI % 4 == 0 && (BN == 64 || BN == 128), "tile shape");
-    __shared__ float lds[2 * BSTEP];
+    constexpr int LDSF = 2 * BSTEP > 4 * 16 * LDT ? 2 * BSTEP : 4 * 16 * LDT;   // two staging buffers; the epilogue's four strips
+    static_assert(NBI % 4 == 0 && (TERMS == 2 || TERMS == 3), "tile shape");
+    __shared__ float lds[LDSF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;              // a lane's row / column within a 16 x 16 tile, its block of 8 k values
@@ -77,8 +88,15 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(x + (int64_t)n_first * d.x_batch_stride), (short)0,
         (int)(unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4), 0x00020000);
-    const v4i32 rs_b = make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * 6,
-                                 (unsigned)((int64_t)d.Cout * Kpad * 6));
+    const v4i32 rs_b = make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * EB,
+                                 (unsigned)((int64_t)d.Cout * Kpad * EB));
+    // TERMS 2: the activation tensor's power-of-two scale from its amax word (scalar), and the inverse for the epilogue
+    float a_scale = 1.f, a_unscale = 1.f;
+    if constexpr (HALF) {
+        const int se = rn_f16_scale_exp(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned *>(d.x_amax)));
+        a_scale = rn_exp_to_float(se);
+        a_unscale = rn_exp_to_float(254 - se);
+    }
 
     // ---- this lane's two activation rows (tile rows 32 * wave + 16 * sm + lr): tap mask and base offset of its 8 k values
     unsigned a_mask[2];
@@ -136,13 +154,13 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         const int q = wave * IB + j, plane = q / (BN / 16), brow = (q % (BN / 16)) * 16 + (lane >> 2);
         const int c = Mf16Geom::dma_chunk(lane);
         const int n = n0 + brow;
-        b_voff[j] = n < d.Cout ? (unsigned)(n * Kpad * 6 + (c >> 1) * 96 + plane * 32 + (c & 1) * 16) : 0x80000000u;
+        b_voff[j] = n < d.Cout ? (unsigned)(n * Kpad * EB + (c >> 1) * REC + plane * 32 + (c & 1) * 16) : 0x80000000u;
     }
     const unsigned lds0 = lds_addr(lds);
     auto dma_b = [&](int ks, int buf) {
 #pragma unroll
         for (int j = 0; j < IB; ++j)
-            dma16(rs_b, lds0 + (unsigned)(buf * BSTEP * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 192));
+            dma16(rs_b, lds0 + (unsigned)(buf * BSTEP * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 2 * REC));
     };
 
     f32x4a acc[2][NSN];
@@ -163,24 +181,33 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     __syncthreads();
     auto k_step = [&](int ks, int rb) {
         asm volatile("" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]));   // the compiler's wait for `cur` here, where it is free
-        Split8 sa[2];
+        typename std::conditional<HALF, SplitH8, Split8>::type sa[2];
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm) {
             const float av[8] = {cur.v[2 * sm][0], cur.v[2 * sm][1], cur.v[2 * sm][2], cur.v[2 * sm][3],
                                  cur.v[2 * sm + 1][0], cur.v[2 * sm + 1][1], cur.v[2 * sm + 1][2], cur.v[2 * sm + 1][3]};
-            sa[sm] = split8(av);
+            if constexpr (HALF) sa[sm] = split8h(av, a_scale);
+            else sa[sm] = split8(av);
         }
         dma_b(ks + 1, rb ^ 1);
         load_a(cur);
         const float *S = lds + rb * BSTEP + fb0;
 #pragma unroll
         for (int sn = 0; sn < NSN; ++sn) {
-            Split8 sb;
-            sb.h = *reinterpret_cast<const bf16x8 *>(S + 256 * sn);
-            sb.m = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + BPL);
-            sb.l = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + 2 * BPL);
+            if constexpr (HALF) {
+                SplitH8 sb;
+                sb.h = *reinterpret_cast<const f16x8 *>(S + 256 * sn);
+                sb.l = *reinterpret_cast<const f16x8 *>(S + 256 * sn + BPL);
 #pragma unroll
-            for (int sm = 0; sm < 2; ++sm) RN_SPLIT_MFMA16(acc[sm][sn], sa[sm], sb);
+                for (int sm = 0; sm < 2; ++sm) RN_SPLITH_MFMA16(acc[sm][sn], sa[sm], sb);
+            } else {
+                Split8 sb;
+                sb.h = *reinterpret_cast<const bf16x8 *>(S + 256 * sn);
+                sb.m = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + BPL);
+                sb.l = *reinterpret_cast<const bf16x8 *>(S + 256 * sn + 2 * BPL);
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm) RN_SPLIT_MFMA16(acc[sm][sn], sa[sm], sb);
+            }
         }
         RN_PIN();
         rn_wait_dma();                                      // B planes of step ks + 1 landed, A registers of step ks + 1 arrived
@@ -197,7 +224,6 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // 16 x 16 tile; out of the strip a lane takes float4s: BN / 4 consecutive lanes one whole row segment, so out, add and mask all
     // move as 16-byte accesses (conv_igemm_tile.h: same arithmetic, same macros).
     float *T = lds + wave * (16 * LDT);
-    static_assert(4 * 16 * LDT <= 2 * BSTEP, "four strips fit the staging buffers");
     constexpr int CPR = BN / 4, RPI = 64 / CPR;              // 16-byte chunks per row, rows one wave instruction covers
     const int c4 = lane % CPR;
     const int col = n0 + 4 * c4;
@@ -209,7 +235,10 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     for (int j = 0; j < 4; ++j) {
         if (!RAW && col_ok && scale != nullptr) sc[j] = scale[col + j];
         if (!RAW && col_ok && shift != nullptr) sh[j] = shift[col + j];
+        // TERMS 2: the accumulators hold the product of the SCALED operands: both inverse scales (powers of two) ride in the column's factor
+        if (HALF && col_ok) sc[j] *= d.w_unscale[(d.w_batch_stride != 0 ? (int64_t)n_first * d.Cout : 0) + col + j] * a_unscale;
     }
+    float rn_am = 0.f;                                       // largest |y| this lane stored (rn_conv_desc.y_amax)
 #pragma unroll
     for (int sm = 0; sm < 2; ++sm) {
 #pragma unroll
@@ -250,7 +279,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                             { RN_EPI_ADDR(GENERAL) a2 = a2off; (void)aoff; (void)off; }
                             if (a2 >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
                         }
-                        if (RAW) *reinterpret_cast<float4 *>(y + off) = t;
+                        if (RAW) *reinterpret_cast<float4 *>(y + off) = HALF ? make_float4(t.x * sc[0], t.y * sc[1], t.z * sc[2], t.w * sc[3]) : t;
                         else { RN_EPI_FINISH() }
                     }
                 }
@@ -259,17 +288,19 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip's reads before the next half's writes
         __builtin_amdgcn_wave_barrier();
     }
+    if (!RAW) rn_amax_commit(d.y_amax, rn_am);
 }
 
-template <bool GENERAL, bool RAW, int BN>
+template <bool GENERAL, bool RAW, int TERMS>
 __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const float *__restrict__ add, const float *__restrict__ mask,
                                                               const float *__restrict__ add2) {
-    conv_mf16_tile<GENERAL, RAW, BN>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_mf16_tile<GENERAL, RAW, TERMS>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
                                                                       const float *__restrict__ scale,
                                                                       const float *__restrict__ shift) {
@@ -284,37 +315,50 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const r
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_mf16_tile<true, false, 128>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_mf16_tile<true, false, TERMS>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // Which problems take this kernel: RN_OPT_MF16 = 0 turns it off (A/B); launches with fewer than RN_OPT_MF16_MIN tiles keep the
 // 32x32x16 kernels.  (rn_get_option: the environment is read once, not per launch; the parity tests switch with rn_set_option.)
 static int mf16_on() { return rn_get_option(RN_OPT_MF16); }
 static int mf16_min_tiles() { return rn_get_option(RN_OPT_MF16_MIN); }
+static bool mf16_geom_ok(const rn_conv_desc *d) {
+    return (d->Cin % 32) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 && (d->Cout % 4) == 0 && d->Cout > 64 && !d->in_relu;
+}
 static bool mf16_ok(const rn_conv_desc *d) {
-    return mf16_on() && d->w_format == 1 && (d->Cin % 32) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24 &&
-           (d->Cout % 4) == 0 && !d->in_relu;
+    if (!mf16_on() || !mf16_geom_ok(d)) return false;
+    if (d->w_format == 3) return d->x_amax != nullptr && d->w_unscale != nullptr;
+    return d->w_format == 1;
 }
 static int64_t mf16_tiles(const rn_conv_desc *d) {
     const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-    return ((M + 127) / 128) * (d->Cout <= 64 ? 1 : (d->Cout + 127) / 128);
+    return ((M + 127) / 128) * ((d->Cout + 127) / 128);
 }
 
-// -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 2 / 3 narrow (Cout <= 64) dense / general, 4 / 5 wide dense / general.
+// include/retinanet_mi355x.h: does this problem run on an fp16-split kernel in RN_FP32_SPLIT3 mode?  (Geometry only; the tile-count
+// threshold RN_OPT_MF16_MIN is an A/B knob whose default, 1, excludes nothing.)
+extern "C" int rn_conv_igemm_wants_f16(const rn_conv_desc *d) {
+    return rn_get_fp32_mfma() == RN_FP32_SPLIT3 && mf16_on() && mf16_geom_ok(d) && d->w_batch_stride >= 0 && mf16_tiles(d) >= mf16_min_tiles();
+}
+
+// -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 4 / 5 wide dense / general.
 bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
                           const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc) {
-    if (!mf16_ok(d) || variant == 1 || variant < 0 || variant > 5) return false;
-    if ((variant == 2 || variant == 3) != (d->Cout <= 64)) return false;
-    // the 128 x 64 instance measured neutral (3x3 64->64 +3 %, 1x1 256->64 -3 %, conv_igemm_4x1 5.68 -> 5.76 ms per step): opt-in
-    if (d->Cout <= 64 && !rn_get_option(RN_OPT_MF16_NARROW)) return false;
+    if (!mf16_ok(d) || (variant != 0 && variant != 4 && variant != 5)) return false;
     const int64_t tiles = mf16_tiles(d);
     if (tiles < mf16_min_tiles() || tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles), block(256);
-    if (variant == 0) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, true, 128>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else if (variant == 4) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, false, 128>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else if (variant == 5) hipLaunchKernelGGL((conv_igemm_mf16_kernel<true, false, 128>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else if (variant == 2) hipLaunchKernelGGL((conv_igemm_mf16_kernel<false, false, 64>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
-    else hipLaunchKernelGGL((conv_igemm_mf16_kernel<true, false, 64>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2);
+#define RN_MF16_LAUNCH(G, R, T) hipLaunchKernelGGL((conv_igemm_mf16_kernel<G, R, T>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
+    if (d->w_format == 3) {
+        if (variant == 0) RN_MF16_LAUNCH(false, true, 2);
+        else if (variant == 4) RN_MF16_LAUNCH(false, false, 2);
+        else RN_MF16_LAUNCH(true, false, 2);
+    } else {
+        if (variant == 0) RN_MF16_LAUNCH(false, true, 3);
+        else if (variant == 4) RN_MF16_LAUNCH(false, false, 3);
+        else RN_MF16_LAUNCH(true, false, 3);
+    }
+#undef RN_MF16_LAUNCH
     const hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? RN_OK : (int)e;
     return true;
@@ -322,7 +366,7 @@ bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, co
 
 bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc) {
     for (int i = 0; i < g->n; ++i)
-        if (!mf16_ok(&g->d[i]) || g->d[i].Cout <= 64) return false;
+        if (!mf16_ok(&g->d[i]) || g->d[i].w_format != g->d[0].w_format) return false;
     rn_conv_group gb = *g;                                  // the caller's tile table counts 128 x 128 tiles: recount
     int64_t total = 0;
     for (int i = 0; i < g->n; ++i) {
@@ -331,9 +375,9 @@ bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const 
     }
     for (int i = g->n; i < RN_MAX_GROUP; ++i) gb.tile_end[i] = (int)total;
     if (total < mf16_min_tiles() || total > 0x7fffffff) return false;
-    hipLaunchKernelGGL(conv_igemm_mf16_grouped_kernel, dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
+    if (g->d[0].w_format == 3) hipLaunchKernelGGL(conv_igemm_mf16_grouped_kernel<2>, dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
+    else hipLaunchKernelGGL(conv_igemm_mf16_grouped_kernel<3>, dim3((unsigned)total), dim3(256), 0, s, gb, w, scale, shift);
     const hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? RN_OK : (int)e;
     return true;
 }
-

@@ -50,16 +50,10 @@ static bool split_a_once(const rn_conv_desc *d) {
     return on && d->w_format == 1 && (d->Cin % 16) == 0 && d->div_shift == 0 && d->kh * d->kw <= 24;
 }
 
-// conv_igemm_big.hip: 256 x 256 tiles, one wave per SIMD (returns false when the problem does not qualify)
-bool rn_igemm_big_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
-                         const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc);
-bool rn_igemm_big_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc);
-// conv_igemm_mf16.hip: 128 x 256 tiles on v_mfma_f32_16x16x32_bf16
+// conv_igemm_mf16.hip: 128 x 128 tiles on v_mfma_f32_16x16x32_bf16 (RN_FP32_SPLIT) / v_mfma_f32_16x16x32_f16 (RN_FP32_SPLIT3)
 bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, const float *scale,
                           const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc);
 bool rn_igemm_mf16_grouped_launch(const rn_conv_group *g, const float *w, const float *scale, const float *shift, hipStream_t s, int *rc);
-// conv_igemm_mf16p.hip: the plain-GEMM form with a short reduction as a continuous K-step stream (persistent, stores spread over the next tile)
-bool rn_igemm_mf16_pipe_launch(int variant, const rn_conv_desc *d, const float *x, const float *w, float *y, hipStream_t s, int *rc);
 
 static int dbg_dyn_lds(const void *fn) {                  // occupancy experiment: RN_DBG_DYN_LDS bytes of unused dynamic LDS per workgroup
     static const int v = getenv("RN_DBG_DYN_LDS") ? atoi(getenv("RN_DBG_DYN_LDS")) : 0;
@@ -83,9 +77,8 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
     }
     {
         int rc = RN_OK;
-        if (rn_igemm_big_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
-        if (rn_igemm_mf16_pipe_launch(variant, d, x, w, y, s, &rc)) return rc;
         if (rn_igemm_mf16_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
+        if (d->w_format == 3) return RN_EINVAL;             // the fp16 pre-split form has no other consumer (rn_conv_igemm_wants_f16 says which problems take it)
     }
     const dim3 grid(tiles), block(256);
 #define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW)                                                                                              \
@@ -113,9 +106,9 @@ int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_gro
     const bool pre = g->d[0].w_format == 1;
     if (!narrow) {
         int rc = RN_OK;
-        if (rn_igemm_big_grouped_launch(g, w, scale, shift, s, &rc)) return rc;
         if (rn_igemm_mf16_grouped_launch(g, w, scale, shift, s, &rc)) return rc;
     }
+    if (g->d[0].w_format == 3) return RN_EINVAL;
     if (!narrow && split_a_once(&g->d[0])) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 3>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
@@ -135,6 +128,55 @@ extern "C" int rn_split_weights(const float *w_packed, void *w_split, int64_t ro
     if (rows <= 0 || Kpad <= 0 || (Kpad & 15)) return RN_EINVAL;
     const int64_t chunks = rows * Kpad / 8;
     hipLaunchKernelGGL(split_weights_kernel, dim3(rn_blocks(chunks, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, w_split, chunks);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// ---- RN_FP32_SPLIT3: the fp16 pre-split form (mfma_split.h, second half).  One wave per row: the row's largest magnitude (one pass, wave
+// maximum), its power-of-two scale, then the hi / lo terms of every 8-value chunk.
+__device__ __forceinline__ void split_row_f16(const float *__restrict__ src, void *__restrict__ dst, float *__restrict__ unscale,
+                                              int64_t row, int Kpad, int lane) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(src + row * Kpad);
+    float am = 0.f;
+    for (int i = lane; i < Kpad / 4; i += 64) {
+        const float4 q = r4[i];
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+    const int se = rn_f16_scale_exp(__builtin_bit_cast(unsigned, rn_wave_max(am)));
+    if (lane == 0) unscale[row] = rn_exp_to_float(254 - se);
+    const float sc = rn_exp_to_float(se);
+    const int64_t c0 = row * (Kpad / 8);
+    for (int i = lane; i < Kpad / 8; i += 64) split_store_chunk_h(src, dst, c0 + i, sc);
+}
+__global__ __launch_bounds__(256) void split_weights_f16_kernel(const float *__restrict__ src, void *__restrict__ dst,
+                                                                 float *__restrict__ unscale, int64_t rows, int Kpad) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < rows) split_row_f16(src, dst, unscale, row, Kpad, threadIdx.x & 63);
+}
+
+extern "C" int rn_split_weights_f16(const float *w_packed, void *w_split, float *row_unscale, int64_t rows, int Kpad, void *stream) {
+    if (rows <= 0 || Kpad <= 0 || (Kpad & 15) || !row_unscale) return RN_EINVAL;
+    hipLaunchKernelGGL(split_weights_f16_kernel, dim3(rn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, w_packed, w_split, row_unscale, rows, Kpad);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// The amax word of a tensor nobody left one for (rn_conv_desc.x_amax): one streaming pass, 8 floats per thread and iteration.
+__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ amax) {
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+    float am = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 q = reinterpret_cast<const float4 *>(x)[i];
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) am = fmaxf(am, fabsf(x[(n4 << 2) + threadIdx.x]));
+    rn_amax_commit(amax, am);
+}
+extern "C" int rn_amax(const float *x, int64_t n, void *amax, void *stream) {
+    if (n <= 0 || !amax || ((uintptr_t)x & 15)) return RN_EINVAL;
+    const int64_t want = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want))), dim3(256), 0, (hipStream_t)stream, x, n,
+                       reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

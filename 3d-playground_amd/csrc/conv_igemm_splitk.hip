@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
     const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
     const int cpr = (d.Cout + 3) / 4;                        // 4-channel chunks per output pixel
     const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (chunk >= M * cpr) return;
+    float rn_am = 0.f;                                       // largest |y| this lane stored (rn_conv_desc.y_amax)
+    if (chunk < M * cpr) {
     const int64_t m = chunk / cpr;
     const int col = (int)(chunk - m * cpr) * 4;
     const bool vec = (d.Cout & 3) == 0;
@@ -49,6 +50,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
     const float4 t = make_float4(a[0], a[1], a[2], a[3]);
     const int HoWo = d.Ho * d.Wo;
     RN_EPI_CHUNK_BODY(GENERAL);
+    }
+    rn_amax_commit(d.y_amax, rn_am);                         // every lane of the wave arrives here
 }
 
 // Slices worth using for this problem (1 = do not split) -- few output tiles and a long K loop.

@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // col, ncol, vec, t, sc, sh, y, add, mask, add2, HoWo from the scope they are expanded in.
 //   RN_EPI_ADDR   -> int64_t off (output / mask / same-geometry addend), aoff, a2off (-1 = none)
 //   RN_EPI_LOAD   -> float mk[4], ad[4] from mask / add / add2
-//   RN_EPI_FINISH -> arithmetic and the store
+//   RN_EPI_FINISH -> arithmetic and the store; the lane's running maximum of |stored value| in `float rn_am` of the scope
+//                    (rn_conv_desc.y_amax: committed once per wave by rn_amax_commit after the last chunk)
 #define RN_EPI_ADDR(GENERAL)                                                                                     \
         int64_t off, aoff = -1, a2off = -1; \
         if (!GENERAL) { \
@@ -69,10 +70,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (vec) { \
             *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]); \
             if (d.sign_out != nullptr) rn_sign_store(reinterpret_cast<unsigned *>(d.sign_out), off, v[0], v[1], v[2], v[3]); \
+            if (d.y_amax != nullptr) rn_am = fmaxf(fmaxf(rn_am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3]))); \
         } else { \
     _Pragma("unroll") \
             for (int j = 0; j < 4; ++j) \
-                if (j < ncol) y[off + j] = v[j]; \
+                if (j < ncol) { y[off + j] = v[j]; rn_am = fmaxf(rn_am, fabsf(v[j])); } \
         }
 
 #define RN_EPI_CHUNK_BODY(GENERAL) \
@@ -618,6 +620,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // memory sees 16-byte accesses, 32 consecutive lanes on one 512-byte row segment: out, add and mask all move as
     // float4.  Accumulator element e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile.
     float *T = lds;
+    float rn_am = 0.f;                                       // largest |y| this lane stored (rn_conv_desc.y_amax)
     constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 16-byte chunks per tile row, rows per pass of stores
     const int c4 = tid % CPR;
     const int col = n0 + 4 * c4;
@@ -701,6 +704,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             }
         }
     }
+    if (partial == nullptr) rn_amax_commit(d.y_amax, rn_am);
 }
 
 
@@ -724,7 +728,8 @@ static inline int check_desc(const rn_conv_desc *d) {
     if (d->os < 1 || d->oo_h < 0 || d->oo_w < 0 || (d->add2_mode != 0 && d->add2_mode != 3)) return RN_EINVAL;
     if ((d->Ho - 1) * d->os + d->oo_h >= d->Hy || (d->Wo - 1) * d->os + d->oo_w >= d->Wy) return RN_EINVAL;
     if (d->os != 1 && d->add_mode == 2) return RN_EINVAL;
-    if (d->w_format < 0 || d->w_format > 2) return RN_EINVAL;
+    if (d->w_format < 0 || d->w_format > 3) return RN_EINVAL;
+    if (d->w_format == 3 && (d->x_amax == nullptr || d->w_unscale == nullptr)) return RN_EINVAL;
     if (d->w_batch_stride < 0 || (d->w_batch_stride != 0 && ((int64_t)d->Ho * d->Wo) % 256 != 0)) return RN_EINVAL;
     return RN_OK;
 }

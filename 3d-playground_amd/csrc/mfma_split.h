@@ -113,3 +113,107 @@ typedef float rn_f32x4 __attribute__((ext_vector_type(4)));
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
     } while (0)
 #endif
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// RN_FP32_SPLIT3 (round 5): TWO fp16 terms and THREE MFMAs per product instead of three bf16 terms and six.
+//
+// With a power-of-two scale s chosen so that the tensor's largest magnitude lands in [2^14, 2^15) (fp16: 11 significand bits, largest
+// finite value 65504, smallest normal 2^-14), x*s = hi + lo with hi = f16(x*s), lo = f16(x*s - hi), both rounded to nearest: the
+// subtraction is exact in fp32, |x*s - hi| <= 2^-11 |x*s|, so hi + lo carries 22 significand bits plus the residual's sign
+// (|error| <= 2^-22 |x|, 2^-23.3 rms) for every element down to 2^-18 of the tensor's maximum; smaller elements keep an ABSOLUTE
+// error of 2^-25 in scaled units = 2^-40 of the maximum (lo is then an fp16 subnormal, which the matrix core does not flush:
+// tools/probes/f16_split_probe.hip).  A product is  ah*bh + ah*bl + al*bh  on v_mfma_f32_16x16x32_f16 / 32x32x16_f16 into the same
+// fp32 accumulator (each term product exact, the sum of the instruction's 32 or 16 products rounded once); the dropped al*bl is at
+// most 2^-22 of the product.  The result is the product of the SCALED operands: the epilogue multiplies by the two inverse scales
+// (powers of two: exact).  Scales: per output channel for weights (rn_split_weights_f16 writes the inverse beside the terms), per
+// tensor for activations and gradients from the amax word their producer's epilogue leaves (rn_conv_desc.x_amax / y_amax;
+// rn_amax for tensors without one).  Against the three-term bf16 form: half the MFMAs, a two-plane instead of a three-plane weight
+// image, 3 instead of 4.5 vector instructions per split value; error against fp64 measured per kernel in tools/fp32_mode_errors.py.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct SplitH8 { f16x8 h, l; };
+
+// The scale of a tensor whose largest magnitude has the fp32 bit pattern `amax_bits` (sign cleared): 2^(14 - floor(log2 amax)), so that
+// amax * scale is in [2^14, 2^15); 1 for an all-zero tensor.  Returned as the biased exponent field: scale = bits(se << 23), its inverse
+// bits((254 - se) << 23); both stay normal numbers for every amax (tensors below 2^-112 are scaled by 2^126 and simply use less of fp16's
+// range).  A NaN / infinite amax gives a finite scale: the non-finite elements themselves make the result NaN.
+__host__ __device__ __forceinline__ int rn_f16_scale_exp(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    if (e == 0) return 127;
+    const int se = 268 - e;                                  // 127 + 14 - (e - 127)
+    return se > 253 ? 253 : se;
+}
+__device__ __forceinline__ float rn_exp_to_float(int biased) { return __builtin_bit_cast(float, (unsigned)biased << 23); }
+
+// Two values at a time: t = x*s; hi = cvt_pk_f16(t0, t1); lo = cvt_pk_f16(fma(x0, s, -hi0), fma(x1, s, -hi1)) -- the fma re-forms x*s
+// exactly (a power-of-two scale) and subtracts hi in one rounding-free step.
+__device__ __forceinline__ void split_pair_h(float x0, float x1, float s, unsigned &h, unsigned &l) {
+    const f16x2 hp = {(_Float16)(x0 * s), (_Float16)(x1 * s)};
+    h = __builtin_bit_cast(unsigned, hp);
+    asm("" : "+v"(h));                                       // pin the PACKED conversion (see split_pair)
+    const f16x2 hq = __builtin_bit_cast(f16x2, h);
+    const float r0 = __builtin_fmaf(x0, s, -(float)hq[0]);
+    const float r1 = __builtin_fmaf(x1, s, -(float)hq[1]);
+    const f16x2 lp = {(_Float16)r0, (_Float16)r1};
+    l = __builtin_bit_cast(unsigned, lp);
+}
+
+__device__ __forceinline__ SplitH8 split8h(const float (&x)[8], float s) {
+    u32x4 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b;
+        split_pair_h(x[2 * j], x[2 * j + 1], s, a, b);
+        hh[j] = a; ll[j] = b;
+    }
+    SplitH8 r;
+    r.h = __builtin_bit_cast(f16x8, hh);
+    r.l = __builtin_bit_cast(f16x8, ll);
+    return r;
+}
+
+// Pre-split fp16 form of a packed fp32 tensor [rows][Kpad] (Kpad a multiple of 16): [rows][Kpad/16] records of 64 bytes, a record =
+// the hi and lo terms (2 x 16 fp16) of the row's 16 values of that K-step, scaled by the ROW's scale.
+__device__ __forceinline__ void split_store_chunk_h(const float *__restrict__ src, void *__restrict__ dst, int64_t i, float s) {
+    const float4 p0 = reinterpret_cast<const float4 *>(src)[2 * i], p1 = reinterpret_cast<const float4 *>(src)[2 * i + 1];
+    const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const SplitH8 sp = split8h(v, s);
+    char *rec = reinterpret_cast<char *>(dst) + (i >> 1) * 64 + (i & 1) * 16;
+    *reinterpret_cast<f16x8 *>(rec) = sp.h;
+    *reinterpret_cast<f16x8 *>(rec + 32) = sp.l;
+}
+
+// acc += a * b for one 32x32 tile and 16 values of k: the three products, smallest first.
+#define RN_SPLITH_MFMA(ACC, A, B)                                                         \
+    do {                                                                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16((A).l, (B).h, ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16((A).h, (B).l, ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16((A).h, (B).h, ACC, 0, 0, 0);         \
+    } while (0)
+// the same for one 16x16 tile and 32 values of k
+#define RN_SPLITH_MFMA16(ACC, A, B)                                                       \
+    do {                                                                                  \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16((A).l, (B).h, ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16((A).h, (B).l, ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16((A).h, (B).h, ACC, 0, 0, 0);         \
+    } while (0)
+
+// amax word of a tensor: the largest |element| as fp32 bits (monotone as unsigned), accumulated by atomic max at device scope.
+// Producers keep a running maximum per lane, reduce it over the wave and commit it once; a wave whose maximum does not raise the
+// word's EXPONENT (all a consumer uses) skips the atomic -- after the first few waves of a launch almost all do.
+__device__ __forceinline__ float rn_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ void rn_amax_commit(void *slot, float lane_max) {
+    if (slot == nullptr) return;
+    unsigned *p = reinterpret_cast<unsigned *>(slot);
+    const unsigned seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // NaN-propagating maximum of the bit patterns: an integer max over |x| bits orders NaN above infinity
+    unsigned b = __builtin_bit_cast(unsigned, lane_max) & 0x7fffffffu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)b, off, 64); b = o > b ? o : b; }
+    if ((threadIdx.x & 63) == 0 && (b >> 23) > (seen >> 23)) atomicMax(p, b);
+}

@@ -25,6 +25,8 @@ SIGNATURES = {
     "rn_set_option": (c_i32, [c_i32, c_i32]),
     "rn_fp32_split_min_k": (c_i32, []),
     "rn_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "rn_split_weights_f16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "rn_amax": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     "rn_anchor_count": (c_i64, [c_i32, c_i32]),
     "rn_anchor_base_boxes": (None, [c_vp]),
     "rn_anchors_fwd": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
@@ -72,7 +74,8 @@ class ConvDesc(ctypes.Structure):
                 ("os", c_i32), ("oo_h", c_i32), ("oo_w", c_i32), ("Hy", c_i32), ("Wy", c_i32),
                 ("add2_mode", c_i32), ("Ha2", c_i32), ("Wa2", c_i32), ("add2_batch_stride", c_i64),
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64),
-                ("w_batch_stride", c_i64), ("w_format", c_i32), ("sign_out", c_vp)]
+                ("w_batch_stride", c_i64), ("w_format", c_i32), ("sign_out", c_vp),
+                ("x_amax", c_vp), ("y_amax", c_vp), ("w_unscale", c_vp)]
 
 
 RN_MAX_GROUP = 5
@@ -116,6 +119,7 @@ SIGNATURES.update({
     "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_splitk_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "rn_conv_igemm_wants_f16": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "rn_conv_igemm_splitk": (c_i32, [ctypes.POINTER(ConvDesc)] + [c_vp] * 10),
     "rn_conv_wgrad": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp] + [c_i32] * 12 + [c_vp]),
     "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp] + [c_i32] * 4 + [c_vp]),

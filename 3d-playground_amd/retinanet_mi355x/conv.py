@@ -41,7 +41,7 @@ def pack_weights(weight, mode=0, scale=None, kw_pad=None, c_pad=None, taps=None,
     out = torch.empty((rows, (ktaps * c_pad + 31) // 32 * 32), dtype=torch.float32, device=w.device)
     _hip.check(lib.rn_pack_weights(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kw_pad, c_pad, mode,
                                    _hip.ptr(scale), r0, nr, s0, ns, _hip.stream()), "rn_pack_weights")
-    return _maybe_split(out) if presplit else out        # split mode: with the pre-split twin attached
+    return _maybe_split(out, rows=rows, cin=c_pad, taps=ktaps) if presplit else out        # split modes: with the pre-split twin attached
 
 
 # Sign bits of ReLU outputs (round 4; csrc/common.h: rn_sign_store).  A producer called with sign=True also writes one bit per
@@ -75,11 +75,13 @@ def _mask_operand(mask, mask_mode):
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
                mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0,
-               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False, bf16_products=False):
+               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False, bf16_products=False, x_amax=None, amax=None):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift) with p an int or (p_rows, p_cols).
     out_map = (os, oo_h, oo_w, Hy, Wy) stores output pixel (oh,ow) at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
-    tensor.  add2: [N,Ha2,Wa2,Cout] added at even stored positions (1x1 stride-2 shortcut gradient)."""
+    tensor.  add2: [N,Ha2,Wa2,Cout] added at even stored positions (1x1 stride-2 shortcut gradient).
+    split3 mode: x_amax = the amax word of x when the caller knows it (default: amax_word(x)); a dense result gets an amax word of its own
+    (y._rn_amax), `amax` = a word several launches that fill ONE tensor share (the parity classes of a stride-2 data gradient)."""
     lib = _hip.load()
     N, Hi, Wi, Cin = x.shape
     Ho, Wo, Cout, kh, kw, a, b, p, ds = geom
@@ -95,6 +97,10 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
                  a2[0], a2[1], a2[2], a2[3], Hi * Wi * Cin, ybs, add_batch_stride, w_batch_stride)
     bits = _sign_words(y, sign and y_batch_stride is None and out_map is None)
     d.sign_out = None if bits is None else bits.data_ptr()
+    yam = None
+    if want_amax() and not w_batch_stride and y_batch_stride is None and (out_map is None or amax is not None):
+        yam = amax if amax is not None else amax_slot(y.device)
+        d.y_amax = yam.data_ptr()
     if kind is None:
         kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
     if prof.BY_SHAPE:                                    # profiling aid (tools/profile_layers.py): one row per layer shape
@@ -106,8 +112,12 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
             ctypes.byref(d), x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
             _hip.ptr(add), mask_ptr, _hip.ptr(add2), ws.data_ptr(), _hip.stream()))
         _hip.check(rc, "rn_conv_igemm_splitk")
+        if yam is not None and amax is None:
+            amax_attach(y, yam)
         return y
-    wptr, d.w_format = _w_operand(w_packed)
+    wptr, d.w_format, d.w_unscale = _w_operand(w_packed, d)
+    if d.w_format == 3:
+        d.x_amax = (x_amax if x_amax is not None else amax_word(x)).data_ptr()
     if bf16_products:                      # the fp32 stem of the bf16 / fp8 engines: products from the first bf16 terms (w_format 2)
         ws = getattr(w_packed, "_rn_split", None)
         if ws is None:
@@ -118,11 +128,13 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
         out_el = N * Ho * Wo * Cout
         mask_el = 0.0 if mask is None else (1.0 / 32 if mask_mode & MASK_BITS else 1.0)
         nb = 4.0 * (x.numel() + out_el * (1 + (add is not None) + mask_el + (1.0 / 32 if bits is not None else 0.0))) \
-            + (6.0 if d.w_format else 4.0) * w_packed.numel() + (4.0 * add2.numel() if add2 is not None else 0.0)
+            + {0: 4.0, 1: 6.0, 2: 6.0, 3: 4.0}[d.w_format] * w_packed.numel() + (4.0 * add2.numel() if add2 is not None else 0.0)
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm(
         ctypes.byref(d), x.data_ptr(), wptr, y.data_ptr(), _hip.ptr(scale), _hip.ptr(shift),
         _hip.ptr(add), mask_ptr, _hip.ptr(add2), _hip.stream()), nb)
     _hip.check(rc, "rn_conv_igemm")
+    if yam is not None and amax is None:
+        amax_attach(y, yam)
     return y
 
 
@@ -141,12 +153,13 @@ def _make_desc(x, geom, act, add_mode, add_hw, mask_mode, in_relu, out_map, y_ba
 
 
 # ---------------------------------------------------------------------------------------------- Winograd F(4x4,3x3)
-FP32_MFMA_MODES = ("native", "split")            # RN_FP32_NATIVE, RN_FP32_SPLIT of include/retinanet_mi355x.h
+FP32_MFMA_MODES = ("native", "split", "split3")  # RN_FP32_NATIVE, RN_FP32_SPLIT, RN_FP32_SPLIT3 of include/retinanet_mi355x.h
 
 
 def set_fp32_mfma(mode):
-    """How the fp32 convolution kernels form their products: "native" (v_mfma_f32_32x32x2_f32) or "split" (three-term
-    bf16 splits of both fp32 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation; csrc/mfma_split.h).  Process-wide."""
+    """How the fp32 convolution kernels form their products: "native" (v_mfma_f32_32x32x2_f32), "split" (three-term
+    bf16 splits of both fp32 operands on v_mfma_f32_32x32x16_bf16, six MFMAs per product) or "split3" (two-term fp16 splits of the
+    operands scaled by powers of two, three MFMAs per product); fp32 accumulation in all (csrc/mfma_split.h).  Process-wide."""
     _hip.check(_hip.load().rn_set_fp32_mfma(FP32_MFMA_MODES.index(mode)), "rn_set_fp32_mfma")
 
 
@@ -154,7 +167,7 @@ def get_fp32_mfma():
     return FP32_MFMA_MODES[_hip.load().rn_get_fp32_mfma()]
 
 
-PRESPLIT = os.environ.get("RN_FP32_PRESPLIT", "1") != "0"      # split mode: prepare the weights' three terms once (rn_split_weights)
+PRESPLIT = os.environ.get("RN_FP32_PRESPLIT", "1") != "0"      # split modes: prepare the weights' terms once (rn_split_weights*)
 
 
 def split_weights(w_packed):
@@ -171,38 +184,114 @@ def split_weights(w_packed):
     return w_packed
 
 
-def _maybe_split(w_packed):
-    """split mode: attach the pre-split twin -- for reductions long enough to run on the split kernels (rn_fp32_split_min_k;
-    the packed row is the reduction, padded)."""
-    if PRESPLIT and get_fp32_mfma() == "split" and w_packed.shape[-1] >= _hip.load().rn_fp32_split_min_k():
-        return split_weights(w_packed)
+def split_weights_f16(w_packed):
+    """split3 mode: attach the fp16 two-term twin of a packed fp32 weight tensor (rn_split_weights_f16: rows * Kpad * 4 bytes, every
+    row written with its own power-of-two scale) as w_packed._rn_split16 = (terms, inverse row scales [rows])."""
+    lib = _hip.load()
+    kpad = w_packed.shape[-1]
+    rows = w_packed.numel() // kpad
+    tw = getattr(w_packed, "_rn_split16", None)
+    if tw is None:
+        tw = (torch.empty(w_packed.numel() * 4, dtype=torch.uint8, device=w_packed.device),
+              torch.empty(rows, dtype=torch.float32, device=w_packed.device))
+    _hip.check(lib.rn_split_weights_f16(w_packed.data_ptr(), tw[0].data_ptr(), tw[1].data_ptr(), rows, kpad, _hip.stream()),
+               "rn_split_weights_f16")
+    w_packed._rn_split16 = tw
     return w_packed
 
 
+def f16_shape_ok(rows, cin, taps=1):
+    """Geometry half of rn_conv_igemm_wants_f16 (csrc/conv_igemm_mf16.hip: mf16_geom_ok) as the weight side sees it: which packed
+    tensors get the fp16 twin in split3 mode (the others keep the three-term bf16 twin and their kernels)."""
+    return rows > 64 and rows % 4 == 0 and cin % 32 == 0 and taps <= 24
+
+
+def _maybe_split(w_packed, rows=None, cin=None, taps=1):
+    """split modes: attach the pre-split twin -- for reductions long enough to run on the split kernels (rn_fp32_split_min_k;
+    the packed row is the reduction, padded).  split3: the fp16 twin where the fp16 kernels take the layer (f16_shape_ok)."""
+    mode = get_fp32_mfma()
+    if not PRESPLIT or mode == "native" or w_packed.shape[-1] < _hip.load().rn_fp32_split_min_k():
+        return w_packed
+    if mode == "split3" and rows is not None and f16_shape_ok(rows, cin, taps):
+        return split_weights_f16(w_packed)
+    return split_weights(w_packed)
+
+
 def _carry_split(src, view):
-    """A view of a packed tensor keeps its pre-split twin."""
-    ws = getattr(src, "_rn_split", None)
-    if ws is not None:
-        view._rn_split = ws
+    """A view of a packed tensor keeps its pre-split twins."""
+    for name in ("_rn_split", "_rn_split16"):
+        ws = getattr(src, name, None)
+        if ws is not None:
+            setattr(view, name, ws)
     return view
 
 
-def _w_operand(w_packed):
-    """(pointer, rn_conv_desc.w_format) of the weight operand for rn_conv_igemm / _grouped."""
+def _w_operand(w_packed, d=None):
+    """(pointer, rn_conv_desc.w_format, inverse-row-scale pointer) of the weight operand for rn_conv_igemm / _grouped; d: the problem's
+    descriptor (split3: the library says whether it runs on an fp16-split kernel, rn_conv_igemm_wants_f16)."""
     if PRESPLIT:
+        mode = get_fp32_mfma()
+        if mode == "split3" and d is not None:
+            tw = getattr(w_packed, "_rn_split16", None)
+            if tw is not None and _hip.load().rn_conv_igemm_wants_f16(ctypes.byref(d)):
+                return tw[0].data_ptr(), 3, tw[1].data_ptr()
         ws = getattr(w_packed, "_rn_split", None)
-        if ws is not None and get_fp32_mfma() == "split":
-            return ws.data_ptr(), 1
-    return w_packed.data_ptr(), 0
+        if ws is not None and mode != "native":
+            return ws.data_ptr(), 1, None
+    return w_packed.data_ptr(), 0, None
+
+
+# ---- amax words (split3; include/retinanet_mi355x.h: rn_conv_desc.x_amax / y_amax).  A producer launched with an amax word leaves the
+# exponent of its result's largest magnitude in it; the tensor object carries (word, tensor._version at that time) as ._rn_amax.  A
+# consumer takes the word if the version still matches (an in-place torch operation since then invalidates it; this module's own in-place
+# kernels drop the attribute), else one rn_amax pass computes it.  Words are views of zeroed chunks that are never reused.
+_AMAX_CHUNK = {}
+
+
+def amax_slot(device):
+    """A fresh zeroed amax word (int32 tensor of one element) on `device`."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    c = _AMAX_CHUNK.get(key)
+    if c is None or c[1] >= c[0].numel():
+        c = _AMAX_CHUNK[key] = [torch.zeros(1024, dtype=torch.int32, device=device), 0]
+    c[1] += 1
+    return c[0][c[1] - 1:c[1]]
+
+
+def amax_attach(t, slot):
+    t._rn_amax = (slot, t._version)
+    return slot
+
+
+def amax_word(t):
+    """The amax word of a dense fp32 tensor: its producer's (see above) or computed now (cached on the tensor object)."""
+    a = getattr(t, "_rn_amax", None)
+    if a is not None and a[1] == t._version:
+        return a[0]
+    assert t.is_contiguous() and t.dtype == torch.float32
+    slot = amax_slot(t.device)
+    if t.numel():
+        _hip.check(_hip.load().rn_amax(t.data_ptr(), t.numel(), slot.data_ptr(), _hip.stream()), "rn_amax")
+    return amax_attach(t, slot)
+
+
+def amax_drop(t):
+    """After an in-place kernel of this module rewrote t."""
+    if hasattr(t, "_rn_amax"):
+        del t._rn_amax
+
+
+def want_amax():
+    """Producers leave amax words in split3 mode (their consumers need them)."""
+    return get_fp32_mfma() == "split3"
 
 
 # RN_OPT_* of include/retinanet_mi355x.h
-OPT_SPLITK, OPT_DETERMINISTIC, OPT_MF16, OPT_MF16_MIN, OPT_MF16_NARROW, OPT_BIG_TILE, OPT_BIG_TILE_MIN, OPT_WGRAD_ONCE, \
-    OPT_PERSIST, OPT_PERSIST_MAX_K, OPT_PERSIST_WGS, OPT_BF16_P8, OPT_FP8_P8 = range(13)
+OPT_SPLITK, OPT_DETERMINISTIC, OPT_MF16, OPT_MF16_MIN, OPT_WGRAD_ONCE, OPT_BF16_P8, OPT_FP8_P8 = range(7)
 
 
 def set_option(option, value):
-    """Process-wide run-time option of the library (0 / 1 switches take a bool; the tile-count thresholds and RN_OPT_BIG_TILE an int)."""
+    """Process-wide run-time option of the library (0 / 1 switches take a bool; the tile-count threshold and the P8 selectors an int)."""
     _hip.check(_hip.load().rn_set_option(option, int(value)), "rn_set_option")
 
 
@@ -241,7 +330,7 @@ def wino_weights(weight, mode=0, scale=None):
     U = torch.empty((36, rows, (k + 31) // 32 * 32), dtype=torch.float32, device=w.device)
     _hip.check(lib.rn_wino_weights(w.data_ptr(), U.data_ptr(), cout, cin, mode, _hip.ptr(scale), _hip.stream()),
                "rn_wino_weights")
-    return _maybe_split(U)
+    return _maybe_split(U, rows=rows, cin=U.shape[2], taps=1)
 
 
 _WINO_WS = {}
@@ -277,6 +366,16 @@ def _wino_transform_in(xs, V, C, Tpad, dy_form):
         _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_group(
             ctypes.byref(g), V.data_ptr(), C, off, Tpad, dy_form, _hip.stream())), "rn_wino_input_group")
         off += t
+
+
+def _wino_amax(V, Tpad, T, C):
+    """split3: the amax word of a Winograd-domain tensor [36][Tpad][C] whose rows past T are scratch: zeroed, then one rn_amax pass.
+    (Fallback for transforms that did not leave the word themselves.)"""
+    if T < Tpad:
+        V[:36 * Tpad * C].view(36, Tpad, C)[:, T:].zero_()
+    slot = amax_slot(V.device)
+    _hip.check(_hip.load().rn_amax(V.data_ptr(), 36 * Tpad * C, slot.data_ptr(), _hip.stream()), "rn_amax")
+    return slot
 
 
 def _wino_workspace(device, floats_v, floats_m):
@@ -317,13 +416,19 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     elif keep_v:                                     # the caller keeps B^T d B of the inputs for the weight gradient
         V = torch.empty(36 * Tpad * C, dtype=torch.float32, device=dev)
     assert all(x.is_contiguous() for x in xs)
-    if not reuse:
+    v_am = None
+    if reuse:                                        # a kept / handed-over V comes with its amax word (split3), if it had one
+        src = V_ready if ready else V_in
+        v_am = src[2] if len(src) > 2 else None
+    else:
         _wino_transform_in(xs, V, C, Tpad, 0)
     # rows past T hold whatever the scratch tensor held: they produce rows of M nobody reads
     Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
     Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)
+    if v_am is None and getattr(U, "_rn_split16", None) is not None and get_fp32_mfma() == "split3":
+        v_am = _wino_amax(V, Tpad, T, C)
     conv_igemm(Vv, _carry_split(U, U.view(36 * cout, U.shape[2])), Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0),
-               flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2])    # executed FLOPs: same kernel, same family
+               flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2], x_amax=v_am)    # executed FLOPs: same kernel, same family
     if outs is None:
         outs = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in xs]
     off = 0
@@ -344,7 +449,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
             ctypes.byref(g), M.data_ptr(), cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), mm,
             act, y_batch_stride, _hip.stream())), "rn_wino_output_group")
         off += t
-    return (outs, (V, tuple(tuple(x.shape) for x in xs))) if keep_v else outs   # V + the shapes it belongs to
+    return (outs, (V, tuple(tuple(x.shape) for x in xs), v_am)) if keep_v else outs   # V + the shapes it belongs to (+ its amax word)
 
 
 def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_input=False):
@@ -397,15 +502,23 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
     g = _hip.ConvGroup()
     g.n = len(problems)
     total = 0
-    wptr, wfmt = _w_operand(w_packed)
+    wptr, wfmt, wus = None, None, None
+    yams = []
     for i, pr in enumerate(problems):
         x, geom = pr["x"], pr["geom"]
         add, mask = pr.get("add"), pr.get("mask")
         mask_ptr, mmode = _mask_operand(mask, pr.get("mask_mode", 2))
         d = _make_desc(x, geom, act, 1 if add is not None else 0, (0, 0), mmode, False, None, pr.get("y_batch_stride"), None, None)
-        d.w_format = wfmt
+        if wfmt is None:                       # the problems share Cin / Cout / taps: one kernel family, one weight form for all
+            wptr, wfmt, wus = _w_operand(w_packed, d)
+        d.w_format, d.w_unscale = wfmt, wus
+        if wfmt == 3:
+            d.x_amax = amax_word(x).data_ptr()
         bits = _sign_words(pr["y"], pr.get("sign", False) and pr.get("y_batch_stride") is None)
         d.sign_out = None if bits is None else bits.data_ptr()
+        yam = amax_slot(x.device) if want_amax() and pr.get("y_batch_stride") is None else None
+        yams.append(yam)
+        d.y_amax = None if yam is None else yam.data_ptr()
         g.d[i] = d
         M = d.N * d.Ho * d.Wo
         total += (M + 255) // 256 if d.Cout <= 64 else ((M + 127) // 128) * ((d.Cout + 127) // 128)
@@ -416,7 +529,7 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
         kind += " grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh)
     nb = 0.0
     if prof.ACTIVE is not None:
-        nb = (6.0 if wfmt else 4.0) * w_packed.numel()
+        nb = {0: 4.0, 1: 6.0, 3: 4.0}[wfmt] * w_packed.numel()
         for pr in problems:
             dd = pr["geom"]
             out_el = pr["x"].shape[0] * dd[0] * dd[1] * dd[2]
@@ -424,6 +537,9 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_grouped(
         ctypes.byref(g), wptr, _hip.ptr(scale), _hip.ptr(shift), _hip.stream()), nb)
     _hip.check(rc, "rn_conv_igemm_grouped")
+    for pr, yam in zip(problems, yams):
+        if yam is not None:
+            amax_attach(pr["y"], yam)
 
 
 def fprop(x, w_packed, cout, k, stride, pad, kw_pad=None, **kw):
@@ -469,13 +585,16 @@ def dgrad_s2_classes(dy, class_weights, in_hw, cin, k, pad, flops=0.0, **kw):
     if len(classes) < 4:
         dx.zero_()                                  # classes without taps (k = 1) receive no gradient
     total_taps = sum(c[2][1] * c[2][3] for c in classes)
+    slot = amax_slot(dy.device) if want_amax() else None      # split3: the classes fill ONE tensor: one amax word for all of them
     for (ph, pw, (r0, nr, s0, ns), (dh0, dw0)), wc in zip(classes, class_weights):
         gh, gw = (Hi - ph + 1) // 2, (Wi - pw + 1) // 2
         if gh <= 0 or gw <= 0:
             continue
         # input row = a + dh0 - i, input column = b + dw0 - j  (a = 1, b = -1, p = dh0, p_w = dw0)
         conv_igemm(dy, wc, dx, (gh, gw, cin, nr, ns, 1, -1, (dh0, dw0), 0), out_map=(2, ph, pw, Hi, Wi),
-                   flops=flops * nr * ns / total_taps, **kw)
+                   flops=flops * nr * ns / total_taps, amax=slot, **kw)
+    if slot is not None:
+        amax_attach(dx, slot)
     return dx
 
 

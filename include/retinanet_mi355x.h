@@ -269,6 +269,14 @@ typedef struct rn_conv_desc {
                                       = (y[e] > 0) for every stored element at float offset e -- what the backward pass needs of a ReLU
                                       output (D/utils.py:60-80), at 1/32 of the bytes.  Needs Cout % 32 == 0 and y_batch_stride % 32
                                       == 0.  mask_mode | RN_MASK_BITS (4): `mask` points to such words (the consumer's side). */
+    const void *x_amax;            /* RN_FP32_SPLIT3 (round 5): the AMAX WORD of x -- one uint32 holding the fp32 bit pattern of a value whose
+                                      exponent is that of the tensor's largest |element| (what a producer's y_amax left, or rn_amax) --
+                                      from which the kernel takes the power-of-two scale of its fp16 split.  Required when w_format == 3. */
+    void *y_amax;                  /* NULL, or the amax word of the RESULT: every kernel that finishes elements raises it (atomic max at
+                                      device scope) to the largest |y| it stored; the caller zeroes it before the launch.  Any product
+                                      mode; not by the raw Winograd-stage GEMM (its result feeds a transform, not a convolution). */
+    const float *w_unscale;        /* w_format == 3: per weight row the inverse 2^-s of the power-of-two scale its fp16 terms were
+                                      written with (rn_split_weights_f16); [batch * Cout] when w_batch_stride != 0 */
 } rn_conv_desc;
 #define RN_MASK_BITS 4
 
@@ -279,9 +287,16 @@ typedef struct rn_conv_desc {
  *                   product is the sum of the six largest of the nine term products on v_mfma_f32_32x32x16_bf16 with the
  *                   fp32 accumulator; the three dropped terms are at most 2^-23 of the product (2^-25 rms), the size of
  *                   one fp32 rounding (csrc/mfma_split.h; DESIGN.md 4.6 has the measured errors of both modes against fp64).
- * Process-wide; initial value from the environment variable RN_FP32_MFMA = native | split, else RN_FP32_DEFAULT. */
+ *   RN_FP32_SPLIT3  (round 5) each operand, scaled by a power of two so that its tensor's largest magnitude lands in [2^14, 2^15), is
+ *                   split into TWO fp16 terms hi + lo (22 significand bits + a sign: |error| <= 2^-22 |x| for elements down to 2^-18
+ *                   of the tensor's maximum, an absolute 2^-40 of the maximum below that) and a product is hi*hi + hi*lo + lo*hi
+ *                   on v_mfma_f32_16x16x32_f16 / 32x32x16_f16: THREE MFMAs instead of six (csrc/mfma_split.h, second half).  Weight
+ *                   scales per output channel (rn_split_weights_f16), activation / gradient scales per tensor from amax words
+ *                   (rn_conv_desc.x_amax).  Kernels that have no such form yet run the RN_FP32_SPLIT one in this mode.
+ * Process-wide; initial value from the environment variable RN_FP32_MFMA = native | split | split3, else RN_FP32_DEFAULT. */
 #define RN_FP32_NATIVE 0
 #define RN_FP32_SPLIT 1
+#define RN_FP32_SPLIT3 2
 #define RN_FP32_DEFAULT RN_FP32_SPLIT
 int rn_get_fp32_mfma(void);
 int rn_set_fp32_mfma(int mode);
@@ -298,17 +313,7 @@ int rn_set_fp32_mfma(int mode);
  * Kernel selectors of the split-operand family (A/B switches; the defaults are the measured best):
  *   RN_OPT_MF16           (RN_MF16, 0/1, default 1)  wide layers with Cin % 32 == 0 take csrc/conv_igemm_mf16.hip (16x16x32 MFMA).
  *   RN_OPT_MF16_MIN       (RN_MF16_MIN, >= 0, default 1)  fewest tiles a launch needs to take it.
- *   RN_OPT_MF16_NARROW    (RN_MF16_NARROW, 0/1, default 0)  its 128 x 64 instance for layers with at most 64 output channels.
- *   RN_OPT_BIG_TILE       (RN_BIG_TILE, 0..3, default 0)  256 x 256 tile variants (csrc/conv_igemm_big.hip).
- *   RN_OPT_BIG_TILE_MIN   (RN_BIG_TILE_MIN, >= 0, default 200)  fewest 256 x 256 tiles a launch needs to take them.
  *   RN_OPT_WGRAD_ONCE     (RN_WGRAD_ONCE, 0/1, default 1)  weight gradient's 128 x 128 tile splits its operands once per workgroup.
- *   RN_OPT_PERSIST        (RN_PERSIST, 0/1, default 0)  the plain-GEMM launches with a short reduction (the Winograd stage) run as
- *                         persistent workgroups with two accumulator sets and the stores of tile n spread over the K-steps of
- *                         tile n + 1 (csrc/conv_igemm_mf16p.hip).  Measured 4-9 % slower than the plain launch
- *                         (profiles/r04_persist_analysis.txt): opt-in, kept with its parity tests.
- *   RN_OPT_PERSIST_MAX_K  (RN_PERSIST_MAX_K, >= 0, default 640)  longest reduction Cin that takes that form.
- *   RN_OPT_PERSIST_WGS    (RN_PERSIST_WGS, >= 0, default 0 = two per CU)  workgroups of a persistent launch (rounded up to a multiple
- *                         of 8); a launch takes the persistent form only when it has more tiles than that.
  *   RN_OPT_BF16_P8        (RN_BF16_P8, 0..2, default 1)  the bf16 engine's stride-1 same-size convolutions on the eight-wave 256 x 256 x 64
  *                         tile with the phased K loop (csrc/conv_bf16_p8.hip): 0 never, 1 where it measured faster, 2 wherever legal.
  *   RN_OPT_FP8_P8         (RN_FP8_P8, 0..2, default 1)  the same for the fp8 inference engine (csrc/conv_fp8_p8.hip, 256 x 256 x 128). */
@@ -316,16 +321,10 @@ int rn_set_fp32_mfma(int mode);
 #define RN_OPT_DETERMINISTIC 1
 #define RN_OPT_MF16 2
 #define RN_OPT_MF16_MIN 3
-#define RN_OPT_MF16_NARROW 4
-#define RN_OPT_BIG_TILE 5
-#define RN_OPT_BIG_TILE_MIN 6
-#define RN_OPT_WGRAD_ONCE 7
-#define RN_OPT_PERSIST 8
-#define RN_OPT_PERSIST_MAX_K 9
-#define RN_OPT_PERSIST_WGS 10
-#define RN_OPT_BF16_P8 11
-#define RN_OPT_FP8_P8 12
-#define RN_OPT_COUNT 13
+#define RN_OPT_WGRAD_ONCE 4
+#define RN_OPT_BF16_P8 5
+#define RN_OPT_FP8_P8 6
+#define RN_OPT_COUNT 7
 int rn_get_option(int option);
 int rn_set_option(int option, int value);
 /* RN_FP32_SPLIT applies to rn_conv_igemm / _grouped launches with kh*kw*Cin >= this (64; environment RN_FP32_SPLIT_MIN_K);
@@ -336,6 +335,16 @@ int rn_fp32_split_min_k(void);
  * w_split [rows][Kpad/16][3][16] bf16 (6 bytes per element of w_packed [rows][Kpad], Kpad % 16 == 0; for a batch of GEMMs
  * rows = batch * rows).  Pass it as w_packed with rn_conv_desc.w_format = 1.  (rn_prep_batched: job kind 4.) */
 int rn_split_weights(const float *w_packed, void *w_split, int64_t rows, int Kpad, void *stream);
+/* RN_FP32_SPLIT3's weight operand: [rows][Kpad/16] records of 64 bytes = the hi and lo fp16 terms (2 x 16) of the row's 16 values of
+ * a K-step, written with the row's own power-of-two scale (largest |value| of the row -> [2^14, 2^15)); row_unscale[rows] receives
+ * the inverse scales.  Pass as w_packed with rn_conv_desc.w_format = 3 and w_unscale = row_unscale.  (rn_prep_batched: job kind 5.) */
+int rn_split_weights_f16(const float *w_packed, void *w_split, float *row_unscale, int64_t rows, int Kpad, void *stream);
+/* The amax word of a tensor (rn_conv_desc.x_amax) for tensors no producer left one for: *amax = max(*amax, bits of max |x[i]|);
+ * zero the word first.  One pass over x. */
+int rn_amax(const float *x, int64_t n, void *amax, void *stream);
+/* 1 when rn_conv_igemm would run this problem on an fp16-split kernel in RN_FP32_SPLIT3 mode (so: wants w_format 3, x_amax, w_unscale),
+ * 0 when it keeps the three-term kernels (w_format 0 / 1).  Depends on the geometry only. */
+int rn_conv_igemm_wants_f16(const rn_conv_desc *d);
 
 int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
                   const float *scale, const float *shift, const float *add, const float *mask, const float *add2,

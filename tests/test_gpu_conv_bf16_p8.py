@@ -209,63 +209,3 @@ def test_dominant_layer_at_full_size(cv, dev):
     close_bf16(nchw(y[:1, :23].float()), want)
     y2 = cv.fprop_bf16(xb, cv.pack_weights_bf16((2.0 * w).to(dev), 0), C, 3, 1, 1)
     assert torch.equal(y2.float(), 2.0 * y.float())            # a power of two scales every product and sum exactly
-
-
-# ------------------------------------------------------------------------------------------------ weight gradient (csrc/conv_wgrad_bf16_p8.hip)
-def close_f32(got, want, tol):
-    got, want = got.detach().cpu().float(), want.detach().cpu().float()
-    assert got.shape == want.shape, (got.shape, want.shape)
-    err, ref = float((got - want).abs().max()), float(want.abs().max()) + 1e-12
-    assert err <= tol * ref, "max err %.3e vs max |ref| %.3e" % (err, ref)
-
-
-WGRAD_CASES = [  # cin, cout, k, pad, N, H, W
-    (256, 256, 3, 1, 2, 19, 23),         # 874 pixels: ragged last K-tile, an image boundary inside a K-tile, one slice per ...
-    (256, 512, 1, 0, 2, 15, 17),         # 1x1: one tap, two channel tiles
-    (512, 256, 3, 1, 2, 9, 15),          # two column tiles per tap; 64 pixels = four rows and four columns further (W = 15)
-    (256, 256, 3, 1, 3, 40, 70),         # 8400 pixels: many slices, every one starting inside an image
-]
-
-
-@pytest.mark.parametrize("case", WGRAD_CASES)
-def test_weight_gradient(cv, dev, case):
-    """dW and the column sums of dY against torch's fp32 autograd on the same bf16-rounded operands (fp32 accumulation on both sides: the
-    bound is the 5e-5 of tests/test_gpu_conv_bf16.py), and against the 128 x 128 kernel."""
-    cin, cout, k, pad, N, H, W = case
-    x, w = rnd((N, cin, H, W), 51), rnd((cout, cin, k, k), 52, (2.0 / (k * k * cin)) ** 0.5)
-    xr, wr = r16(x), r16(w).requires_grad_(True)
-    y = F.conv2d(xr, wr, None, 1, pad)
-    g = rnd(tuple(y.shape), 53)
-    y.backward(r16(g))
-    gb, xb = cv.to_bf16(nhwc(g).to(dev)), cv.to_bf16(nhwc(x).to(dev))
-    kp = k * k * cin
-    dw, cs = torch.zeros((cout, kp), device=dev), torch.zeros(cout, device=dev)
-    cv.wgrad_bf16(gb, xb, dw, cout, k, 1, pad, colsum=cs)
-    close_f32(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), wr.grad, 5e-5)
-    close_f32(cs, r16(g).sum(dim=(0, 2, 3)), 5e-5)
-    cv.set_option(cv.OPT_BF16_P8, 0)
-    dw0, cs0 = torch.zeros((cout, kp), device=dev), torch.zeros(cout, device=dev)
-    cv.wgrad_bf16(gb, xb, dw0, cout, k, 1, pad, colsum=cs0)
-    cv.set_option(cv.OPT_BF16_P8, 2)
-    close_f32(dw, dw0, 2e-5)
-    close_f32(cs, cs0, 2e-5)
-    # it ACCUMULATES: a second call doubles the buffers
-    cv.wgrad_bf16(gb, xb, dw, cout, k, 1, pad, colsum=cs)
-    close_f32(dw, 2.0 * dw0, 4e-5)
-
-
-def test_weight_gradient_of_a_padded_gradient_slice(cv, dev):
-    """dY rows wider than Cout (ldy > Cout: the head outputs' padded gradient slices, engine.py) and no column sums."""
-    cin, cout, ldy, N, H, W = 256, 256, 288, 2, 11, 13
-    x, g = rnd((N, cin, H, W), 61), rnd((N, ldy, H, W), 62)
-    xb, gb = cv.to_bf16(nhwc(x).to(dev)), cv.to_bf16(nhwc(g).to(dev))
-    dw = torch.zeros((cout, 9 * cin), device=dev)
-    cv.wgrad_bf16(gb, xb, dw, cout, 3, 1, 1)
-    cv.set_option(cv.OPT_BF16_P8, 0)
-    dw0 = torch.zeros((cout, 9 * cin), device=dev)
-    cv.wgrad_bf16(gb, xb, dw0, cout, 3, 1, 1)
-    cv.set_option(cv.OPT_BF16_P8, 2)
-    close_f32(dw, dw0, 2e-5)
-    wr = torch.zeros((cout, cin, 3, 3), requires_grad=True)
-    F.conv2d(r16(x), wr, None, 1, 1).backward(r16(g)[:, :cout])
-    close_f32(dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), wr.grad, 5e-5)

@@ -158,17 +158,17 @@ sys.path.insert(0, %r)
 os.environ["RN_MF16_MIN"] = "7"
 from retinanet_mi355x import _hip, conv
 lib = _hip.load()
-assert conv.get_option(conv.OPT_MF16) == 1 and conv.get_option(conv.OPT_PERSIST) == 0 and conv.get_option(conv.OPT_BIG_TILE) == 0
+assert conv.get_option(conv.OPT_MF16) == 1 and conv.get_option(conv.OPT_BF16_P8) == 1 and conv.get_option(conv.OPT_FP8_P8) == 1
 assert conv.get_option(conv.OPT_WGRAD_ONCE) == 1 and conv.get_option(conv.OPT_SPLITK) == 1 and conv.get_option(conv.OPT_DETERMINISTIC) == 0
 assert conv.get_option(conv.OPT_MF16_MIN) == 7                      # from the environment, at first use
 os.environ["RN_MF16_MIN"] = "9"
 assert conv.get_option(conv.OPT_MF16_MIN) == 7                      # ... and never again
 conv.set_option(conv.OPT_MF16_MIN, 3)
 assert conv.get_option(conv.OPT_MF16_MIN) == 3
-conv.set_option(conv.OPT_BIG_TILE, 3)
-assert lib.rn_set_option(conv.OPT_BIG_TILE, 4) != 0 and conv.get_option(conv.OPT_BIG_TILE) == 3      # out of range: refused, unchanged
+conv.set_option(conv.OPT_BF16_P8, 2)
+assert lib.rn_set_option(conv.OPT_BF16_P8, 3) != 0 and conv.get_option(conv.OPT_BF16_P8) == 2      # out of range: refused, unchanged
 assert lib.rn_set_option(conv.OPT_MF16, 2) != 0 and lib.rn_set_option(99, 1) != 0 and lib.rn_get_option(99) == -1
-assert lib.rn_set_option(conv.OPT_PERSIST_WGS, -1) != 0
+assert lib.rn_set_option(conv.OPT_MF16_MIN, -1) != 0
 print("ok")
 ''' % PKG
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)

@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--mfma", default="", choices=["", "native", "split"], help="fp32 product mode (default: the library's)")
+    ap.add_argument("--mfma", default="", choices=["", "native", "split", "split3"], help="fp32 product mode (default: the library's)")
     args = ap.parse_args()
     if args.mfma:
         cv.set_fp32_mfma(args.mfma)
@@ -85,6 +85,8 @@ def main():
         Uv = U.view(36 * co, c)
         if cv.PRESPLIT and cv.get_fp32_mfma() == "split":
             Uv = cv.split_weights(Uv)
+        elif cv.PRESPLIT and cv.get_fp32_mfma() == "split3":
+            Uv = cv.split_weights_f16(Uv)
         t = timeit(lambda: cv.conv_igemm(V, Uv, Mo, (1, Tpad, co, 1, 1, 1, 1, 0, 0), w_batch_stride=co * c), args.iters)
         tf = 2.0 * 36 * Tpad * co * c / (t * 1e-3) / 1e12
         print("%-26s %5.1f %3.0f%%   ms %.3f   (T %d, %.0f MB in + %.0f MB out)" % (name[:26], tf, 100 * tf / PEAK, t, Tpad, V.numel() * 4e-6, Mo.numel() * 4e-6))
