@@ -62,14 +62,26 @@ struct WgradArgs {
     // in slice order.  NULL: fp32 atomics.
     float *slab, *cs_slab;
     int64_t slab_stride;
+    // RN_FP32_SPLIT3 (fp16 two-term products; mfma_split.h): the amax words of dy and x (their power-of-two scales), else NULL
+    const unsigned *dy_amax, *x_amax;
 };
+
+// scale / inverse scale of an operand from its amax word (wave-uniform)
+__device__ __forceinline__ void wgrad_scales(const unsigned *amax, float &scale, float &unscale) {
+    const int se = rn_f16_scale_exp(__builtin_amdgcn_readfirstlane(*amax));
+    scale = rn_exp_to_float(se);
+    unscale = rn_exp_to_float(254 - se);
+}
 
 // WK pixels per K-step, OCC workgroups per CU the register budget is cut for (LDS: 2 * WK * (BM + BN) * 4 + 8 KiB).
 // SPLIT: split-operand products (mfma_split.h): the 16 pixels of a K-step are one v_mfma_f32_32x32x16_bf16 k extent, a lane's
 // eight of them are the ones it reads anyway (pixels 2j + (lane >> 5)), for both operands.
-template <int WM, int WN, bool RELU, int WK, int OCC, bool SPLIT = false>
+// HALF (with SPLIT): the fp16 two-term form (RN_FP32_SPLIT3): both operands scaled by their tensors' powers of two inside the split,
+// three v_mfma_f32_32x32x16_f16 per block, the tile multiplied by the two inverse scales before it leaves.
+template <int WM, int WN, bool RELU, int WK, int OCC, bool SPLIT = false, bool HALF = false>
 __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p) {
     static_assert(!SPLIT || WK == 16, "split-operand form: 16-pixel K-steps");
+    static_assert(!HALF || SPLIT, "the fp16 form is a split form");
     using G = WgradGeom<WM, WN, WK>;                         // index arithmetic shared with the host-side range check
     constexpr int BM = G::BM, BN = G::BN;
     constexpr int TB = G::TB;                                // K-steps per pixel-table batch: one entry per thread
@@ -192,6 +204,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
 #pragma unroll
             for (int e_ = 0; e_ < 16; ++e_) acc[i][j][e_] = 0.f;
     float2 cs = make_float2(0.f, 0.f);                       // column sums of this lane's two channels (its k parity)
+    float s_a = 1.f, s_b = 1.f, us = 1.f;                    // HALF: operand scales and the product of their inverses
+    if constexpr (HALF) {
+        float ua, ub;
+        wgrad_scales(p.dy_amax, s_a, ua);
+        wgrad_scales(p.x_amax, s_b, ub);
+        us = ua * ub;
+    }
 
     fill_batch(0);
     __syncthreads();
@@ -225,14 +244,25 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
                     if (CS) { cs.x += va.x; cs.y += va.y; }
                     a0[kp] = va.x; a1[kp] = va.y; b0[kp] = vb.x; b1[kp] = vb.y;
                 }
-                const Split8 sa0 = split8(a0), sb0 = split8(b0), sb1 = split8(b1);
-                RN_SPLIT_MFMA(acc[0][0], sa0, sb0);
-                const Split8 sa1 = split8(a1);
-                RN_SPLIT_MFMA(acc[0][1], sa0, sb1);
-                make_offsets();                               // step ks+2 (see the fp32 form below)
-                if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
-                RN_SPLIT_MFMA(acc[1][0], sa1, sb0);
-                RN_SPLIT_MFMA(acc[1][1], sa1, sb1);
+                if constexpr (HALF) {
+                    const SplitH8 sa0 = split8h(a0, s_a), sb0 = split8h(b0, s_b), sb1 = split8h(b1, s_b);
+                    RN_SPLITH_MFMA(acc[0][0], sa0, sb0);
+                    const SplitH8 sa1 = split8h(a1, s_a);
+                    RN_SPLITH_MFMA(acc[0][1], sa0, sb1);
+                    make_offsets();
+                    if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
+                    RN_SPLITH_MFMA(acc[1][0], sa1, sb0);
+                    RN_SPLITH_MFMA(acc[1][1], sa1, sb1);
+                } else {
+                    const Split8 sa0 = split8(a0), sb0 = split8(b0), sb1 = split8(b1);
+                    RN_SPLIT_MFMA(acc[0][0], sa0, sb0);
+                    const Split8 sa1 = split8(a1);
+                    RN_SPLIT_MFMA(acc[0][1], sa0, sb1);
+                    make_offsets();                               // step ks+2 (see the fp32 form below)
+                    if ((ks % TB) == 3 && (ks / TB + 1) * TB < nks) fill_batch(ks / TB + 1);
+                    RN_SPLIT_MFMA(acc[1][0], sa1, sb0);
+                    RN_SPLIT_MFMA(acc[1][1], sa1, sb1);
+                }
                 rn_wait_dma();
                 __syncthreads();
                 continue;
@@ -295,8 +325,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) + tm;   // tile tm: channels 2*i + tm
                 if (row < p.Cout && col < p.Kflat) {
-                    if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = acc[tm][tn][e];
-                    else atomicAdd(out + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                    const float v = HALF ? acc[tm][tn][e] * us : acc[tm][tn][e];
+                    if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = v;
+                    else atomicAdd(out + (int64_t)row * p.Kpad + col, v);
                 }
             }
         }
@@ -321,11 +352,17 @@ __device__ __forceinline__ bf16x8 wgs_operand(const char *img, unsigned a0, unsi
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool RELU>
+// HALF: the fp16 two-term form (RN_FP32_SPLIT3): two planes per operand (a buffer = dY hi, lo, X hi, lo: 16 KB instead of 24), the
+// operands scaled by their tensors' powers of two inside the split, three v_mfma_f32_32x32x16_f16 per block, the tile multiplied by the
+// two inverse scales before its atomics.
+template <bool RELU, bool HALF = false>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs p) {
     using G = WgradSplitGeom;
     constexpr int BM = 128, BN = 128, WK = G::WK, TB = G::TB;
-    __shared__ __attribute__((aligned(16))) char lds[2][G::BUF];
+    constexpr int NP = HALF ? 2 : 3;                         // planes per operand
+    constexpr int BUFB = 2 * NP * G::IMG;
+    static_assert(BUFB <= G::BUF && 8 * BM * 4 <= BUFB, "planes fit; the column-sum reduction fits a buffer");
+    __shared__ __attribute__((aligned(16))) char lds[2][BUFB];
     __shared__ int2 pixtab[2][TB * WK];                      // (byte offset of input pixel (ih0, iw0), ih0 | iw0 << 16): 53 KB in all = 3 per CU
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -405,6 +442,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
     };
     float cs4[4] = {0.f, 0.f, 0.f, 0.f};                     // column sums of this thread's 4 dY channels over its pixels
     const bool do_cs = p.colsum != nullptr && batch == p.colsum_batch && (tile % p.tiles_n) == 0;
+    float s_a = 1.f, s_b = 1.f, us = 1.f;                    // HALF: operand scales and the product of their inverses
+    if constexpr (HALF) {
+        float ua, ub;
+        wgrad_scales(p.dy_amax, s_a, ua);
+        wgrad_scales(p.x_amax, s_b, ub);
+        us = ua * ub;
+    }
     // split the registers of one K-step and store the planes of buffer `buf`
     auto split_store = [&](int buf, const Regs &r) {
         char *B = &lds[buf][0];
@@ -420,6 +464,18 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
             if (do_cs) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cs4[j] += av[j];
+            }
+            if constexpr (HALF) {
+                unsigned ah[2], al[2], bh[2], bl[2];
+                split_pair_h(av[0], av[1], s_a, ah[0], al[0]);
+                split_pair_h(av[2], av[3], s_a, ah[1], al[1]);
+                split_pair_h(bv[0], bv[1], s_b, bh[0], bl[0]);
+                split_pair_h(bv[2], bv[3], s_b, bh[1], bl[1]);
+                *reinterpret_cast<uint2 *>(B + 0 * G::IMG + wr) = make_uint2(ah[0], ah[1]);
+                *reinterpret_cast<uint2 *>(B + 1 * G::IMG + wr) = make_uint2(al[0], al[1]);
+                *reinterpret_cast<uint2 *>(B + 2 * G::IMG + wr) = make_uint2(bh[0], bh[1]);
+                *reinterpret_cast<uint2 *>(B + 3 * G::IMG + wr) = make_uint2(bl[0], bl[1]);
+                continue;
             }
             unsigned ah[2], am[2], al[2], bh[2], bm[2], bl[2];
             split_pair(av[0], av[1], ah[0], am[0], al[0]);
@@ -440,7 +496,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
             fa[t][rd] = (unsigned)G::tr_addr(wm, t, rd, lane);
-            fb[t][rd] = (unsigned)(3 * G::IMG + G::tr_addr(wn, t, rd, lane));
+            fb[t][rd] = (unsigned)(NP * G::IMG + G::tr_addr(wn, t, rd, lane));
         }
     f32x16 acc[2][2];
 #pragma unroll
@@ -461,6 +517,22 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
     // the dY descriptor ends at kend and the table marks those pixels invalid).
     auto k_step = [&](int ks, int buf, Regs &cur, Regs &nxt) {
         const char *S = &lds[buf][0];
+        if constexpr (HALF) {
+            SplitH8 sa[2], sb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sa[t].h = __builtin_bit_cast(f16x8, wgs_operand(S, fa[t][0], fa[t][1]));
+                sa[t].l = __builtin_bit_cast(f16x8, wgs_operand(S + G::IMG, fa[t][0], fa[t][1]));
+                sb[t].h = __builtin_bit_cast(f16x8, wgs_operand(S, fb[t][0], fb[t][1]));
+                sb[t].l = __builtin_bit_cast(f16x8, wgs_operand(S + G::IMG, fb[t][0], fb[t][1]));
+            }
+            split_store(buf ^ 1, cur);
+            load_step(ks + 2, nxt);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) RN_SPLITH_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+        } else {
         Split8 sa[2], sb[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -477,6 +549,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) RN_SPLIT_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+        }
         // table batch b is first read for step b * TB (loaded in iteration b * TB - 2); its slot held batch b - 2, last read in
         // iteration (b - 1) * TB - 3: fill it in iteration (b - 1) * TB + 4
         if ((ks % TB) == 4 && (ks / TB + 1) * TB < nks + 2) fill_batch(ks / TB + 1);
@@ -513,8 +586,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (row < p.Cout && col < p.Kflat) {
-                    if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = acc[tm][tn][e];
-                    else atomicAdd(out + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                    const float v = HALF ? acc[tm][tn][e] * us : acc[tm][tn][e];
+                    if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = v;
+                    else atomicAdd(out + (int64_t)row * p.Kpad + col, v);
                 }
             }
         }
@@ -545,24 +619,26 @@ __global__ __launch_bounds__(256) void wgrad_combine_kernel(float *__restrict__ 
 static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                         int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                         int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                        int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes);
+                        int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes,
+                        const void *dy_amax = nullptr, const void *x_amax = nullptr);
 
 extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                                      int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                                      int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                                     int in_relu, void *stream) {
+                                     int in_relu, const void *dy_amax, const void *x_amax, void *stream) {
     return wgrad_launch(dy, ldy, x, dw, colsum, nbatch, dy_bstride, x_bstride, dw_bstride, colsum_batch, N, Hi, Wi, Cin, Ho, Wo, Cout,
-                        kh, kw, stride, pad, in_relu, stream, false, nullptr, 0, nullptr);
+                        kh, kw, stride, pad, in_relu, stream, false, nullptr, 0, nullptr, dy_amax, x_amax);
 }
 
 // Fixed-order reduction (RN_OPT_DETERMINISTIC): same kernel, K slices store into slabs of `workspace`, one ordered combine.
 extern "C" int rn_conv_wgrad_batched_det(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                                          int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                                          int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                                         int in_relu, void *workspace, int64_t workspace_bytes, void *stream) {
+                                         int in_relu, const void *dy_amax, const void *x_amax, void *workspace, int64_t workspace_bytes,
+                                         void *stream) {
     if (workspace == nullptr) return RN_EINVAL;
     return wgrad_launch(dy, ldy, x, dw, colsum, nbatch, dy_bstride, x_bstride, dw_bstride, colsum_batch, N, Hi, Wi, Cin, Ho, Wo, Cout,
-                        kh, kw, stride, pad, in_relu, stream, true, workspace, workspace_bytes, nullptr);
+                        kh, kw, stride, pad, in_relu, stream, true, workspace, workspace_bytes, nullptr, dy_amax, x_amax);
 }
 
 // Bytes of workspace rn_conv_wgrad_batched_det needs for this problem (slices x (result image + Cout column sums)).
@@ -577,7 +653,8 @@ extern "C" int64_t rn_conv_wgrad_det_workspace_bytes(int ldy, int nbatch, int64_
 static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                         int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                         int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                        int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes) {
+                        int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes,
+                        const void *dy_amax, const void *x_amax) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
         return RN_EINVAL;
     if (nbatch < 1 || nbatch > 4096 || dy_bstride < 0 || x_bstride < 0 || dw_bstride < 0 || colsum_batch < 0 || colsum_batch >= nbatch)
@@ -602,7 +679,7 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
     // least 512 pixels long
     static const int wgs_native = getenv("RN_WGRAD_WGS") ? atoi(getenv("RN_WGRAD_WGS")) : 2048;
     static const int wgs_split = getenv("RN_WGRAD_SPLIT_WGS") ? atoi(getenv("RN_WGRAD_SPLIT_WGS")) : 1536;   // split kernels: three per CU -> two rounds of 768 (measured 768 / 1024 / 1536 / 2048 / 3072: 21.8 / 21.5 / 20.6 / 21.0 / 21.5 ms per step)
-    const int wg_target = rn_get_fp32_mfma() == RN_FP32_SPLIT ? wgs_split : wgs_native;
+    const int wg_target = rn_get_fp32_mfma() != RN_FP32_NATIVE ? wgs_split : wgs_native;
     int64_t splits = (wg_target + tiles - 1) / tiles;
     const int64_t max_splits = (a.pixels + 16 * WK_MAX - 1) / (16 * WK_MAX);
     if (splits > max_splits) splits = max_splits;
@@ -637,10 +714,17 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
     const dim3 grid((unsigned)(tiles * (a.xcd_map ? (splits + 7) / 8 * 8 : splits)));
     // 16-pixel K-steps: 40-48 KiB of LDS, four / three workgroups per CU (measured: +2..4 % over 32-pixel steps at two per CU
     // on the mid-size layers, equal on the largest; the 64 x 256 tile does not fit twice at 32).
-    const bool split = rn_get_fp32_mfma() == RN_FP32_SPLIT;
+    const bool split = rn_get_fp32_mfma() != RN_FP32_NATIVE;
+    // RN_FP32_SPLIT3 with both amax words: the fp16 two-term kernels; without them (a caller of the plain entry point) the three-term ones
+    const bool half = rn_get_fp32_mfma() == RN_FP32_SPLIT3 && dy_amax != nullptr && x_amax != nullptr;
+    a.dy_amax = reinterpret_cast<const unsigned *>(dy_amax);
+    a.x_amax = reinterpret_cast<const unsigned *>(x_amax);
 #define RN_WGRAD_LAUNCH(WM_, WN_)                                                                                        \
     do {                                                                                                                 \
-        if (split) {                                                                                                     \
+        if (half) {                                                                                                      \
+            if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3, true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+            else hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, false, 16, 3, true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);         \
+        } else if (split) {                                                                                              \
             if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
             else hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, false, 16, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, a);         \
         } else if (in_relu) hipLaunchKernelGGL((conv_wgrad_kernel<WM_, WN_, true, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
@@ -648,7 +732,10 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
     } while (0)
     // RN_OPT_WGRAD_ONCE = 0: the per-wave split for the 128 x 128 tile too (A/B)
     const bool once = split && shape == 2 && rn_get_option(RN_OPT_WGRAD_ONCE) != 0 && Hi + pad < 32000 && Wi + pad < 32000;
-    if (once) {
+    if (once && half) {
+        if (in_relu) hipLaunchKernelGGL((conv_wgrad_once_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_once_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else if (once) {
         if (in_relu) hipLaunchKernelGGL((conv_wgrad_once_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_wgrad_once_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     } else if (shape == 0) RN_WGRAD_LAUNCH(1, 4);
@@ -670,5 +757,5 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
                              int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
                              void *stream) {
     return rn_conv_wgrad_batched(dy, ldy, x, dw, colsum, 1, 0, 0, 0, 0, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
-                                 in_relu, stream);
+                                 in_relu, nullptr, nullptr, stream);
 }

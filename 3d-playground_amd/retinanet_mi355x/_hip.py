@@ -139,8 +139,8 @@ SIGNATURES.update({
     "rn_wino_weights": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rn_wino_dy": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "rn_wino_dw": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
-    "rn_conv_wgrad_batched": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp]),
-    "rn_conv_wgrad_batched_det": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_i64, c_vp]),
+    "rn_conv_wgrad_batched": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_vp, c_vp]),
+    "rn_conv_wgrad_batched_det": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rn_conv_wgrad_det_workspace_bytes": (c_i64, [c_i32, c_i32, c_i64] + [c_i32] * 9),
     "rn_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "rn_bf16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),

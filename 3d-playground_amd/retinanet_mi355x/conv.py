@@ -305,17 +305,19 @@ def set_deterministic(on=True):
     set_option(OPT_DETERMINISTIC, on)
 
 
-def _wgrad_call(lib, dev, dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, geom):
+def _wgrad_call(lib, dev, dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, geom, amax=(None, None)):
     """rn_conv_wgrad_batched, or its fixed-order form with a slab workspace when the deterministic option is on.
-    geom = (N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu)."""
+    geom = (N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu); amax = the amax words of (dy, x) (split3 mode) or Nones."""
+    am = (_hip.ptr(amax[0]), _hip.ptr(amax[1]))
     if not lib.rn_get_option(OPT_DETERMINISTIC):
-        return lib.rn_conv_wgrad_batched(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, _hip.stream())
+        return lib.rn_conv_wgrad_batched(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, am[0], am[1],
+                                         _hip.stream())
     N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw = geom[:9]
     nb = lib.rn_conv_wgrad_det_workspace_bytes(ldy, nbatch, dw_bs, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw)
     if nb < 0:
         return 1
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)      # caching allocator: same stream, reused by the next layer
-    return lib.rn_conv_wgrad_batched_det(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom,
+    return lib.rn_conv_wgrad_batched_det(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, am[0], am[1],
                                          ws.data_ptr(), nb, _hip.stream())
 
 
@@ -464,6 +466,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
     Tpad = (T + 255) // 256 * 256
     # V: (B^T d B of the forward's inputs, their shapes) kept by wino_conv_group(keep_v=True); used only for the same grouping
     have_v = V is not None and V[1] == tuple(tuple(x.shape) for x in xs) and V[0].numel() == 36 * Tpad * C
+    v_am = V[2] if have_v and len(V) > 2 else None   # split3: the kept transform's amax word
     V = V[0] if have_v else None
     Vw, Z = _wino_workspace(dev, 0 if have_v else 36 * Tpad * C, 36 * Tpad * cout)
     if not have_v:
@@ -481,15 +484,18 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
         nb = 4.0 * (sum(t.numel() for t in gs) + 2 * 36 * T * cout)
         _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_both_group(
             ctypes.byref(g), Vd.data_ptr(), Z.data_ptr(), cout, 0, Tpad, _hip.stream())), "rn_wino_input_both_group")
-        v_dy = (Vd, tuple(tuple(t.shape) for t in gs))
+        v_dy = (Vd, tuple(tuple(t.shape) for t in gs), None)
     else:
         _wino_transform_in(gs, Z, cout, Tpad, 1)
+    am = (None, None)
+    if want_amax():                                  # split3: both operands of the 36 reductions are Winograd-domain tensors
+        am = (_wino_amax(Z, Tpad, T, cout), v_am if v_am is not None else _wino_amax(V, Tpad, T, C))
     ku = (C + 31) // 32 * 32
     if dU is None or tuple(dU.shape) != (36, cout, ku):      # dU: a ZEROED [36, cout, ku] accumulator of the caller (used once)
         dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
     rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: _wgrad_call(    # executed FLOPs
         lib, dev, Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
-        (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0)))
+        (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0), amax=am))
     _hip.check(rc, "rn_conv_wgrad_batched")
     _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
     return v_dy                                      # (B^T dy B, shapes) for the data gradient that follows, or None when not fused
@@ -605,9 +611,10 @@ def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
     kind = "conv_wgrad" + (" %dx%dx%d %d->%d k%d s%d" % (N, Ho, Wo, Cin, cout, k, stride) if prof.BY_SHAPE else "")
+    am = (amax_word(dy), amax_word(x)) if want_amax() else (None, None)      # split3: the operands' power-of-two scales
     rc = prof.timed(kind, flops, lambda: _wgrad_call(
         lib, dy.device, dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), 1, 0, 0, 0, 0,
-        (N, Hi, Wi, Cin, Ho, Wo, cout, k, k if kw_pad is None else kw_pad, stride, pad, int(in_relu))))
+        (N, Hi, Wi, Cin, Ho, Wo, cout, k, k if kw_pad is None else kw_pad, stride, pad, int(in_relu)), amax=am))
     _hip.check(rc, "rn_conv_wgrad")
     return dw
 

@@ -391,7 +391,10 @@ int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *co
  * x + b*x_bstride, dw + b*dw_bstride (floats); colsum (if given) is taken from entry colsum_batch only. */
 int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                           int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
-                          int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu, void *stream);
+                          int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
+                          const void *dy_amax, const void *x_amax, void *stream);
+/* dy_amax / x_amax (round 5): the amax words of the two operands (rn_conv_desc.x_amax: one uint32 each; for a batched launch one word
+ * covers all entries of the operand) -- with both given, RN_FP32_SPLIT3 mode runs the fp16 two-term kernels; NULL: the three-term ones. */
 /* The same reduction in a FIXED order (RN_OPT_DETERMINISTIC; the host logic selects it when the option is on): every K slice
  * stores its partial result into its own slab of `workspace` (plain stores) and one ordered pass adds slabs 0, 1, 2 ... and the
  * slices' column sums into dw / colsum: bit-identical from run to run, as the reference's CPU autograd is.  Costs one write and
@@ -401,7 +404,7 @@ int64_t rn_conv_wgrad_det_workspace_bytes(int ldy, int nbatch, int64_t dw_bstrid
 int rn_conv_wgrad_batched_det(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                               int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
                               int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
-                              void *workspace, int64_t workspace_bytes, void *stream);
+                              const void *dy_amax, const void *x_amax, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------- bf16 convolution engine -----------------
  * The reduced-precision form of rn_conv_igemm / rn_conv_wgrad for BASELINE configs[2] (bf16 MFMA,

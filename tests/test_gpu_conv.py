@@ -12,15 +12,16 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["native", "split", "split-in-kernel"])
+@pytest.fixture(scope="module", params=["native", "split", "split-in-kernel", "split3"])
 def cv(dev, request):
-    """Every test of this module runs in both product modes of the fp32 kernels (include/retinanet_mi355x.h:
-    RN_FP32_NATIVE / RN_FP32_SPLIT), the split mode with the weights' terms prepared by rn_split_weights (w_format 1) and
-    with both operands split inside the kernels, against the same fp64 / fp32 references with the same tolerances."""
+    """Every test of this module runs in all product modes of the fp32 kernels (include/retinanet_mi355x.h:
+    RN_FP32_NATIVE / RN_FP32_SPLIT / RN_FP32_SPLIT3), the split mode with the weights' terms prepared by rn_split_weights (w_format 1)
+    and with both operands split inside the kernels, split3 with the fp16 two-term kernels wherever they exist -- against the same
+    fp64 / fp32 references with the same tolerances."""
     from retinanet_mi355x import conv
     before = conv.get_fp32_mfma(), conv.PRESPLIT
     conv.set_fp32_mfma(request.param.split("-")[0])
-    conv.PRESPLIT = request.param == "split"
+    conv.PRESPLIT = request.param in ("split", "split3")
     yield conv
     conv.set_fp32_mfma(before[0])
     conv.PRESPLIT = before[1]
