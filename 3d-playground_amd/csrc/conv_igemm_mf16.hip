@@ -90,13 +90,10 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         (int)(unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4), 0x00020000);
     const v4i32 rs_b = make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * EB,
                                  (unsigned)((int64_t)d.Cout * Kpad * EB));
-    // TERMS 2: the activation tensor's power-of-two scale from its amax word (scalar), and the inverse for the epilogue
-    float a_scale = 1.f, a_unscale = 1.f;
-    if constexpr (HALF) {
-        const int se = rn_f16_scale_exp(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned *>(d.x_amax)));
-        a_scale = rn_exp_to_float(se);
-        a_unscale = rn_exp_to_float(254 - se);
-    }
+    // TERMS 2: every activation row has the power-of-two scale of ITS image (rn_conv_desc.x_amax: per image, or per row for the Winograd
+    // stage), taken from the amax words below; the inverses wait in a 128-float table for the epilogue, which multiplies row by row.
+    __shared__ float row_unscale[HALF ? BM : 1];
+    float a_scale[2] = {1.f, 1.f};
 
     // ---- this lane's two activation rows (tile rows 32 * wave + 16 * sm + lr): tap mask and base offset of its 8 k values
     unsigned a_mask[2];
@@ -113,6 +110,12 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             a_img = (int)((int64_t)n * d.x_batch_stride * 4);
             a_h = (int)oh * d.a + d.p;
             a_w = (int)ow * d.a + d.p_w;
+            if constexpr (HALF) {
+                const int se = rn_f16_scale_exp(reinterpret_cast<const unsigned *>(d.x_amax)[
+                    (int64_t)(n_first + (int)n) * d.x_amax_img_stride + (int64_t)rem * d.x_amax_row_stride]);
+                a_scale[sm] = rn_exp_to_float(se);
+                if (lg == 0) row_unscale[row] = rn_exp_to_float(254 - se);      // (the wave's own rows: no other wave reads them)
+            }
         }
         unsigned mk = 0;
         for (int r = 0, t = 0; r < d.kh; ++r)
@@ -186,7 +189,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         for (int sm = 0; sm < 2; ++sm) {
             const float av[8] = {cur.v[2 * sm][0], cur.v[2 * sm][1], cur.v[2 * sm][2], cur.v[2 * sm][3],
                                  cur.v[2 * sm + 1][0], cur.v[2 * sm + 1][1], cur.v[2 * sm + 1][2], cur.v[2 * sm + 1][3]};
-            if constexpr (HALF) sa[sm] = split8h(av, a_scale);
+            if constexpr (HALF) sa[sm] = split8h(av, a_scale[sm]);
             else sa[sm] = split8(av);
         }
         dma_b(ks + 1, rb ^ 1);
@@ -235,10 +238,13 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     for (int j = 0; j < 4; ++j) {
         if (!RAW && col_ok && scale != nullptr) sc[j] = scale[col + j];
         if (!RAW && col_ok && shift != nullptr) sh[j] = shift[col + j];
-        // TERMS 2: the accumulators hold the product of the SCALED operands: both inverse scales (powers of two) ride in the column's factor
-        if (HALF && col_ok) sc[j] *= d.w_unscale[(d.w_batch_stride != 0 ? (int64_t)n_first * d.Cout : 0) + col + j] * a_unscale;
+        // TERMS 2: the accumulators hold the product of the SCALED operands: the weight row's inverse scale (a power of two) rides in
+        // the column's factor, the activation row's is applied row by row below
+        if (HALF && col_ok) sc[j] *= d.w_unscale[(d.w_batch_stride != 0 ? (int64_t)n_first * d.Cout : 0) + col + j];
     }
     float rn_am = 0.f;                                       // largest |y| this lane stored (rn_conv_desc.y_amax)
+    const int64_t m_last = (int64_t)m0 + BM - 1 < M ? (int64_t)m0 + BM - 1 : M - 1;
+    const bool rn_span = (int)(m0 / HoWo) != (int)(m_last / HoWo);           // the tile's rows lie in more than one image (scalar)
 #pragma unroll
     for (int sm = 0; sm < 2; ++sm) {
 #pragma unroll
@@ -271,7 +277,8 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                     const int r = lane / CPR + RPI * (g + i);
                     const int64_t m = (int64_t)m0 + 32 * wave + 16 * sm + r;
                     if (m < M) {
-                        const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                        float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                        if constexpr (HALF) { const float ru = row_unscale[32 * wave + 16 * sm + r]; t.x *= ru; t.y *= ru; t.z *= ru; t.w *= ru; }
                         const int64_t off = off_[i];
                         float mk[4] = {mk_[i].x, mk_[i].y, mk_[i].z, mk_[i].w}, ad[4] = {ad_[i].x, ad_[i].y, ad_[i].z, ad_[i].w};
                         if (!RAW && d.add2_mode == 3) {
@@ -288,7 +295,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip's reads before the next half's writes
         __builtin_amdgcn_wave_barrier();
     }
-    if (!RAW) rn_amax_commit(d.y_amax, rn_am);
+    if (!RAW && !rn_span) rn_amax_commit(d.y_amax, m0 / HoWo, rn_am);
 }
 
 template <bool GENERAL, bool RAW, int TERMS>

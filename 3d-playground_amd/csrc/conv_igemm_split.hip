@@ -132,22 +132,7 @@ extern "C" int rn_split_weights(const float *w_packed, void *w_split, int64_t ro
     return RN_OK;
 }
 
-// ---- RN_FP32_SPLIT3: the fp16 pre-split form (mfma_split.h, second half).  One wave per row: the row's largest magnitude (one pass, wave
-// maximum), its power-of-two scale, then the hi / lo terms of every 8-value chunk.
-__device__ __forceinline__ void split_row_f16(const float *__restrict__ src, void *__restrict__ dst, float *__restrict__ unscale,
-                                              int64_t row, int Kpad, int lane) {
-    const float4 *r4 = reinterpret_cast<const float4 *>(src + row * Kpad);
-    float am = 0.f;
-    for (int i = lane; i < Kpad / 4; i += 64) {
-        const float4 q = r4[i];
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
-    }
-    const int se = rn_f16_scale_exp(__builtin_bit_cast(unsigned, rn_wave_max(am)));
-    if (lane == 0) unscale[row] = rn_exp_to_float(254 - se);
-    const float sc = rn_exp_to_float(se);
-    const int64_t c0 = row * (Kpad / 8);
-    for (int i = lane; i < Kpad / 8; i += 64) split_store_chunk_h(src, dst, c0 + i, sc);
-}
+// ---- RN_FP32_SPLIT3: the fp16 pre-split form (mfma_split.h: split_row_f16, one wave per row)
 __global__ __launch_bounds__(256) void split_weights_f16_kernel(const float *__restrict__ src, void *__restrict__ dst,
                                                                  float *__restrict__ unscale, int64_t rows, int Kpad) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -161,22 +146,28 @@ extern "C" int rn_split_weights_f16(const float *w_packed, void *w_split, float 
     return RN_OK;
 }
 
-// The amax word of a tensor nobody left one for (rn_conv_desc.x_amax): one streaming pass, 8 floats per thread and iteration.
-__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ amax) {
-    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+// The amax words of a tensor nobody left them for (rn_conv_desc.x_amax): one streaming pass, grid.y = image.
+__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t per_image, unsigned *__restrict__ amax) {
+    const float *xi = x + (int64_t)blockIdx.y * per_image;
+    const int64_t n4 = per_image >> 2, stride = (int64_t)gridDim.x * 256;
     float am = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const float4 q = reinterpret_cast<const float4 *>(x)[i];
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    if ((((uintptr_t)xi) & 15) == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const float4 q = reinterpret_cast<const float4 *>(xi)[i];
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (per_image & 3)) am = fmaxf(am, fabsf(xi[(n4 << 2) + threadIdx.x]));
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_image; i += stride) am = fmaxf(am, fabsf(xi[i]));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) am = fmaxf(am, fabsf(x[(n4 << 2) + threadIdx.x]));
-    rn_amax_commit(amax, am);
+    rn_amax_commit(amax, blockIdx.y, am);
 }
-extern "C" int rn_amax(const float *x, int64_t n, void *amax, void *stream) {
-    if (n <= 0 || !amax || ((uintptr_t)x & 15)) return RN_EINVAL;
-    const int64_t want = (n / 4 + 255) / 256;
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want))), dim3(256), 0, (hipStream_t)stream, x, n,
-                       reinterpret_cast<unsigned *>(amax));
+extern "C" int rn_amax(const float *x, int64_t per_image, int n_images, void *amax, void *stream) {
+    if (per_image <= 0 || n_images <= 0 || n_images > 65535 || !amax || ((uintptr_t)x & 3)) return RN_EINVAL;
+    const int64_t want = (per_image / 4 + 255) / 256;
+    const int64_t cap = 2048 / n_images < 8 ? 8 : 2048 / n_images;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(want < 1 ? 1 : (want > cap ? cap : want)), (unsigned)n_images), dim3(256), 0,
+                       (hipStream_t)stream, x, per_image, reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
     const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
     const int cpr = (d.Cout + 3) / 4;                        // 4-channel chunks per output pixel
     const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float rn_am = 0.f;                                       // largest |y| this lane stored (rn_conv_desc.y_amax)
+    float rn_am = 0.f;
+    const bool rn_span = true;                               // rn_conv_desc.y_amax: every chunk into the word of its own image
     if (chunk < M * cpr) {
     const int64_t m = chunk / cpr;
     const int col = (int)(chunk - m * cpr) * 4;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
     const int HoWo = d.Ho * d.Wo;
     RN_EPI_CHUNK_BODY(GENERAL);
     }
-    rn_amax_commit(d.y_amax, rn_am);                         // every lane of the wave arrives here
+    (void)rn_am;
 }
 
 // Slices worth using for this problem (1 = do not split) -- few output tiles and a long K loop.

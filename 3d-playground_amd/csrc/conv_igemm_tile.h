@@ -17,8 +17,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // col, ncol, vec, t, sc, sh, y, add, mask, add2, HoWo from the scope they are expanded in.
 //   RN_EPI_ADDR   -> int64_t off (output / mask / same-geometry addend), aoff, a2off (-1 = none)
 //   RN_EPI_LOAD   -> float mk[4], ad[4] from mask / add / add2
-//   RN_EPI_FINISH -> arithmetic and the store; the lane's running maximum of |stored value| in `float rn_am` of the scope
-//                    (rn_conv_desc.y_amax: committed once per wave by rn_amax_commit after the last chunk)
+//   RN_EPI_FINISH -> arithmetic and the store; rn_conv_desc.y_amax (one word per image): the lane's running maximum of |stored value|
+//                    in `float rn_am` of the scope, committed once per wave by rn_amax_commit after the last chunk when the scope's
+//                    `bool rn_span` is false (all rows of the tile in one image: the usual case), else per chunk into the word of
+//                    the chunk's own image m / HoWo
 #define RN_EPI_ADDR(GENERAL)                                                                                     \
         int64_t off, aoff = -1, a2off = -1; \
         if (!GENERAL) { \
@@ -70,11 +72,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (vec) { \
             *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]); \
             if (d.sign_out != nullptr) rn_sign_store(reinterpret_cast<unsigned *>(d.sign_out), off, v[0], v[1], v[2], v[3]); \
-            if (d.y_amax != nullptr) rn_am = fmaxf(fmaxf(rn_am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3]))); \
+            if (d.y_amax != nullptr) { \
+                const float q_ = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); \
+                if (rn_span) rn_amax_lane(d.y_amax, (int64_t)((unsigned)m / (unsigned)HoWo), q_); else rn_am = fmaxf(rn_am, q_); \
+            } \
         } else { \
+            float q_ = 0.f; \
     _Pragma("unroll") \
             for (int j = 0; j < 4; ++j) \
-                if (j < ncol) { y[off + j] = v[j]; rn_am = fmaxf(rn_am, fabsf(v[j])); } \
+                if (j < ncol) { y[off + j] = v[j]; q_ = fmaxf(q_, fabsf(v[j])); } \
+            if (d.y_amax != nullptr) { if (rn_span) rn_amax_lane(d.y_amax, (int64_t)((unsigned)m / (unsigned)HoWo), q_); else rn_am = fmaxf(rn_am, q_); } \
         }
 
 #define RN_EPI_CHUNK_BODY(GENERAL) \
@@ -621,6 +628,8 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     // float4.  Accumulator element e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile.
     float *T = lds;
     float rn_am = 0.f;                                       // largest |y| this lane stored (rn_conv_desc.y_amax)
+    const int64_t m_last = (int64_t)m0 + BM - 1 < M ? (int64_t)m0 + BM - 1 : M - 1;
+    const bool rn_span = (int)(m0 / HoWo) != (int)(m_last / HoWo);           // the tile's rows lie in more than one image (scalar)
     constexpr int CPR = BN / 4, RPP = 256 / CPR;             // 16-byte chunks per tile row, rows per pass of stores
     const int c4 = tid % CPR;
     const int col = n0 + 4 * c4;
@@ -704,7 +713,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             }
         }
     }
-    if (partial == nullptr) rn_amax_commit(d.y_amax, rn_am);
+    if (partial == nullptr && !rn_span) rn_amax_commit(d.y_amax, m0 / HoWo, rn_am);
 }
 
 

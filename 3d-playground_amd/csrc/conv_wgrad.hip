@@ -62,13 +62,20 @@ struct WgradArgs {
     // in slice order.  NULL: fp32 atomics.
     float *slab, *cs_slab;
     int64_t slab_stride;
-    // RN_FP32_SPLIT3 (fp16 two-term products; mfma_split.h): the amax words of dy and x (their power-of-two scales), else NULL
+    // RN_FP32_SPLIT3 (fp16 two-term products; mfma_split.h): the amax words of dy and x (one per image, or one for a whole
+    // Winograd-domain tensor) and their counts, else NULL.  The reduction runs over the pixels of ALL images, so each operand takes ONE
+    // power-of-two scale: that of the largest of its words.
     const unsigned *dy_amax, *x_amax;
+    int dy_amax_n, x_amax_n;
 };
 
-// scale / inverse scale of an operand from its amax word (wave-uniform)
-__device__ __forceinline__ void wgrad_scales(const unsigned *amax, float &scale, float &unscale) {
-    const int se = rn_f16_scale_exp(__builtin_amdgcn_readfirstlane(*amax));
+// scale / inverse scale of an operand from its amax words (all 64 lanes of the wave active; the result is wave-uniform)
+__device__ __forceinline__ void wgrad_scales(const unsigned *amax, int count, float &scale, float &unscale) {
+    unsigned b = 0;
+    for (int i = threadIdx.x & 63; i < count; i += 64) { const unsigned w = amax[i] & 0x7fffffffu; b = w > b ? w : b; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)b, off, 64); b = o > b ? o : b; }
+    const int se = rn_f16_scale_exp(__builtin_amdgcn_readfirstlane(b));
     scale = rn_exp_to_float(se);
     unscale = rn_exp_to_float(254 - se);
 }
@@ -207,8 +214,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
     float s_a = 1.f, s_b = 1.f, us = 1.f;                    // HALF: operand scales and the product of their inverses
     if constexpr (HALF) {
         float ua, ub;
-        wgrad_scales(p.dy_amax, s_a, ua);
-        wgrad_scales(p.x_amax, s_b, ub);
+        wgrad_scales(p.dy_amax, p.dy_amax_n, s_a, ua);
+        wgrad_scales(p.x_amax, p.x_amax_n, s_b, ub);
         us = ua * ub;
     }
 
@@ -445,8 +452,8 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
     float s_a = 1.f, s_b = 1.f, us = 1.f;                    // HALF: operand scales and the product of their inverses
     if constexpr (HALF) {
         float ua, ub;
-        wgrad_scales(p.dy_amax, s_a, ua);
-        wgrad_scales(p.x_amax, s_b, ub);
+        wgrad_scales(p.dy_amax, p.dy_amax_n, s_a, ua);
+        wgrad_scales(p.x_amax, p.x_amax_n, s_b, ub);
         us = ua * ub;
     }
     // split the registers of one K-step and store the planes of buffer `buf`
@@ -620,25 +627,25 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
                         int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                         int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                         int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes,
-                        const void *dy_amax = nullptr, const void *x_amax = nullptr);
+                        const void *dy_amax = nullptr, int dy_amax_n = 0, const void *x_amax = nullptr, int x_amax_n = 0);
 
 extern "C" int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                                      int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                                      int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                                     int in_relu, const void *dy_amax, const void *x_amax, void *stream) {
+                                     int in_relu, const void *dy_amax, int dy_amax_n, const void *x_amax, int x_amax_n, void *stream) {
     return wgrad_launch(dy, ldy, x, dw, colsum, nbatch, dy_bstride, x_bstride, dw_bstride, colsum_batch, N, Hi, Wi, Cin, Ho, Wo, Cout,
-                        kh, kw, stride, pad, in_relu, stream, false, nullptr, 0, nullptr, dy_amax, x_amax);
+                        kh, kw, stride, pad, in_relu, stream, false, nullptr, 0, nullptr, dy_amax, dy_amax_n, x_amax, x_amax_n);
 }
 
 // Fixed-order reduction (RN_OPT_DETERMINISTIC): same kernel, K slices store into slabs of `workspace`, one ordered combine.
 extern "C" int rn_conv_wgrad_batched_det(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                                          int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                                          int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
-                                         int in_relu, const void *dy_amax, const void *x_amax, void *workspace, int64_t workspace_bytes,
-                                         void *stream) {
+                                         int in_relu, const void *dy_amax, int dy_amax_n, const void *x_amax, int x_amax_n,
+                                         void *workspace, int64_t workspace_bytes, void *stream) {
     if (workspace == nullptr) return RN_EINVAL;
     return wgrad_launch(dy, ldy, x, dw, colsum, nbatch, dy_bstride, x_bstride, dw_bstride, colsum_batch, N, Hi, Wi, Cin, Ho, Wo, Cout,
-                        kh, kw, stride, pad, in_relu, stream, true, workspace, workspace_bytes, nullptr, dy_amax, x_amax);
+                        kh, kw, stride, pad, in_relu, stream, true, workspace, workspace_bytes, nullptr, dy_amax, dy_amax_n, x_amax, x_amax_n);
 }
 
 // Bytes of workspace rn_conv_wgrad_batched_det needs for this problem (slices x (result image + Cout column sums)).
@@ -654,7 +661,7 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
                         int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi,
                         int Wi, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                         int in_relu, void *stream, bool det, void *workspace, int64_t workspace_bytes, int64_t *need_bytes,
-                        const void *dy_amax, const void *x_amax) {
+                        const void *dy_amax, int dy_amax_n, const void *x_amax, int x_amax_n) {
     if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin < 4 || (Cin & 3) || (ldy & 3) || ldy < Cout)
         return RN_EINVAL;
     if (nbatch < 1 || nbatch > 4096 || dy_bstride < 0 || x_bstride < 0 || dw_bstride < 0 || colsum_batch < 0 || colsum_batch >= nbatch)
@@ -716,9 +723,11 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
     // on the mid-size layers, equal on the largest; the 64 x 256 tile does not fit twice at 32).
     const bool split = rn_get_fp32_mfma() != RN_FP32_NATIVE;
     // RN_FP32_SPLIT3 with both amax words: the fp16 two-term kernels; without them (a caller of the plain entry point) the three-term ones
-    const bool half = rn_get_fp32_mfma() == RN_FP32_SPLIT3 && dy_amax != nullptr && x_amax != nullptr;
+    const bool half = rn_get_fp32_mfma() == RN_FP32_SPLIT3 && dy_amax != nullptr && x_amax != nullptr && dy_amax_n > 0 && x_amax_n > 0;
     a.dy_amax = reinterpret_cast<const unsigned *>(dy_amax);
     a.x_amax = reinterpret_cast<const unsigned *>(x_amax);
+    a.dy_amax_n = dy_amax_n;
+    a.x_amax_n = x_amax_n;
 #define RN_WGRAD_LAUNCH(WM_, WN_)                                                                                        \
     do {                                                                                                                 \
         if (half) {                                                                                                      \
@@ -757,5 +766,5 @@ extern "C" int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw
                              int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
                              void *stream) {
     return rn_conv_wgrad_batched(dy, ldy, x, dw, colsum, 1, 0, 0, 0, 0, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
-                                 in_relu, nullptr, nullptr, stream);
+                                 in_relu, nullptr, 0, nullptr, 0, stream);
 }

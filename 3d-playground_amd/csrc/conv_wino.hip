@@ -22,6 +22,7 @@
 // A thread owns one tile x 4 channels: 36 16-byte loads (a wave reads one pixel's whole channel vector per load: 1 KiB
 // contiguous), the two 1-D transforms in registers, 36 (16) 16-byte stores.
 #include "common.h"
+#include "mfma_split.h"
 
 __device__ __forceinline__ float4 f4(float s) { return make_float4(s, s, s, s); }
 // M (the GEMM's result: written once, read once by the output transform, larger than the caches) is read with the nontemporal
@@ -68,7 +69,26 @@ struct WinoTable {
     const float *add[RN_MAX_GROUP];
     const float *mask[RN_MAX_GROUP];
     unsigned *sign[RN_MAX_GROUP];                // output transform: sign bits of y (common.h: rn_sign_store), or NULL
+    unsigned *amax[RN_MAX_GROUP];                // amax words, one per image (mfma_split.h; RN_FP32_SPLIT3), or NULL: of src (input
+                                                 // transforms, read) / of dst (output transform, raised)
 };
+
+// Amax words of a Winograd-domain tensor (RN_FP32_SPLIT3).  The transforms are linear maps of bounded gain -- |B^T d B| <= 100 max|d|
+// (< 2^7), |A dy A^T| <= 225 max|dy| (< 2^8): the absolute row sums of B^T are at most 10, of A at most 15 -- so the word of a tile's row
+// of V / Z follows from its IMAGE's word of the untransformed tensor by adding the gain to the exponent: no reduction, no atomics, and
+// an image's scales still depend on that image alone.  The GEMM of the forward / data gradient takes the ROW words (rn_conv_desc.x_amax
+// with strides (0, 1)); the weight gradient, which reduces over the tiles of all images, takes the one TENSOR word (the largest of all).
+#define WINO_GAIN_BT 7
+#define WINO_GAIN_A 8
+__device__ __forceinline__ void wino_tensor_word(const WinoTable &g, unsigned *tensor_amax, int gain) {
+    if (tensor_amax == nullptr || blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned b = 0;
+#pragma unroll
+    for (int i = 0; i < RN_MAX_GROUP; ++i)
+        if (i < g.n && g.amax[i] != nullptr)
+            for (int n = 0; n < g.p[i].N; ++n) { const unsigned w = g.amax[i][n] & 0x7fffffffu; b = w > b ? w : b; }
+    atomicMax(tensor_amax, rn_amax_gain(b, gain));           // (several launches may fill one tensor: the caller zeroes the word)
+}
 __device__ __forceinline__ int wino_locate(const WinoTable &g, int64_t gt, int64_t &local) {
     int q = 0;
 #pragma unroll
@@ -87,7 +107,9 @@ __device__ __forceinline__ int wino_locate(const WinoTable &g, int64_t gt, int64
     _Pragma("unroll") for (int i_ = 1; i_ < RN_MAX_GROUP; ++i_) \
         if (q == i_) { pr = g.p[i_]; EXTRA }
 
-__global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *__restrict__ V, int C, int64_t t0, int64_t Tpad) {
+__global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *__restrict__ V, int C, int64_t t0, int64_t Tpad,
+                                                      unsigned *__restrict__ row_amax, unsigned *__restrict__ tensor_amax) {
+    wino_tensor_word(g, tensor_amax, WINO_GAIN_BT);
     const int cq = C >> 2;
     // 6x6 patches of neighbouring tiles overlap by two pixels: every input pixel is read by 2.25 tiles.  With the plain id the
     // tiles of one image row are spread over all eight XCDs and each L2 fetched its own copy of the shared pixels (PMC: 2.06x
@@ -99,13 +121,15 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *
     int64_t tile;
     const int q = wino_locate(g, gt, tile);
     const float *x = g.src[0];
-    WINO_SELECT(q, g, pr, x = g.src[i_];)
+    const unsigned *xw = g.amax[0];
+    WINO_SELECT(q, g, pr, x = g.src[i_]; xw = g.amax[i_];)
     const int H = pr.H, W = pr.W, TW = pr.TW;
     const int n = (int)(tile / (pr.TH * TW));
     const int r = (int)(tile - (int64_t)n * pr.TH * TW);
     const int th = r / TW, tw = r - th * TW;
     const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
     const float *xb = x + (int64_t)n * H * W * C + c4;
+    if (row_amax != nullptr && c4 == 0) row_amax[t0 + gt] = xw != nullptr ? rn_amax_gain(xw[n], WINO_GAIN_BT) : 0u;
     float4 t[6][6];                                           // t[i][j] = (B^T d)[i][j]: columns first
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -150,8 +174,9 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
     const int q = wino_locate(g, gt, tile);
     float *y = g.dst[0];
     const float *add = g.add[0], *mask = g.mask[0];
-    unsigned *sign = g.sign[0];
-    WINO_SELECT(q, g, pr, y = g.dst[i_]; add = g.add[i_]; mask = g.mask[i_]; sign = g.sign[i_];)
+    unsigned *sign = g.sign[0], *yam = g.amax[0];
+    WINO_SELECT(q, g, pr, y = g.dst[i_]; add = g.add[i_]; mask = g.mask[i_]; sign = g.sign[i_]; yam = g.amax[i_];)
+    float am = 0.f;                                           // largest |y| this thread stores (the result's amax word of image n)
     const bool mbits = (mask_mode & RN_MASK_BITS) != 0;
     mask_mode &= 3;
     const int H = pr.H, W = pr.W, TW = pr.TW;
@@ -201,8 +226,10 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
             }
             *reinterpret_cast<float4 *>(y + yoff) = make_float4(v[0], v[1], v[2], v[3]);
             if (sign != nullptr) rn_sign_store(sign, off, v[0], v[1], v[2], v[3]);      // (dense geometry: the 8 lanes of a word share the pixel)
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     }
+    if (yam != nullptr) rn_amax_lane(yam, n, am);
 }
 
 // ---------------------------------------------------------------------------------------------- weight transform
@@ -266,7 +293,9 @@ __device__ __forceinline__ void a6(const float4 v[4], float4 o[6]) {
     o[5] = v[3];
 }
 
-__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoTable g, float *__restrict__ Z, int C, int64_t t0, int64_t Tpad) {
+__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoTable g, float *__restrict__ Z, int C, int64_t t0, int64_t Tpad,
+                                                      unsigned *__restrict__ tensor_amax) {
+    wino_tensor_word(g, tensor_amax, WINO_GAIN_A);
     const int cq = C >> 2;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t gt = id / cq;
@@ -309,7 +338,9 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoTable g, float *
 // their halo) and Z = A dy A^T (the weight gradient's: the patch's inner 4x4).  The backward of a Winograd layer needs both and
 // read dy twice; the patch a thread has loaded for V holds the pixels of Z.
 __global__ __launch_bounds__(256) void wino_in_both_kernel(const WinoTable g, float *__restrict__ V, float *__restrict__ Z, int C,
-                                                           int64_t t0, int64_t Tpad) {
+                                                           int64_t t0, int64_t Tpad, unsigned *__restrict__ v_row_amax,
+                                                           unsigned *__restrict__ z_tensor_amax) {
+    wino_tensor_word(g, z_tensor_amax, WINO_GAIN_A);
     const int cq = C >> 2;
     const int64_t id = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int64_t gt = id / cq;
@@ -318,13 +349,15 @@ __global__ __launch_bounds__(256) void wino_in_both_kernel(const WinoTable g, fl
     int64_t tile;
     const int q = wino_locate(g, gt, tile);
     const float *x = g.src[0];
-    WINO_SELECT(q, g, pr, x = g.src[i_];)
+    const unsigned *xw = g.amax[0];
+    WINO_SELECT(q, g, pr, x = g.src[i_]; xw = g.amax[i_];)
     const int H = pr.H, W = pr.W, TW = pr.TW;
     const int n = (int)(tile / (pr.TH * TW));
     const int r = (int)(tile - (int64_t)n * pr.TH * TW);
     const int th = r / TW, tw = r - th * TW;
     const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
     const float *xb = x + (int64_t)n * H * W * C + c4;
+    if (v_row_amax != nullptr && c4 == 0) v_row_amax[t0 + gt] = xw != nullptr ? rn_amax_gain(xw[n], WINO_GAIN_BT) : 0u;
     float4 t[6][6];                                           // t[i][j] = (B^T d)[i][j]
     float4 tz[6][4];                                          // tz[a][j] = (A dy)[a][j], dy = the patch's rows / columns 1..4
 #pragma unroll
@@ -406,12 +439,13 @@ static int wino_table(const rn_wino_group *g, WinoTable &t) {
         t.tile_end[i] = end;
         t.src[i] = g->src[k]; t.dst[i] = g->dst[k]; t.add[i] = g->add[k]; t.mask[i] = g->mask[k];
         t.sign[i] = reinterpret_cast<unsigned *>(g->sign[k]);
+        t.amax[i] = reinterpret_cast<unsigned *>(g->amax[k]);
     }
     return RN_OK;
 }
 
 extern "C" int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form,
-                                   void *stream) {
+                                   void *row_amax, void *tensor_amax, void *stream) {
     WinoTable t;
     const int rc = wino_table(g, t);
     if (rc) return rc;
@@ -419,13 +453,17 @@ extern "C" int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int6
     for (int i = 0; i < t.n; ++i)
         if (!t.src[i]) return RN_EINVAL;
     const dim3 grid(rn_blocks(t.tile_end[t.n - 1] * (C >> 2), 256));
-    if (dy_form) hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad);
-    else hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad);
+    if (dy_form && row_amax != nullptr) return RN_EINVAL;    // A dy A^T feeds the weight gradient only: the tensor word
+    if (dy_form) hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad,
+                                    reinterpret_cast<unsigned *>(tensor_amax));
+    else hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, (hipStream_t)stream, t, V, C, tile_offset, Tpad,
+                            reinterpret_cast<unsigned *>(row_amax), reinterpret_cast<unsigned *>(tensor_amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
 
-extern "C" int rn_wino_input_both_group(const rn_wino_group *g, float *V, float *Z, int C, int64_t tile_offset, int64_t Tpad, void *stream) {
+extern "C" int rn_wino_input_both_group(const rn_wino_group *g, float *V, float *Z, int C, int64_t tile_offset, int64_t Tpad,
+                                        void *v_row_amax, void *z_tensor_amax, void *stream) {
     WinoTable t;
     const int rc = wino_table(g, t);
     if (rc) return rc;
@@ -433,7 +471,7 @@ extern "C" int rn_wino_input_both_group(const rn_wino_group *g, float *V, float 
     for (int i = 0; i < t.n; ++i)
         if (!t.src[i]) return RN_EINVAL;
     hipLaunchKernelGGL(wino_in_both_kernel, dim3(rn_blocks(t.tile_end[t.n - 1] * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, t,
-                       V, Z, C, tile_offset, Tpad);
+                       V, Z, C, tile_offset, Tpad, reinterpret_cast<unsigned *>(v_row_amax), reinterpret_cast<unsigned *>(z_tensor_amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -467,11 +505,11 @@ static rn_wino_group wino_single(const float *src, float *dst, const float *add,
 extern "C" int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad,
                              void *stream) {
     const rn_wino_group g = wino_single(x, nullptr, nullptr, nullptr, N, H, W);
-    return rn_wino_input_group(&g, V, C, tile_offset, Tpad, 0, stream);
+    return rn_wino_input_group(&g, V, C, tile_offset, Tpad, 0, nullptr, nullptr, stream);
 }
 extern "C" int rn_wino_dy(const float *dy, float *Z, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream) {
     const rn_wino_group g = wino_single(dy, nullptr, nullptr, nullptr, N, H, W);
-    return rn_wino_input_group(&g, Z, C, tile_offset, Tpad, 1, stream);
+    return rn_wino_input_group(&g, Z, C, tile_offset, Tpad, 1, nullptr, nullptr, stream);
 }
 extern "C" int rn_wino_output(const float *M, float *y, int N, int H, int W, int Cout, int64_t tile_offset, int64_t Tpad,
                               const float *scale, const float *shift, const float *add, const float *mask, int mask_mode,

@@ -164,6 +164,11 @@ __global__ __launch_bounds__(256) void prep_batched_kernel(const rn_prep_job *__
         j.bn_rstd[i] = rs;
         return;
     }
+    if (j.kind == 5) {                                       // fp16 pre-split form (RN_FP32_SPLIT3): a block = 4 rows, one wave each; bn_scale <- inverse row scales
+        const int64_t row = (int64_t)c.y * 4 + (threadIdx.x >> 6);
+        if (row < j.rows) split_row_f16(j.src, j.dst, j.bn_scale, row, j.Kpad, threadIdx.x & 63);
+        return;
+    }
     if (j.kind == 4) {                                       // pre-split form of an already packed fp32 buffer (mfma_split.h): 8 values per thread
         if (i < (int64_t)j.rows * j.Kpad / 8) split_store_chunk(j.src, j.dst, i);
         return;

@@ -199,21 +199,52 @@ __device__ __forceinline__ void split_store_chunk_h(const float *__restrict__ sr
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16((A).h, (B).h, ACC, 0, 0, 0);         \
     } while (0)
 
-// amax word of a tensor: the largest |element| as fp32 bits (monotone as unsigned), accumulated by atomic max at device scope.
-// Producers keep a running maximum per lane, reduce it over the wave and commit it once; a wave whose maximum does not raise the
-// word's EXPONENT (all a consumer uses) skips the atomic -- after the first few waves of a launch almost all do.
+// amax words of a tensor: per IMAGE the largest |element| as fp32 bits (monotone as unsigned), accumulated by atomic max at device
+// scope.  Per image, not per tensor, so that the scales -- and with them every bit of an image's result -- do not depend on which other
+// images share the launch (tests/test_gpu_batch8.py pins that).  A consumer uses only a word's EXPONENT (rn_f16_scale_exp), so a
+// producer whose maximum does not raise the exponent skips the atomic -- after the first few waves of a launch almost all do; what a
+// word holds at the end is the exact exponent with some lower bound of the mantissa: deterministic where it matters.
 __device__ __forceinline__ float rn_wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
-__device__ __forceinline__ void rn_amax_commit(void *slot, float lane_max) {
-    if (slot == nullptr) return;
-    unsigned *p = reinterpret_cast<unsigned *>(slot);
+// one lane's maximum into word n (any subset of the wave)
+__device__ __forceinline__ void rn_amax_lane(void *words, int64_t n, float v) {
+    unsigned *p = reinterpret_cast<unsigned *>(words) + n;
+    const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
     const unsigned seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // NaN-propagating maximum of the bit patterns: an integer max over |x| bits orders NaN above infinity
-    unsigned b = __builtin_bit_cast(unsigned, lane_max) & 0x7fffffffu;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)b, off, 64); b = o > b ? o : b; }
+    if ((b >> 23) > (seen >> 23)) atomicMax(p, b);
+}
+// a whole wave's maximum into word n (all 64 lanes active, n wave-uniform)
+__device__ __forceinline__ void rn_amax_commit(void *words, int64_t n, float lane_max) {
+    if (words == nullptr) return;
+    unsigned *p = reinterpret_cast<unsigned *>(words) + n;
+    const unsigned seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned b = __builtin_bit_cast(unsigned, rn_wave_max(lane_max)) & 0x7fffffffu;
     if ((threadIdx.x & 63) == 0 && (b >> 23) > (seen >> 23)) atomicMax(p, b);
+}
+// the word of a tensor derived from another's by a linear map whose gain is below 2^gain_log2 (the Winograd transforms): exponent + gain
+__host__ __device__ __forceinline__ unsigned rn_amax_gain(unsigned word, int gain_log2) {
+    const int e = (int)((word >> 23) & 0xffu);
+    if (e == 0) return 0u;
+    const int g = e + gain_log2 > 254 ? 254 : e + gain_log2;
+    return ((unsigned)g << 23) | 0x7fffffu;
+}
+
+// One weight row of the fp16 pre-split form, by one wave: the row's largest magnitude (one pass, wave maximum), its power-of-two scale,
+// then the hi / lo terms of every 8-value chunk (rn_split_weights_f16; rn_prep_batched job kind 5).
+__device__ __forceinline__ void split_row_f16(const float *__restrict__ src, void *__restrict__ dst, float *__restrict__ unscale,
+                                              int64_t row, int Kpad, int lane) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(src + row * Kpad);
+    float am = 0.f;
+    for (int i = lane; i < Kpad / 4; i += 64) {
+        const float4 q = r4[i];
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+    const int se = rn_f16_scale_exp(__builtin_bit_cast(unsigned, rn_wave_max(am)));
+    if (lane == 0) unscale[row] = rn_exp_to_float(254 - se);
+    const float sc = rn_exp_to_float(se);
+    const int64_t c0 = row * (Kpad / 8);
+    for (int i = lane; i < Kpad / 8; i += 64) split_store_chunk_h(src, dst, c0 + i, sc);
 }

@@ -26,7 +26,7 @@ SIGNATURES = {
     "rn_fp32_split_min_k": (c_i32, []),
     "rn_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "rn_split_weights_f16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
-    "rn_amax": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    "rn_amax": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "rn_anchor_count": (c_i64, [c_i32, c_i32]),
     "rn_anchor_base_boxes": (None, [c_vp]),
     "rn_anchors_fwd": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
@@ -75,7 +75,7 @@ class ConvDesc(ctypes.Structure):
                 ("add2_mode", c_i32), ("Ha2", c_i32), ("Wa2", c_i32), ("add2_batch_stride", c_i64),
                 ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("add_batch_stride", c_i64),
                 ("w_batch_stride", c_i64), ("w_format", c_i32), ("sign_out", c_vp),
-                ("x_amax", c_vp), ("y_amax", c_vp), ("w_unscale", c_vp)]
+                ("x_amax", c_vp), ("y_amax", c_vp), ("w_unscale", c_vp), ("x_amax_img_stride", c_i32), ("x_amax_row_stride", c_i32)]
 
 
 RN_MAX_GROUP = 5
@@ -107,14 +107,14 @@ class WinoGroup(ctypes.Structure):
     """rn_wino_group of include/retinanet_mi355x.h."""
     _fields_ = [("n", c_i32), ("N", c_i32 * RN_MAX_GROUP), ("H", c_i32 * RN_MAX_GROUP), ("W", c_i32 * RN_MAX_GROUP),
                 ("src", c_vp * RN_MAX_GROUP), ("dst", c_vp * RN_MAX_GROUP), ("add", c_vp * RN_MAX_GROUP),
-                ("mask", c_vp * RN_MAX_GROUP), ("sign", c_vp * RN_MAX_GROUP)]
+                ("mask", c_vp * RN_MAX_GROUP), ("sign", c_vp * RN_MAX_GROUP), ("amax", c_vp * RN_MAX_GROUP)]
 
 
 SIGNATURES.update({
     "rn_unpack_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
     "rn_prep_batched": (c_i32, [c_vp, c_vp, c_i32, c_vp]),
-    "rn_wino_input_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
-    "rn_wino_input_both_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "rn_wino_input_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "rn_wino_input_both_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "rn_wino_output_group": (c_i32, [ctypes.POINTER(WinoGroup), c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "rn_conv_igemm_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_vp, c_vp, c_vp]),
     "rn_conv_igemm": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -139,8 +139,8 @@ SIGNATURES.update({
     "rn_wino_weights": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rn_wino_dy": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "rn_wino_dw": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
-    "rn_conv_wgrad_batched": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_vp, c_vp]),
-    "rn_conv_wgrad_batched_det": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rn_conv_wgrad_batched": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "rn_conv_wgrad_batched_det": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32] + [c_i32] * 12 + [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "rn_conv_wgrad_det_workspace_bytes": (c_i64, [c_i32, c_i32, c_i64] + [c_i32] * 9),
     "rn_f32_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "rn_bf16_to_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),

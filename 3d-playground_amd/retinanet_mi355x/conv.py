@@ -75,13 +75,15 @@ def _mask_operand(mask, mask_mode):
 
 def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=0, add_hw=(0, 0), mask=None,
                mask_mode=2, act=ACT_NONE, y_batch_stride=None, add_batch_stride=None, in_relu=False, flops=0.0,
-               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False, bf16_products=False, x_amax=None, amax=None):
+               out_map=None, add2=None, w_batch_stride=0, kind=None, sign=False, bf16_products=False, x_amax=None, x_amax_rows=False,
+               amax=None):
     """Launch rn_conv_igemm.  x [N,Hi,Wi,Cin]; y a tensor whose storage receives [N,Ho,Wo,Cout] at batch stride
     y_batch_stride; geom = (Ho, Wo, Cout, kh, kw, a, b, p, div_shift) with p an int or (p_rows, p_cols).
     out_map = (os, oo_h, oo_w, Hy, Wy) stores output pixel (oh,ow) at (oh*os+oo_h, ow*os+oo_w) of a [N,Hy,Wy,Cout]
     tensor.  add2: [N,Ha2,Wa2,Cout] added at even stored positions (1x1 stride-2 shortcut gradient).
-    split3 mode: x_amax = the amax word of x when the caller knows it (default: amax_word(x)); a dense result gets an amax word of its own
-    (y._rn_amax), `amax` = a word several launches that fill ONE tensor share (the parity classes of a stride-2 data gradient)."""
+    split3 mode: x_amax = the amax words of x when the caller holds them (default: amax_words(x), one per image; x_amax_rows: one per GEMM
+    row instead -- the Winograd stage); a dense result gets words of its own (y._rn_amax), `amax` = the words several launches that fill
+    ONE tensor share (the parity classes of a stride-2 data gradient)."""
     lib = _hip.load()
     N, Hi, Wi, Cin = x.shape
     Ho, Wo, Cout, kh, kw, a, b, p, ds = geom
@@ -99,7 +101,7 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
     d.sign_out = None if bits is None else bits.data_ptr()
     yam = None
     if want_amax() and not w_batch_stride and y_batch_stride is None and (out_map is None or amax is not None):
-        yam = amax if amax is not None else amax_slot(y.device)
+        yam = amax if amax is not None else amax_slot(y.device, N)
         d.y_amax = yam.data_ptr()
     if kind is None:
         kind = "conv_igemm_4x1" if Cout <= 64 else "conv_igemm_2x2"
@@ -117,7 +119,8 @@ def conv_igemm(x, w_packed, y, geom, scale=None, shift=None, add=None, add_mode=
         return y
     wptr, d.w_format, d.w_unscale = _w_operand(w_packed, d)
     if d.w_format == 3:
-        d.x_amax = (x_amax if x_amax is not None else amax_word(x)).data_ptr()
+        d.x_amax = (x_amax if x_amax is not None else amax_words(x)).data_ptr()
+        d.x_amax_img_stride, d.x_amax_row_stride = (0, 1) if x_amax_rows else (1, 0)
     if bf16_products:                      # the fp32 stem of the bf16 / fp8 engines: products from the first bf16 terms (w_format 2)
         ws = getattr(w_packed, "_rn_split", None)
         if ws is None:
@@ -241,38 +244,40 @@ def _w_operand(w_packed, d=None):
     return w_packed.data_ptr(), 0, None
 
 
-# ---- amax words (split3; include/retinanet_mi355x.h: rn_conv_desc.x_amax / y_amax).  A producer launched with an amax word leaves the
-# exponent of its result's largest magnitude in it; the tensor object carries (word, tensor._version at that time) as ._rn_amax.  A
-# consumer takes the word if the version still matches (an in-place torch operation since then invalidates it; this module's own in-place
-# kernels drop the attribute), else one rn_amax pass computes it.  Words are views of zeroed chunks that are never reused.
+# ---- amax words (split3; include/retinanet_mi355x.h: rn_conv_desc.x_amax / y_amax): ONE WORD PER IMAGE of a [N, ...] tensor.  A producer
+# launched with amax words leaves in word n the exponent of the largest magnitude it stored in image n; the tensor object carries
+# (words, tensor._version at that time) as ._rn_amax.  A consumer takes the words if the version still matches (an in-place torch
+# operation since then invalidates them; this module's own in-place kernels drop the attribute), else one rn_amax pass computes them.
+# Words are views of zeroed chunks that are never reused.  Per image, so that an image's scales -- and every bit of its results -- do not
+# depend on what else is in the batch.
 _AMAX_CHUNK = {}
 
 
-def amax_slot(device):
-    """A fresh zeroed amax word (int32 tensor of one element) on `device`."""
+def amax_slot(device, n=1):
+    """n fresh zeroed amax words (int32 tensor) on `device`."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     c = _AMAX_CHUNK.get(key)
-    if c is None or c[1] >= c[0].numel():
-        c = _AMAX_CHUNK[key] = [torch.zeros(1024, dtype=torch.int32, device=device), 0]
-    c[1] += 1
-    return c[0][c[1] - 1:c[1]]
+    if c is None or c[1] + n > c[0].numel():
+        c = _AMAX_CHUNK[key] = [torch.zeros(max(4096, n), dtype=torch.int32, device=device), 0]
+    c[1] += n
+    return c[0][c[1] - n:c[1]]
 
 
-def amax_attach(t, slot):
-    t._rn_amax = (slot, t._version)
-    return slot
+def amax_attach(t, words):
+    t._rn_amax = (words, t._version)
+    return words
 
 
-def amax_word(t):
-    """The amax word of a dense fp32 tensor: its producer's (see above) or computed now (cached on the tensor object)."""
+def amax_words(t):
+    """The amax words [N] of a dense fp32 tensor [N, ...]: its producer's (see above) or computed now (cached on the tensor object)."""
     a = getattr(t, "_rn_amax", None)
-    if a is not None and a[1] == t._version:
+    if a is not None and a[1] == t._version and a[0].numel() == t.shape[0]:
         return a[0]
     assert t.is_contiguous() and t.dtype == torch.float32
-    slot = amax_slot(t.device)
+    words = amax_slot(t.device, t.shape[0])
     if t.numel():
-        _hip.check(_hip.load().rn_amax(t.data_ptr(), t.numel(), slot.data_ptr(), _hip.stream()), "rn_amax")
-    return amax_attach(t, slot)
+        _hip.check(_hip.load().rn_amax(t.data_ptr(), t.numel() // t.shape[0], t.shape[0], words.data_ptr(), _hip.stream()), "rn_amax")
+    return amax_attach(t, words)
 
 
 def amax_drop(t):
@@ -308,16 +313,15 @@ def set_deterministic(on=True):
 def _wgrad_call(lib, dev, dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, geom, amax=(None, None)):
     """rn_conv_wgrad_batched, or its fixed-order form with a slab workspace when the deterministic option is on.
     geom = (N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu); amax = the amax words of (dy, x) (split3 mode) or Nones."""
-    am = (_hip.ptr(amax[0]), _hip.ptr(amax[1]))
+    am = (_hip.ptr(amax[0]), 0 if amax[0] is None else amax[0].numel(), _hip.ptr(amax[1]), 0 if amax[1] is None else amax[1].numel())
     if not lib.rn_get_option(OPT_DETERMINISTIC):
-        return lib.rn_conv_wgrad_batched(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, am[0], am[1],
-                                         _hip.stream())
+        return lib.rn_conv_wgrad_batched(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, *am, _hip.stream())
     N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw = geom[:9]
     nb = lib.rn_conv_wgrad_det_workspace_bytes(ldy, nbatch, dw_bs, N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw)
     if nb < 0:
         return 1
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)      # caching allocator: same stream, reused by the next layer
-    return lib.rn_conv_wgrad_batched_det(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, am[0], am[1],
+    return lib.rn_conv_wgrad_batched_det(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, *am,
                                          ws.data_ptr(), nb, _hip.stream())
 
 
@@ -338,9 +342,10 @@ def wino_weights(weight, mode=0, scale=None):
 _WINO_WS = {}
 
 
-def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None, mask_bits=False, signs=None):
+def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None, mask_bits=False, signs=None, amaxs=None):
     """rn_wino_group for problems shaped like xs ([N,H,W,.]); at most RN_MAX_GROUP of them.  mask_bits: the masks' sign-bit words
-    (tensor._rn_sign) instead of the fp32 tensors; signs: per problem the words that receive the result's sign bits, or None."""
+    (tensor._rn_sign) instead of the fp32 tensors; signs: per problem the words that receive the result's sign bits, or None;
+    amaxs: per problem the amax words (of the source for the input transforms, of the result for the output transform), or None."""
     g = _hip.WinoGroup()
     g.n = len(xs)
     for i, x in enumerate(xs):
@@ -353,31 +358,27 @@ def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None, mask_bits=False
         else:
             g.mask[i] = masks[i]._rn_sign.data_ptr() if mask_bits else masks[i].data_ptr()
         g.sign[i] = None if signs is None or signs[i] is None else signs[i].data_ptr()
+        g.amax[i] = None if amaxs is None or amaxs[i] is None else amaxs[i].data_ptr()
     return g
 
 
-def _wino_transform_in(xs, V, C, Tpad, dy_form):
-    """Input-side transform of every problem of xs into V, RN_MAX_GROUP problems per launch."""
+def _wino_transform_in(xs, V, C, Tpad, dy_form, want_rows=False, want_tensor=False):
+    """Input-side transform of every problem of xs into V, RN_MAX_GROUP problems per launch.  split3 (want_rows / want_tensor): also the
+    transformed tensor's amax words, derived from the sources' per-image words -- returns (row words [Tpad] or None, tensor word or None)."""
     lib = _hip.load()
     off = 0
+    am = want_amax() and (want_rows or want_tensor)
+    rows = torch.zeros(Tpad, dtype=torch.int32, device=V.device) if am and want_rows else None
+    tword = amax_slot(V.device) if am and want_tensor else None
     for k in range(0, len(xs), _hip.RN_MAX_GROUP):
         part = xs[k:k + _hip.RN_MAX_GROUP]
         t = sum(x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in part)
-        g = _wino_group(part, srcs=part)
+        g = _wino_group(part, srcs=part, amaxs=[amax_words(x) for x in part] if am else None)
         nb = 4.0 * (sum(x.numel() for x in part) + 36 * t * C)
         _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_group(
-            ctypes.byref(g), V.data_ptr(), C, off, Tpad, dy_form, _hip.stream())), "rn_wino_input_group")
+            ctypes.byref(g), V.data_ptr(), C, off, Tpad, dy_form, _hip.ptr(rows), _hip.ptr(tword), _hip.stream())), "rn_wino_input_group")
         off += t
-
-
-def _wino_amax(V, Tpad, T, C):
-    """split3: the amax word of a Winograd-domain tensor [36][Tpad][C] whose rows past T are scratch: zeroed, then one rn_amax pass.
-    (Fallback for transforms that did not leave the word themselves.)"""
-    if T < Tpad:
-        V[:36 * Tpad * C].view(36, Tpad, C)[:, T:].zero_()
-    slot = amax_slot(V.device)
-    _hip.check(_hip.load().rn_amax(V.data_ptr(), 36 * Tpad * C, slot.data_ptr(), _hip.stream()), "rn_amax")
-    return slot
+    return rows, tword
 
 
 def _wino_workspace(device, floats_v, floats_m):
@@ -418,19 +419,20 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     elif keep_v:                                     # the caller keeps B^T d B of the inputs for the weight gradient
         V = torch.empty(36 * Tpad * C, dtype=torch.float32, device=dev)
     assert all(x.is_contiguous() for x in xs)
-    v_am = None
-    if reuse:                                        # a kept / handed-over V comes with its amax word (split3), if it had one
+    v_am = (None, None)                              # split3: V's amax words (one per tile row for this GEMM, one for the weight gradient)
+    if reuse:                                        # a kept / handed-over V comes with them
         src = V_ready if ready else V_in
-        v_am = src[2] if len(src) > 2 else None
+        v_am = src[2] if len(src) > 2 and src[2] is not None else (None, None)
     else:
-        _wino_transform_in(xs, V, C, Tpad, 0)
+        v_am = _wino_transform_in(xs, V, C, Tpad, 0, want_rows=True, want_tensor=keep_v)
     # rows past T hold whatever the scratch tensor held: they produce rows of M nobody reads
     Vv = V[:36 * Tpad * C].view(36, 1, Tpad, C)
     Mv = M[:36 * Tpad * cout].view(36, 1, Tpad, cout)
-    if v_am is None and getattr(U, "_rn_split16", None) is not None and get_fp32_mfma() == "split3":
-        v_am = _wino_amax(V, Tpad, T, C)
-    conv_igemm(Vv, _carry_split(U, U.view(36 * cout, U.shape[2])), Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0),
-               flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2], x_amax=v_am)    # executed FLOPs: same kernel, same family
+    Uv = _carry_split(U, U.view(36 * cout, U.shape[2]))
+    if want_amax() and v_am[0] is None:              # a V somebody else made without words: the three-term kernels for this launch
+        Uv = U.view(36 * cout, U.shape[2])
+    conv_igemm(Vv, Uv, Mv, (1, Tpad, cout, 1, 1, 1, 1, 0, 0), flops=2.0 * 36 * T * cout * C, w_batch_stride=cout * U.shape[2],
+               x_amax=v_am[0], x_amax_rows=True)    # executed FLOPs: same kernel, same family
     if outs is None:
         outs = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in xs]
     off = 0
@@ -443,13 +445,17 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
         # sign bits: read instead of the fp32 masks when every mask of the launch carries them; written for dense results on request
         mbits = has_mask and BITMASKS and all(getattr(m, "_rn_sign", None) is not None for m in pm)
         signs = [_sign_words(o, sign and not y_batch_stride) for o in outs[sl]]
-        g = _wino_group(part, dsts=outs[sl], adds=pa, masks=pm, mask_bits=mbits, signs=signs)
+        yams = [amax_slot(dev, o.shape[0]) for o in outs[sl]] if want_amax() and not y_batch_stride else None
+        g = _wino_group(part, dsts=outs[sl], adds=pa, masks=pm, mask_bits=mbits, signs=signs, amaxs=yams)
         nops = 1 + (pa is not None and pa[0] is not None) + (1.0 / 32 if mbits else 1.0) * has_mask + (1.0 / 32 if signs[0] is not None else 0.0)
         nb = 4.0 * (36 * t * cout + nops * sum(x.shape[0] * x.shape[1] * x.shape[2] for x in part) * cout)
         mm = (mask_mode | (MASK_BITS if mbits else 0)) if has_mask else 0
         _hip.check(prof.timed("wino_output", nb, lambda: lib.rn_wino_output_group(
             ctypes.byref(g), M.data_ptr(), cout, off, Tpad, _hip.ptr(scale), _hip.ptr(shift), mm,
             act, y_batch_stride, _hip.stream())), "rn_wino_output_group")
+        if yams is not None:
+            for o, w_ in zip(outs[sl], yams):
+                amax_attach(o, w_)
         off += t
     return (outs, (V, tuple(tuple(x.shape) for x in xs), v_am)) if keep_v else outs   # V + the shapes it belongs to (+ its amax word)
 
@@ -466,30 +472,33 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
     Tpad = (T + 255) // 256 * 256
     # V: (B^T d B of the forward's inputs, their shapes) kept by wino_conv_group(keep_v=True); used only for the same grouping
     have_v = V is not None and V[1] == tuple(tuple(x.shape) for x in xs) and V[0].numel() == 36 * Tpad * C
-    v_am = V[2] if have_v and len(V) > 2 else None   # split3: the kept transform's amax word
+    v_tw = V[2][1] if have_v and len(V) > 2 and V[2] is not None else None      # split3: the kept transform's tensor word
     V = V[0] if have_v else None
     Vw, Z = _wino_workspace(dev, 0 if have_v else 36 * Tpad * C, 36 * Tpad * cout)
     if not have_v:
         V = Vw
     assert all(g.shape[:3] == x.shape[:3] and g.is_contiguous() and x.is_contiguous() for g, x in zip(gs, xs))
     if not have_v:
-        _wino_transform_in(xs, V, C, Tpad, 0)
-    v_dy = None
+        v_tw = _wino_transform_in(xs, V, C, Tpad, 0, want_tensor=True)[1]
+    v_dy, z_tw = None, None
     if fuse_dgrad_input and have_v and len(gs) <= _hip.RN_MAX_GROUP:
         # The data gradient of the same layer follows and needs B^T dy B of the same gs: both transforms in ONE pass over dy
         # (rn_wino_input_both_group).  B^T dy B goes to the V half of the workspace (idle here: the forward's V was kept), and
         # the (tensor, shapes) pair goes back to the caller for wino_conv_group(V_ready=...).
         Vd, Z = _wino_workspace(dev, 36 * Tpad * cout, 36 * Tpad * cout)
-        g = _wino_group(gs, srcs=gs)
+        am_on = want_amax()
+        g = _wino_group(gs, srcs=gs, amaxs=[amax_words(t) for t in gs] if am_on else None)
+        vd_rows = torch.zeros(Tpad, dtype=torch.int32, device=dev) if am_on else None
+        z_tw = amax_slot(dev) if am_on else None
         nb = 4.0 * (sum(t.numel() for t in gs) + 2 * 36 * T * cout)
         _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_both_group(
-            ctypes.byref(g), Vd.data_ptr(), Z.data_ptr(), cout, 0, Tpad, _hip.stream())), "rn_wino_input_both_group")
-        v_dy = (Vd, tuple(tuple(t.shape) for t in gs), None)
+            ctypes.byref(g), Vd.data_ptr(), Z.data_ptr(), cout, 0, Tpad, _hip.ptr(vd_rows), _hip.ptr(z_tw), _hip.stream())),
+            "rn_wino_input_both_group")
+        v_dy = (Vd, tuple(tuple(t.shape) for t in gs), (vd_rows, None))
     else:
-        _wino_transform_in(gs, Z, cout, Tpad, 1)
-    am = (None, None)
-    if want_amax():                                  # split3: both operands of the 36 reductions are Winograd-domain tensors
-        am = (_wino_amax(Z, Tpad, T, cout), v_am if v_am is not None else _wino_amax(V, Tpad, T, C))
+        z_tw = _wino_transform_in(gs, Z, cout, Tpad, 1, want_tensor=True)[1]
+    # split3: both operands of the 36 reductions are Winograd-domain tensors, one word each (the reduction runs over all images)
+    am = (z_tw, v_tw) if (want_amax() and z_tw is not None and v_tw is not None) else (None, None)
     ku = (C + 31) // 32 * 32
     if dU is None or tuple(dU.shape) != (36, cout, ku):      # dU: a ZEROED [36, cout, ku] accumulator of the caller (used once)
         dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
@@ -519,10 +528,10 @@ def conv_igemm_grouped(problems, w_packed, scale=None, shift=None, act=ACT_NONE,
             wptr, wfmt, wus = _w_operand(w_packed, d)
         d.w_format, d.w_unscale = wfmt, wus
         if wfmt == 3:
-            d.x_amax = amax_word(x).data_ptr()
+            d.x_amax, d.x_amax_img_stride, d.x_amax_row_stride = amax_words(x).data_ptr(), 1, 0
         bits = _sign_words(pr["y"], pr.get("sign", False) and pr.get("y_batch_stride") is None)
         d.sign_out = None if bits is None else bits.data_ptr()
-        yam = amax_slot(x.device) if want_amax() and pr.get("y_batch_stride") is None else None
+        yam = amax_slot(x.device, x.shape[0]) if want_amax() and pr.get("y_batch_stride") is None else None
         yams.append(yam)
         d.y_amax = None if yam is None else yam.data_ptr()
         g.d[i] = d
@@ -591,7 +600,7 @@ def dgrad_s2_classes(dy, class_weights, in_hw, cin, k, pad, flops=0.0, **kw):
     if len(classes) < 4:
         dx.zero_()                                  # classes without taps (k = 1) receive no gradient
     total_taps = sum(c[2][1] * c[2][3] for c in classes)
-    slot = amax_slot(dy.device) if want_amax() else None      # split3: the classes fill ONE tensor: one amax word for all of them
+    slot = amax_slot(dy.device, N) if want_amax() else None   # split3: the classes fill ONE tensor: one set of amax words for all of them
     for (ph, pw, (r0, nr, s0, ns), (dh0, dw0)), wc in zip(classes, class_weights):
         gh, gw = (Hi - ph + 1) // 2, (Wi - pw + 1) // 2
         if gh <= 0 or gw <= 0:
@@ -611,7 +620,8 @@ def wgrad(dy, x, dw, cout, k, stride, pad, kw_pad=None, in_relu=False, flops=0.0
     N, Ho, Wo, ldy = dy.shape
     _, Hi, Wi, Cin = x.shape
     kind = "conv_wgrad" + (" %dx%dx%d %d->%d k%d s%d" % (N, Ho, Wo, Cin, cout, k, stride) if prof.BY_SHAPE else "")
-    am = (amax_word(dy), amax_word(x)) if want_amax() else (None, None)      # split3: the operands' power-of-two scales
+    # split3: the operands' power-of-two scales
+    am = (amax_words(dy), amax_words(x)) if want_amax() and dy.is_contiguous() and x.is_contiguous() else (None, None)
     rc = prof.timed(kind, flops, lambda: _wgrad_call(
         lib, dy.device, dy.data_ptr(), ldy, x.data_ptr(), dw.data_ptr(), _hip.ptr(colsum), 1, 0, 0, 0, 0,
         (N, Hi, Wi, Cin, Ho, Wo, cout, k, k if kw_pad is None else kw_pad, stride, pad, int(in_relu)), amax=am))
@@ -707,12 +717,13 @@ def upsample_add_bwd(src, dst):
     fn = lib.rn_upsample_add_bwd_bf16 if src.dtype == torch.bfloat16 else lib.rn_upsample_add_bwd
     assert src.dtype == dst.dtype
     _hip.check(fn(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C, _hip.stream()), "rn_upsample_add_bwd")
+    amax_drop(dst)
     return dst
 
 
 def relu_mask_(g, z):
     _hip.check(_hip.load().rn_relu_mask(g.data_ptr(), z.data_ptr(), g.numel(), _hip.stream()), "rn_relu_mask")
-    return g
+    return g                                       # (a mask only lowers magnitudes: an amax word stays a valid bound)
 
 
 def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, device, bf16=False):
@@ -728,6 +739,7 @@ def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, d
 
 def add_(dst, src):
     _hip.check(_hip.load().rn_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), _hip.stream()), "rn_add_inplace")
+    amax_drop(dst)
     return dst
 
 

@@ -651,17 +651,27 @@ class Engine:
             add(2, j, src.numel())
             return dst
 
-        presplit = cv.PRESPLIT and cv.get_fp32_mfma() == "split" and not self.bf16
+        mode = cv.get_fp32_mfma()
+        presplit = cv.PRESPLIT and mode != "native" and not self.bf16
 
-        def split_job(src, force=False):
-            """split mode: the pre-split twin of a packed fp32 buffer (cv.split_weights' attribute), filled by launch 2.
-            force: the stem of the bf16 / fp8 engines, whose one-term products read the twin's first plane in every mode."""
+        def split_job(src, force=False, f16=None):
+            """split modes: the pre-split twin of a packed fp32 buffer (cv.split_weights' / split_weights_f16's attribute), filled by
+            launch 2.  force: the stem of the bf16 / fp8 engines, whose one-term products read the twin's first plane in every mode.
+            f16 = (rows, cin, taps) of the GEMM the buffer feeds: split3 mode writes the fp16 two-term form where the fp16 kernels
+            take the layer (cv.f16_shape_ok), the three-term bf16 form elsewhere."""
             if not force and (not presplit or src.shape[-1] < _hip.load().rn_fp32_split_min_k()):
                 return
-            dst = torch.empty(src.numel() * 6, dtype=torch.uint8, device=dev)
+            rows = src.numel() // src.shape[-1]
             j = _hip.PrepJob()
-            j.kind, j.rows, j.Kpad = 4, src.numel() // src.shape[-1], src.shape[-1]
-            j.src, j.dst = src.data_ptr(), dst.data_ptr()
+            j.rows, j.Kpad, j.src = rows, src.shape[-1], src.data_ptr()
+            if not force and mode == "split3" and f16 is not None and cv.f16_shape_ok(*f16):
+                dst = (torch.empty(src.numel() * 4, dtype=torch.uint8, device=dev), torch.empty(rows, dtype=torch.float32, device=dev))
+                j.kind, j.dst, j.bn_scale = 5, dst[0].data_ptr(), dst[1].data_ptr()
+                add(2, j, (rows + 3) // 4 * 256)
+                src._rn_split16 = dst
+                return
+            dst = torch.empty(src.numel() * 6, dtype=torch.uint8, device=dev)
+            j.kind, j.dst = 4, dst.data_ptr()
             add(2, j, src.numel() // 8)
             src._rn_split = dst
 
@@ -687,7 +697,7 @@ class Engine:
             b = bufs[name] = {}
             b["wf"] = torch.empty((cout, (kh * L.kw_pad * L.cin_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
             add(0, pack_job(w, b["wf"], 0, L.kw_pad, L.cin_pad, None), b["wf"].numel())
-            split_job(b["wf"], force=getattr(L, "bf16_products", False))
+            split_job(b["wf"], force=getattr(L, "bf16_products", False), f16=(cout, L.cin_pad, kh * L.kw_pad))
             if L.bf16:
                 b["wf16"] = cast_job(b["wf"])
             scale = None
@@ -709,7 +719,7 @@ class Engine:
                     j.rows, j.Kpad = dst.shape[1], dst.shape[2]
                     j.src, j.dst, j.scale = w.data_ptr(), dst.data_ptr(), None if (mode == 0 or scale is None) else scale.data_ptr()
                     add(which, j, dst.shape[1] * dst.shape[2])
-                    split_job(dst)
+                    split_job(dst, f16=(dst.shape[1], dst.shape[2], 1))
                 b["wino"] = (uf, ud)
                 continue
             if name == "conv1":
@@ -720,14 +730,14 @@ class Engine:
                     r0, nr, s0, ns = c[2]
                     d = torch.empty((cin, (nr * ns * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
                     add(1, pack_job(w, d, 2, kw, L.cout_pad, scale, c[2]), d.numel())
-                    split_job(d)
+                    split_job(d, f16=(cin, L.cout_pad, nr * ns))
                     b["wd"].append(d)
                 if L.bf16:
                     b["wd16"] = [cast_job(d) for d in b["wd"]]
             else:
                 d = b["wd"] = torch.empty((cin, (kh * kw * L.cout_pad + 31) // 32 * 32), dtype=torch.float32, device=dev)
                 add(1, pack_job(w, d, 1, kw, L.cout_pad, scale), d.numel())
-                split_job(d)
+                split_job(d, f16=(cin, L.cout_pad, kh * kw))
                 if L.bf16:
                     b["wd16"] = cast_job(d)
         out = []

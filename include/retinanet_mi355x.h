@@ -269,14 +269,20 @@ typedef struct rn_conv_desc {
                                       = (y[e] > 0) for every stored element at float offset e -- what the backward pass needs of a ReLU
                                       output (D/utils.py:60-80), at 1/32 of the bytes.  Needs Cout % 32 == 0 and y_batch_stride % 32
                                       == 0.  mask_mode | RN_MASK_BITS (4): `mask` points to such words (the consumer's side). */
-    const void *x_amax;            /* RN_FP32_SPLIT3 (round 5): the AMAX WORD of x -- one uint32 holding the fp32 bit pattern of a value whose
-                                      exponent is that of the tensor's largest |element| (what a producer's y_amax left, or rn_amax) --
-                                      from which the kernel takes the power-of-two scale of its fp16 split.  Required when w_format == 3. */
-    void *y_amax;                  /* NULL, or the amax word of the RESULT: every kernel that finishes elements raises it (atomic max at
-                                      device scope) to the largest |y| it stored; the caller zeroes it before the launch.  Any product
-                                      mode; not by the raw Winograd-stage GEMM (its result feeds a transform, not a convolution). */
+    const void *x_amax;            /* RN_FP32_SPLIT3 (round 5): the AMAX WORDS of x -- uint32 words each holding the fp32 bit pattern of a value
+                                      whose exponent is that of the largest |element| of one IMAGE of x (what a producer's y_amax left, or
+                                      rn_amax) -- from which the kernel takes the power-of-two scales of its fp16 split, row by row: the word
+                                      of GEMM row (image n, pixel r of it) is x_amax[n * x_amax_img_stride + r * x_amax_row_stride].
+                                      (1, 0): one word per image, the usual form -- an image's result then does not depend on what else
+                                      is in the batch; (0, 1): one word per row, the same for every "image": the Winograd-stage GEMM, whose
+                                      rows are tiles (rn_wino_input_group writes them).  Required when w_format == 3. */
+    void *y_amax;                  /* NULL, or the amax words of the RESULT, one per image [N]: every kernel that finishes elements raises
+                                      word n (atomic max at device scope) to the largest |y| it stored in image n; the caller zeroes them
+                                      before the launch.  Any product mode; not by the raw Winograd-stage GEMM (its result feeds a
+                                      transform, not a convolution). */
     const float *w_unscale;        /* w_format == 3: per weight row the inverse 2^-s of the power-of-two scale its fp16 terms were
                                       written with (rn_split_weights_f16); [batch * Cout] when w_batch_stride != 0 */
+    int x_amax_img_stride, x_amax_row_stride;
 } rn_conv_desc;
 #define RN_MASK_BITS 4
 
@@ -339,9 +345,9 @@ int rn_split_weights(const float *w_packed, void *w_split, int64_t rows, int Kpa
  * a K-step, written with the row's own power-of-two scale (largest |value| of the row -> [2^14, 2^15)); row_unscale[rows] receives
  * the inverse scales.  Pass as w_packed with rn_conv_desc.w_format = 3 and w_unscale = row_unscale.  (rn_prep_batched: job kind 5.) */
 int rn_split_weights_f16(const float *w_packed, void *w_split, float *row_unscale, int64_t rows, int Kpad, void *stream);
-/* The amax word of a tensor (rn_conv_desc.x_amax) for tensors no producer left one for: *amax = max(*amax, bits of max |x[i]|);
- * zero the word first.  One pass over x. */
-int rn_amax(const float *x, int64_t n, void *amax, void *stream);
+/* The amax words of a tensor (rn_conv_desc.x_amax) for tensors no producer left them for: x = n_images images of per_image floats,
+ * amax[i] = max(amax[i], bits of the largest |element| of image i); zero the words first.  One pass over x. */
+int rn_amax(const float *x, int64_t per_image, int n_images, void *amax, void *stream);
 /* 1 when rn_conv_igemm would run this problem on an fp16-split kernel in RN_FP32_SPLIT3 mode (so: wants w_format 3, x_amax, w_unscale),
  * 0 when it keeps the three-term kernels (w_format 0 / 1).  Depends on the geometry only. */
 int rn_conv_igemm_wants_f16(const rn_conv_desc *d);
@@ -392,9 +398,10 @@ int rn_conv_wgrad(const float *dy, int ldy, const float *x, float *dw, float *co
 int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                           int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
-                          const void *dy_amax, const void *x_amax, void *stream);
-/* dy_amax / x_amax (round 5): the amax words of the two operands (rn_conv_desc.x_amax: one uint32 each; for a batched launch one word
- * covers all entries of the operand) -- with both given, RN_FP32_SPLIT3 mode runs the fp16 two-term kernels; NULL: the three-term ones. */
+                          const void *dy_amax, int dy_amax_n, const void *x_amax, int x_amax_n, void *stream);
+/* dy_amax / x_amax (round 5): the amax words of the two operands (rn_conv_desc.x_amax) and how many there are (one per image; one for a
+ * whole Winograd-domain tensor, whatever the batch) -- with both given, RN_FP32_SPLIT3 mode runs the fp16 two-term kernels, each
+ * operand scaled by the power of two of its LARGEST word (the reduction runs over all images); NULL: the three-term kernels. */
 /* The same reduction in a FIXED order (RN_OPT_DETERMINISTIC; the host logic selects it when the option is on): every K slice
  * stores its partial result into its own slab of `workspace` (plain stores) and one ordered pass adds slabs 0, 1, 2 ... and the
  * slices' column sums into dw / colsum: bit-identical from run to run, as the reference's CPU autograd is.  Costs one write and
@@ -404,7 +411,8 @@ int64_t rn_conv_wgrad_det_workspace_bytes(int ldy, int nbatch, int64_t dw_bstrid
 int rn_conv_wgrad_batched_det(const float *dy, int ldy, const float *x, float *dw, float *colsum, int nbatch,
                               int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
                               int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
-                              const void *dy_amax, const void *x_amax, void *workspace, int64_t workspace_bytes, void *stream);
+                              const void *dy_amax, int dy_amax_n, const void *x_amax, int x_amax_n, void *workspace, int64_t workspace_bytes,
+                              void *stream);
 
 /* ---------------------------------------------------------------- bf16 convolution engine -----------------
  * The reduced-precision form of rn_conv_igemm / rn_conv_wgrad for BASELINE configs[2] (bf16 MFMA,
@@ -502,11 +510,20 @@ typedef struct rn_wino_group {
     const float *add[RN_MAX_GROUP];
     const float *mask[RN_MAX_GROUP];       /* rn_wino_output_group: fp32, or sign-bit words with mask_mode | RN_MASK_BITS */
     void *sign[RN_MAX_GROUP];              /* rn_wino_output_group: NULL or the words that receive the result's sign bits (rn_conv_desc.sign_out) */
+    void *amax[RN_MAX_GROUP];              /* RN_FP32_SPLIT3: NULL, or amax words, one per image [N] -- of src for the input transforms (read:
+                                              rn_conv_desc.x_amax of the untransformed tensor), of dst for rn_wino_output_group (raised:
+                                              rn_conv_desc.y_amax) */
 } rn_wino_group;
-int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form, void *stream);
+/* row_amax / tensor_amax (round 5, RN_FP32_SPLIT3; NULL otherwise): the amax words of the TRANSFORMED tensor, derived from the sources'
+ * per-image words by the transform's gain bound (2^7 for B^T d B, 2^8 for A dy A^T; csrc/conv_wino.hip) without a reduction:
+ * row_amax[tile_offset + t] = the word of tile row t (its image's) -- the Winograd-stage GEMM's rn_conv_desc.x_amax with strides (0, 1);
+ * *tensor_amax = max(*tensor_amax, the largest of them) -- the weight gradient's single word (zero it before the first launch). */
+int rn_wino_input_group(const rn_wino_group *g, float *V, int C, int64_t tile_offset, int64_t Tpad, int dy_form,
+                        void *row_amax, void *tensor_amax, void *stream);
 /* Both input-side transforms of an output gradient in one pass over it: V = B^T dy B (rn_wino_input_group, dy_form 0: what the
  * data gradient's GEMM reads) and Z = A dy A^T (dy_form 1: what the weight gradient's reads). */
-int rn_wino_input_both_group(const rn_wino_group *g, float *V, float *Z, int C, int64_t tile_offset, int64_t Tpad, void *stream);
+int rn_wino_input_both_group(const rn_wino_group *g, float *V, float *Z, int C, int64_t tile_offset, int64_t Tpad,
+                             void *v_row_amax, void *z_tensor_amax, void *stream);
 int rn_wino_output_group(const rn_wino_group *g, const float *M, int Cout, int64_t tile_offset, int64_t Tpad,
                          const float *scale, const float *shift, int mask_mode, int act, int64_t y_batch_stride, void *stream);
 int rn_wino_input(const float *x, float *V, int N, int H, int W, int C, int64_t tile_offset, int64_t Tpad, void *stream);
@@ -526,7 +543,9 @@ int rn_wino_dw(const float *dU, float *dw, int Cout, int Cin, void *stream);
 /* Batched per-step preparation: batch-norm folding (kind 0: bn_scale = gamma / sqrt(var + eps), bn_shift = beta - mean *
  * bn_scale, bn_rstd), weight packing (kind 1: the arguments of rn_pack_weights, rows / Kpad as it derives them) and
  * Winograd weight transforms (kind 2: the arguments of rn_wino_weights, dst [36][rows][Kpad]) and bf16 copies of packed
- * buffers (kind 3: rows * Kpad floats at src -> bf16 at dst; a launch AFTER the one that packs src) for many layers in one launch.  jobs_dev: device array of rn_prep_job; chunks_dev: device array of nchunks (job index,
+ * buffers (kind 3: rows * Kpad floats at src -> bf16 at dst; a launch AFTER the one that packs src), the pre-split forms of packed buffers
+ * (kind 4: rn_split_weights, 8 values per thread; kind 5: rn_split_weights_f16, chunk = 4 rows, inverse row scales to bn_scale; both AFTER
+ * the launch that packs src) for many layers in one launch.  jobs_dev: device array of rn_prep_job; chunks_dev: device array of nchunks (job index,
  * 256-element block inside the job) pairs.  Jobs of one launch must not depend on each other: the data-gradient packs
  * (which read bn_scale) go in a second launch. */
 typedef struct rn_prep_job {

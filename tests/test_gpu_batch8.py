@@ -25,7 +25,7 @@ LOSS_TOL = 1e-6
 GRAD_L2_TOL = 1e-5
 
 
-@pytest.fixture(params=["native", "split"])
+@pytest.fixture(params=["native", "split", "split3"])
 def mfma(request, dev):
     from retinanet_mi355x import conv
     before = conv.get_fp32_mfma()

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["split", "native"])
+@pytest.fixture(params=["split", "native", "split3"])
 def cv(dev, request):
     from retinanet_mi355x import conv
     before = conv.get_fp32_mfma(), conv.BITMASKS

@@ -126,7 +126,7 @@ def test_directional_eval_localize(dev, golden, arch):
     rel_close(boxes.cpu().numpy(), z["%s_dir_boxes" % arch], 1e-4)
 
 
-@pytest.fixture(params=["native", "split"])
+@pytest.fixture(params=["native", "split", "split3"])
 def mfma(request, dev):
     """Both product modes of the fp32 convolution kernels (include/retinanet_mi355x.h: RN_FP32_NATIVE / RN_FP32_SPLIT)."""
     from retinanet_mi355x import conv
