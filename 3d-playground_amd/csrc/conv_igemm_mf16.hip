@@ -98,6 +98,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // ---- this lane's two activation rows (tile rows 32 * wave + 16 * sm + lr): tap mask and base offset of its 8 k values
     unsigned a_mask[2];
     int a_base[2];
+    int a_n[2] = {-1, -1}, a_rem[2] = {0, 0};              // TERMS 2: the rows' images (absolute) and pixels; -1: a row past M
 #pragma unroll
     for (int sm = 0; sm < 2; ++sm) {
         const int row = 32 * wave + 16 * sm + lr;
@@ -110,12 +111,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             a_img = (int)((int64_t)n * d.x_batch_stride * 4);
             a_h = (int)oh * d.a + d.p;
             a_w = (int)ow * d.a + d.p_w;
-            if constexpr (HALF) {
-                const int se = rn_f16_scale_exp(reinterpret_cast<const unsigned *>(d.x_amax)[
-                    (int64_t)(n_first + (int)n) * d.x_amax_img_stride + (int64_t)rem * d.x_amax_row_stride]);
-                a_scale[sm] = rn_exp_to_float(se);
-                if (lg == 0) row_unscale[row] = rn_exp_to_float(254 - se);      // (the wave's own rows: no other wave reads them)
-            }
+            if constexpr (HALF) { a_n[sm] = n_first + (int)n; a_rem[sm] = (int)rem; }
         }
         unsigned mk = 0;
         for (int r = 0, t = 0; r < d.kh; ++r)
@@ -180,6 +176,27 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // return zeros / stale weights nobody uses, and all have landed (vmcnt(0)) before the epilogue reuses the LDS.
     ARegs cur;
     load_a(cur); dma_b(0, 0);
+    if constexpr (HALF) {
+        // the rows' scales, while the first operands travel: per image from its exponent table (one 256-byte read per wave and image --
+        // a wave's 32 rows lie in one image, rarely two), or per row from the plain words the Winograd input transform wrote
+        int e[2];
+        if (d.x_amax_row_stride == 0) {
+            const unsigned char *tb = reinterpret_cast<const unsigned char *>(d.x_amax);
+            e[0] = rn_amax_exp_lanes(a_n[0] < 0 ? nullptr : tb + (int64_t)a_n[0] * d.x_amax_img_stride * RN_AMAX_BYTES);
+            e[1] = __ballot(a_n[1] != a_n[0]) == 0ull ? e[0]
+                 : rn_amax_exp_lanes(a_n[1] < 0 ? nullptr : tb + (int64_t)a_n[1] * d.x_amax_img_stride * RN_AMAX_BYTES);
+        } else {
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm)
+                e[sm] = a_n[sm] < 0 ? 0 : (int)((reinterpret_cast<const unsigned *>(d.x_amax)[(int64_t)a_rem[sm] * d.x_amax_row_stride] >> 23) & 0xffu);
+        }
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const int se = rn_f16_scale_exp_of(e[sm]);
+            a_scale[sm] = rn_exp_to_float(se);
+            if (lg == 0) row_unscale[32 * wave + 16 * sm + lr] = rn_exp_to_float(254 - se);      // (the wave's own rows: no other wave reads them)
+        }
+    }
     rn_wait_dma();
     __syncthreads();
     auto k_step = [&](int ks, int rb) {
@@ -295,11 +312,14 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip's reads before the next half's writes
         __builtin_amdgcn_wave_barrier();
     }
-    if (!RAW && !rn_span) rn_amax_commit(d.y_amax, m0 / HoWo, rn_am);
+    if (!RAW && !rn_span) rn_amax_note(d.y_amax, m0 / HoWo, rn_am);
 }
 
+#ifndef RN_MF16H_OCC
+#define RN_MF16H_OCC 3           // workgroups per CU the fp16 form's registers are cut for (120 registers, 33 KB of LDS: 4 fit; A/B below)
+#endif
 template <bool GENERAL, bool RAW, int TERMS>
-__global__ __launch_bounds__(256, 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
+__global__ __launch_bounds__(256, TERMS == 2 ? RN_MF16H_OCC : 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const float *__restrict__ add, const float *__restrict__ mask,
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_mf16_kernel(const rn_conv_d
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(256, 3) void conv_igemm_mf16_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
+__global__ __launch_bounds__(256, TERMS == 2 ? RN_MF16H_OCC : 3) void conv_igemm_mf16_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
                                                                       const float *__restrict__ scale,
                                                                       const float *__restrict__ shift) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);

@@ -147,7 +147,7 @@ extern "C" int rn_split_weights_f16(const float *w_packed, void *w_split, float 
 }
 
 // The amax words of a tensor nobody left them for (rn_conv_desc.x_amax): one streaming pass, grid.y = image.
-__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t per_image, unsigned *__restrict__ amax) {
+__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t per_image, void *__restrict__ amax) {
     const float *xi = x + (int64_t)blockIdx.y * per_image;
     const int64_t n4 = per_image >> 2, stride = (int64_t)gridDim.x * 256;
     float am = 0.f;
@@ -160,14 +160,14 @@ __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, 
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_image; i += stride) am = fmaxf(am, fabsf(xi[i]));
     }
-    rn_amax_commit(amax, blockIdx.y, am);
+    rn_amax_note(amax, blockIdx.y, am);
 }
 extern "C" int rn_amax(const float *x, int64_t per_image, int n_images, void *amax, void *stream) {
     if (per_image <= 0 || n_images <= 0 || n_images > 65535 || !amax || ((uintptr_t)x & 3)) return RN_EINVAL;
     const int64_t want = (per_image / 4 + 255) / 256;
     const int64_t cap = 2048 / n_images < 8 ? 8 : 2048 / n_images;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(want < 1 ? 1 : (want > cap ? cap : want)), (unsigned)n_images), dim3(256), 0,
-                       (hipStream_t)stream, x, per_image, reinterpret_cast<unsigned *>(amax));
+                       (hipStream_t)stream, x, per_image, amax);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
     const int64_t M = (int64_t)d.N * d.Ho * d.Wo;
     const int cpr = (d.Cout + 3) / 4;                        // 4-channel chunks per output pixel
     const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float rn_am = 0.f;
-    const bool rn_span = true;                               // rn_conv_desc.y_amax: every chunk into the word of its own image
+    float rn_am = 0.f;                                       // rn_conv_desc.y_amax: what this thread's chunk stores, into its image's word
+    const bool rn_span = false;
+    const int64_t m_mine = chunk < M * cpr ? chunk / cpr : M - 1;
+    const int n_mine = (int)((unsigned)m_mine / (unsigned)(d.Ho * d.Wo));
     if (chunk < M * cpr) {
     const int64_t m = chunk / cpr;
     const int col = (int)(chunk - m * cpr) * 4;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const rn_conv_d
     const int HoWo = d.Ho * d.Wo;
     RN_EPI_CHUNK_BODY(GENERAL);
     }
-    (void)rn_am;
+    if (chunk < M * cpr) rn_amax_note(d.y_amax, n_mine, rn_am);
 }
 
 // Slices worth using for this problem (1 = do not split) -- few output tiles and a long K loop.

@@ -17,10 +17,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // col, ncol, vec, t, sc, sh, y, add, mask, add2, HoWo from the scope they are expanded in.
 //   RN_EPI_ADDR   -> int64_t off (output / mask / same-geometry addend), aoff, a2off (-1 = none)
 //   RN_EPI_LOAD   -> float mk[4], ad[4] from mask / add / add2
-//   RN_EPI_FINISH -> arithmetic and the store; rn_conv_desc.y_amax (one word per image): the lane's running maximum of |stored value|
-//                    in `float rn_am` of the scope, committed once per wave by rn_amax_commit after the last chunk when the scope's
-//                    `bool rn_span` is false (all rows of the tile in one image: the usual case), else per chunk into the word of
-//                    the chunk's own image m / HoWo
+//   RN_EPI_FINISH -> arithmetic and the store; rn_conv_desc.y_amax (an exponent table per image, mfma_split.h): the lane's running
+//                    maximum of |stored value| in `float rn_am` of the scope, noted once per lane (rn_amax_note) after the last chunk
+//                    when the scope's `bool rn_span` is false (all rows of the tile in one image: the usual case), else per chunk
+//                    in the table of the chunk's own image m / HoWo
 #define RN_EPI_ADDR(GENERAL)                                                                                     \
         int64_t off, aoff = -1, a2off = -1; \
         if (!GENERAL) { \
@@ -74,14 +74,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
             if (d.sign_out != nullptr) rn_sign_store(reinterpret_cast<unsigned *>(d.sign_out), off, v[0], v[1], v[2], v[3]); \
             if (d.y_amax != nullptr) { \
                 const float q_ = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); \
-                if (rn_span) rn_amax_lane(d.y_amax, (int64_t)((unsigned)m / (unsigned)HoWo), q_); else rn_am = fmaxf(rn_am, q_); \
+                if (rn_span) rn_amax_note(d.y_amax, (int64_t)((unsigned)m / (unsigned)HoWo), q_); else rn_am = fmaxf(rn_am, q_); \
             } \
         } else { \
             float q_ = 0.f; \
     _Pragma("unroll") \
             for (int j = 0; j < 4; ++j) \
                 if (j < ncol) { y[off + j] = v[j]; q_ = fmaxf(q_, fabsf(v[j])); } \
-            if (d.y_amax != nullptr) { if (rn_span) rn_amax_lane(d.y_amax, (int64_t)((unsigned)m / (unsigned)HoWo), q_); else rn_am = fmaxf(rn_am, q_); } \
+            if (d.y_amax != nullptr) { if (rn_span) rn_amax_note(d.y_amax, (int64_t)((unsigned)m / (unsigned)HoWo), q_); else rn_am = fmaxf(rn_am, q_); } \
         }
 
 #define RN_EPI_CHUNK_BODY(GENERAL) \
@@ -713,7 +713,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             }
         }
     }
-    if (partial == nullptr && !rn_span) rn_amax_commit(d.y_amax, m0 / HoWo, rn_am);
+    if (partial == nullptr && !rn_span) rn_amax_note(d.y_amax, m0 / HoWo, rn_am);
 }
 
 

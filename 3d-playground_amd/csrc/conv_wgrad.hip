@@ -62,20 +62,18 @@ struct WgradArgs {
     // in slice order.  NULL: fp32 atomics.
     float *slab, *cs_slab;
     int64_t slab_stride;
-    // RN_FP32_SPLIT3 (fp16 two-term products; mfma_split.h): the amax words of dy and x (one per image, or one for a whole
-    // Winograd-domain tensor) and their counts, else NULL.  The reduction runs over the pixels of ALL images, so each operand takes ONE
-    // power-of-two scale: that of the largest of its words.
-    const unsigned *dy_amax, *x_amax;
+    // RN_FP32_SPLIT3 (fp16 two-term products; mfma_split.h): the amax tables of dy and x and how many images they cover (count > 0), or
+    // ONE plain word each (count -1: a Winograd-domain tensor's), else NULL.  The reduction runs over the pixels of ALL images, so each
+    // operand takes ONE power-of-two scale: that of the largest exponent in any of its tables.
+    const void *dy_amax, *x_amax;
     int dy_amax_n, x_amax_n;
 };
 
-// scale / inverse scale of an operand from its amax words (all 64 lanes of the wave active; the result is wave-uniform)
-__device__ __forceinline__ void wgrad_scales(const unsigned *amax, int count, float &scale, float &unscale) {
-    unsigned b = 0;
-    for (int i = threadIdx.x & 63; i < count; i += 64) { const unsigned w = amax[i] & 0x7fffffffu; b = w > b ? w : b; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)b, off, 64); b = o > b ? o : b; }
-    const int se = rn_f16_scale_exp(__builtin_amdgcn_readfirstlane(b));
+// scale / inverse scale of an operand (all 64 lanes of the wave active; the result is wave-uniform)
+__device__ __forceinline__ void wgrad_scales(const void *amax, int count, float &scale, float &unscale) {
+    const int e = count > 0 ? rn_amax_exp_all(amax, count)
+                            : (int)((__builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned *>(amax)) >> 23) & 0xffu);
+    const int se = rn_f16_scale_exp_of(e);
     scale = rn_exp_to_float(se);
     unscale = rn_exp_to_float(254 - se);
 }
@@ -723,9 +721,9 @@ static int wgrad_launch(const float *dy, int ldy, const float *x, float *dw, flo
     // on the mid-size layers, equal on the largest; the 64 x 256 tile does not fit twice at 32).
     const bool split = rn_get_fp32_mfma() != RN_FP32_NATIVE;
     // RN_FP32_SPLIT3 with both amax words: the fp16 two-term kernels; without them (a caller of the plain entry point) the three-term ones
-    const bool half = rn_get_fp32_mfma() == RN_FP32_SPLIT3 && dy_amax != nullptr && x_amax != nullptr && dy_amax_n > 0 && x_amax_n > 0;
-    a.dy_amax = reinterpret_cast<const unsigned *>(dy_amax);
-    a.x_amax = reinterpret_cast<const unsigned *>(x_amax);
+    const bool half = rn_get_fp32_mfma() == RN_FP32_SPLIT3 && dy_amax != nullptr && x_amax != nullptr && dy_amax_n != 0 && x_amax_n != 0;
+    a.dy_amax = dy_amax;
+    a.x_amax = x_amax;
     a.dy_amax_n = dy_amax_n;
     a.x_amax_n = x_amax_n;
 #define RN_WGRAD_LAUNCH(WM_, WN_)                                                                                        \

@@ -69,25 +69,24 @@ struct WinoTable {
     const float *add[RN_MAX_GROUP];
     const float *mask[RN_MAX_GROUP];
     unsigned *sign[RN_MAX_GROUP];                // output transform: sign bits of y (common.h: rn_sign_store), or NULL
-    unsigned *amax[RN_MAX_GROUP];                // amax words, one per image (mfma_split.h; RN_FP32_SPLIT3), or NULL: of src (input
-                                                 // transforms, read) / of dst (output transform, raised)
+    unsigned *amax[RN_MAX_GROUP];                // amax tables, one per image (mfma_split.h; RN_FP32_SPLIT3), or NULL: of src (input
+                                                 // transforms, read) / of dst (output transform, written)
 };
 
-// Amax words of a Winograd-domain tensor (RN_FP32_SPLIT3).  The transforms are linear maps of bounded gain -- |B^T d B| <= 100 max|d|
+// Amax of a Winograd-domain tensor (RN_FP32_SPLIT3), as plain WORDS (an fp32 bit pattern whose exponent field is the bound).  The transforms are linear maps of bounded gain -- |B^T d B| <= 100 max|d|
 // (< 2^7), |A dy A^T| <= 225 max|dy| (< 2^8): the absolute row sums of B^T are at most 10, of A at most 15 -- so the word of a tile's row
-// of V / Z follows from its IMAGE's word of the untransformed tensor by adding the gain to the exponent: no reduction, no atomics, and
+// of V / Z follows from the largest exponent in its IMAGE's table of the untransformed tensor by adding the gain: no reduction, no atomics, and
 // an image's scales still depend on that image alone.  The GEMM of the forward / data gradient takes the ROW words (rn_conv_desc.x_amax
 // with strides (0, 1)); the weight gradient, which reduces over the tiles of all images, takes the one TENSOR word (the largest of all).
 #define WINO_GAIN_BT 7
 #define WINO_GAIN_A 8
 __device__ __forceinline__ void wino_tensor_word(const WinoTable &g, unsigned *tensor_amax, int gain) {
-    if (tensor_amax == nullptr || blockIdx.x != 0 || threadIdx.x != 0) return;
-    unsigned b = 0;
+    if (tensor_amax == nullptr || blockIdx.x != 0 || threadIdx.x >= 64) return;      // wave 0 of workgroup 0, all 64 lanes
+    int e = 0;
 #pragma unroll
     for (int i = 0; i < RN_MAX_GROUP; ++i)
-        if (i < g.n && g.amax[i] != nullptr)
-            for (int n = 0; n < g.p[i].N; ++n) { const unsigned w = g.amax[i][n] & 0x7fffffffu; b = w > b ? w : b; }
-    atomicMax(tensor_amax, rn_amax_gain(b, gain));           // (several launches may fill one tensor: the caller zeroes the word)
+        if (i < g.n && g.amax[i] != nullptr) { const int ei = rn_amax_exp_all(g.amax[i], g.p[i].N); e = ei > e ? ei : e; }
+    if (threadIdx.x == 0) atomicMax(tensor_amax, rn_amax_word_of_exp(e, gain));     // (several launches may fill one tensor: the caller zeroes the word)
 }
 __device__ __forceinline__ int wino_locate(const WinoTable &g, int64_t gt, int64_t &local) {
     int q = 0;
@@ -115,9 +114,9 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *
     // tiles of one image row are spread over all eight XCDs and each L2 fetched its own copy of the shared pixels (PMC: 2.06x
     // the input from HBM); one contiguous band of tiles per XCD keeps the re-reads in that L2.
     const int64_t id = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    const int64_t gt = id / cq;
-    if (gt >= g.tile_end[g.n - 1]) return;
-    const int c4 = (int)(id - gt * cq) * 4;
+    const int64_t gt_raw = id / cq, t_last = g.tile_end[g.n - 1];
+    const int64_t gt = gt_raw < t_last ? gt_raw : t_last - 1;   // (threads past the end still help with the table read below)
+    const int c4 = (int)(id - gt_raw * cq) * 4;
     int64_t tile;
     const int q = wino_locate(g, gt, tile);
     const float *x = g.src[0];
@@ -129,7 +128,11 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *
     const int th = r / TW, tw = r - th * TW;
     const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
     const float *xb = x + (int64_t)n * H * W * C + c4;
-    if (row_amax != nullptr && c4 == 0) row_amax[t0 + gt] = xw != nullptr ? rn_amax_gain(xw[n], WINO_GAIN_BT) : 0u;
+    if (row_amax != nullptr) {                                // wave-cooperative: every lane the largest exponent of ITS image's table
+        const int e_img = rn_amax_exp_lanes(xw != nullptr ? reinterpret_cast<const unsigned char *>(xw) + (int64_t)n * RN_AMAX_BYTES : nullptr);
+        if (gt_raw < t_last && c4 == 0) row_amax[t0 + gt] = rn_amax_word_of_exp(e_img, WINO_GAIN_BT);
+    }
+    if (gt_raw >= t_last) return;
     float4 t[6][6];                                           // t[i][j] = (B^T d)[i][j]: columns first
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -168,15 +171,23 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
     const int cq = Cout >> 2;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t gt = id / cq;
-    if (gt >= g.tile_end[g.n - 1]) return;
+    // (the body sits in a one-trip loop so that threads past the last tile leave it by `break` and reach the amax commit at the end)
+    float am = 0.f;                                           // largest |y| this thread stores (the result's amax word of image n)
+    unsigned *yam = nullptr;
+    int n_img = 0;
+    bool live = false;
+    do {
+    if (gt >= g.tile_end[g.n - 1]) break;
+    live = true;
     const int c4 = (int)(id - gt * cq) * 4;
     int64_t tile;
     const int q = wino_locate(g, gt, tile);
     float *y = g.dst[0];
     const float *add = g.add[0], *mask = g.mask[0];
-    unsigned *sign = g.sign[0], *yam = g.amax[0];
+    unsigned *sign = g.sign[0];
+    yam = g.amax[0];
     WINO_SELECT(q, g, pr, y = g.dst[i_]; add = g.add[i_]; mask = g.mask[i_]; sign = g.sign[i_]; yam = g.amax[i_];)
-    float am = 0.f;                                           // largest |y| this thread stores (the result's amax word of image n)
+    n_img = (int)(tile / (pr.TH * pr.TW));
     const bool mbits = (mask_mode & RN_MASK_BITS) != 0;
     mask_mode &= 3;
     const int H = pr.H, W = pr.W, TW = pr.TW;
@@ -229,7 +240,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
             am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     }
-    if (yam != nullptr) rn_amax_lane(yam, n, am);
+    } while (0);
+    if (live) rn_amax_note(yam, n_img, am);
 }
 
 // ---------------------------------------------------------------------------------------------- weight transform
@@ -343,9 +355,9 @@ __global__ __launch_bounds__(256) void wino_in_both_kernel(const WinoTable g, fl
     wino_tensor_word(g, z_tensor_amax, WINO_GAIN_A);
     const int cq = C >> 2;
     const int64_t id = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    const int64_t gt = id / cq;
-    if (gt >= g.tile_end[g.n - 1]) return;
-    const int c4 = (int)(id - gt * cq) * 4;
+    const int64_t gt_raw = id / cq, t_last = g.tile_end[g.n - 1];
+    const int64_t gt = gt_raw < t_last ? gt_raw : t_last - 1;   // (threads past the end still help with the table read below)
+    const int c4 = (int)(id - gt_raw * cq) * 4;
     int64_t tile;
     const int q = wino_locate(g, gt, tile);
     const float *x = g.src[0];
@@ -357,7 +369,11 @@ __global__ __launch_bounds__(256) void wino_in_both_kernel(const WinoTable g, fl
     const int th = r / TW, tw = r - th * TW;
     const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
     const float *xb = x + (int64_t)n * H * W * C + c4;
-    if (v_row_amax != nullptr && c4 == 0) v_row_amax[t0 + gt] = xw != nullptr ? rn_amax_gain(xw[n], WINO_GAIN_BT) : 0u;
+    if (v_row_amax != nullptr) {
+        const int e_img = rn_amax_exp_lanes(xw != nullptr ? reinterpret_cast<const unsigned char *>(xw) + (int64_t)n * RN_AMAX_BYTES : nullptr);
+        if (gt_raw < t_last && c4 == 0) v_row_amax[t0 + gt] = rn_amax_word_of_exp(e_img, WINO_GAIN_BT);
+    }
+    if (gt_raw >= t_last) return;
     float4 t[6][6];                                           // t[i][j] = (B^T d)[i][j]
     float4 tz[6][4];                                          // tz[a][j] = (A dy)[a][j], dy = the patch's rows / columns 1..4
 #pragma unroll

@@ -248,19 +248,23 @@ extern "C" int rn_prep_batched(const rn_prep_job *jobs_dev, const int32_t *chunk
 }
 
 // ------------------------------------------------------------------------------------------------ layout
-__global__ void nchw_to_nhwc4_kernel(const float *__restrict__ src, float4 *__restrict__ dst, int64_t HW, int64_t total) {
+// (every kernel below that produces an activation / gradient tensor takes `amax`: NULL, or the result's amax words, one per image --
+// include/retinanet_mi355x.h: rn_conv_desc.y_amax; mfma_split.h: rn_amax_note)
+__global__ void nchw_to_nhwc4_kernel(const float *__restrict__ src, float4 *__restrict__ dst, int64_t HW, int64_t total, unsigned *__restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // pixel index over N*H*W
     if (i >= total) return;
     const int64_t n = i / HW, p = i - n * HW;
     const float *s = src + n * 3 * HW + p;
-    dst[i] = make_float4(s[0], s[HW], s[2 * HW], 0.f);
+    const float4 v = make_float4(s[0], s[HW], s[2 * HW], 0.f);
+    dst[i] = v;
+    rn_amax_note(amax, n, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)));
 }
 
-extern "C" int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *stream) {
+extern "C" int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *amax, void *stream) {
     if (N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
     const int64_t HW = (int64_t)H * W, total = HW * N;
     hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       reinterpret_cast<float4 *>(dst), HW, total);
+                       reinterpret_cast<float4 *>(dst), HW, total, reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -313,7 +317,8 @@ extern "C" int rn_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int N, 
 // Gather form: every input element looks at the (at most 4) windows that contain it and takes dy of those whose
 // recorded first maximum is this element.
 __global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ dy, const uchar4 *__restrict__ arg,
-                                   float4 *__restrict__ dx, int H, int W, int C4, int Ho, int Wo, int relu_mask, int64_t total) {
+                                   float4 *__restrict__ dx, int H, int W, int C4, int Ho, int Wo, int relu_mask, int64_t total,
+                                   unsigned *__restrict__ amax) {
     const int64_t i = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;       // over N*H*W*C4 (band per XCD, as above)
     if (i >= total) return;
     const int c = (int)(i % C4);
@@ -344,17 +349,18 @@ __global__ void maxpool_bwd_kernel(const float4 *__restrict__ x, const float4 *_
         g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
     }
     dx[i] = g;
+    rn_amax_note(amax, n, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
 }
 
 extern "C" int rn_maxpool_bwd(const float *x, const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
-                              int Ho, int Wo, int relu_mask, void *stream) {
+                              int Ho, int Wo, int relu_mask, void *amax, void *stream) {
     if (N <= 0 || (C & 3) || argmax == nullptr || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RN_EINVAL;
     if (relu_mask < 0 || relu_mask > 2 || (relu_mask == 2 && (C & 31))) return RN_EINVAL;
     const int64_t total = (int64_t)N * H * W * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy),
                        reinterpret_cast<const uchar4 *>(argmax), reinterpret_cast<float4 *>(dx), H, W, C / 4, Ho, Wo, relu_mask,
-                       total);
+                       total, reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -404,7 +410,7 @@ extern "C" int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out
 
 // ------------------------------------------------------------------------------------------------ FPN top-down backward
 __global__ void upsample_add_bwd_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int Hs, int Ws, int Hd, int Wd,
-                                        int C4, int64_t total) {
+                                        int C4, int64_t total, unsigned *__restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over N*Hd*Wd*C4
     if (i >= total) return;
     const int c = (int)(i % C4);
@@ -427,13 +433,15 @@ __global__ void upsample_add_bwd_kernel(const float4 *__restrict__ src, float4 *
         }
     }
     dst[i] = a;
+    rn_amax_note(amax, n, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
 }
 
-extern "C" int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *stream) {
+extern "C" int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *amax, void *stream) {
     if (N <= 0 || (C & 3)) return RN_EINVAL;
     const int64_t total = (int64_t)N * Hd * Wd * (C / 4);
     hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(rn_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), Hs, Ws, Hd, Wd, C / 4, total);
+                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), Hs, Ws, Hd, Wd, C / 4, total,
+                       reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -451,37 +459,43 @@ extern "C" int rn_relu_mask(float *g, const float *z, int64_t n, void *stream) {
 }
 
 __global__ void sigmoid_bwd_pad_kernel(const float *__restrict__ dy, const float *__restrict__ s, float *__restrict__ out,
-                                       int64_t rows, int64_t rpi, int C, int ld, int64_t bstride) {
+                                       int64_t rows, int64_t rpi, int C, int ld, int64_t bstride, unsigned *__restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * ld) return;
     const int64_t r = i / ld;
     const int c = (int)(i - r * ld);
+    const int64_t b = r / rpi;
     float v = 0.f;
     if (c < C) {
-        const int64_t b = r / rpi;
         const int64_t src = b * bstride + (r - b * rpi) * C + c;
         v = dy[src];
         if (s) { const float p = s[src]; v *= p * (1.0f - p); }
     }
     out[i] = v;
+    rn_amax_note(amax, b, fabsf(v));
 }
 extern "C" int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int B, int64_t rows_per_image, int C, int ld,
-                                  int64_t src_batch_stride, void *stream) {
+                                  int64_t src_batch_stride, void *amax, void *stream) {
     const int64_t rows = (int64_t)B * rows_per_image;
     if (rows <= 0 || C <= 0 || ld < C) return RN_EINVAL;
     hipLaunchKernelGGL(sigmoid_bwd_pad_kernel, dim3(rn_blocks(rows * ld, 256)), dim3(256), 0, (hipStream_t)stream, dy, s, out,
-                       rows, rows_per_image, C, ld, src_batch_stride);
+                       rows, rows_per_image, C, ld, src_batch_stride, reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
 
-__global__ void add_inplace_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n) {
+__global__ void add_inplace_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n, int64_t per_image, unsigned *__restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] += src[i];
+    if (i >= n) return;
+    const int64_t img = amax != nullptr ? i / per_image : 0;
+    const float v = dst[i] + src[i];
+    dst[i] = v;
+    rn_amax_note(amax, img, fabsf(v));
 }
-extern "C" int rn_add_inplace(float *dst, const float *src, int64_t n, void *stream) {
-    if (n <= 0) return RN_EINVAL;
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(rn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+extern "C" int rn_add_inplace(float *dst, const float *src, int64_t n, int64_t per_image, void *amax, void *stream) {
+    if (n <= 0 || (amax != nullptr && per_image <= 0)) return RN_EINVAL;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(rn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, per_image,
+                       reinterpret_cast<unsigned *>(amax));
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

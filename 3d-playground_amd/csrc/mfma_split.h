@@ -144,6 +144,11 @@ __host__ __device__ __forceinline__ int rn_f16_scale_exp(unsigned amax_bits) {
     const int se = 268 - e;                                  // 127 + 14 - (e - 127)
     return se > 253 ? 253 : se;
 }
+__host__ __device__ __forceinline__ int rn_f16_scale_exp_of(int e) {          // the same from the exponent field itself
+    if (e <= 0) return 127;
+    const int se = 268 - e;
+    return se > 253 ? 253 : se;
+}
 __device__ __forceinline__ float rn_exp_to_float(int biased) { return __builtin_bit_cast(float, (unsigned)biased << 23); }
 
 // Two values at a time: t = x*s; hi = cvt_pk_f16(t0, t1); lo = cvt_pk_f16(fma(x0, s, -hi0), fma(x1, s, -hi1)) -- the fma re-forms x*s
@@ -199,35 +204,72 @@ __device__ __forceinline__ void split_store_chunk_h(const float *__restrict__ sr
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16((A).h, (B).h, ACC, 0, 0, 0);         \
     } while (0)
 
-// amax words of a tensor: per IMAGE the largest |element| as fp32 bits (monotone as unsigned), accumulated by atomic max at device
-// scope.  Per image, not per tensor, so that the scales -- and with them every bit of an image's result -- do not depend on which other
-// images share the launch (tests/test_gpu_batch8.py pins that).  A consumer uses only a word's EXPONENT (rn_f16_scale_exp), so a
-// producer whose maximum does not raise the exponent skips the atomic -- after the first few waves of a launch almost all do; what a
-// word holds at the end is the exact exponent with some lower bound of the mantissa: deterministic where it matters.
+// AMAX TABLES of a tensor (rn_conv_desc.x_amax / y_amax): per IMAGE, which binary exponents its elements have -- 256 bytes, byte e != 0
+// iff some element's fp32 exponent field is e.  That is all a consumer needs (rn_f16_scale_exp takes the LARGEST exponent: the scale is
+// a power of two), and it makes the producer side free of atomics and of read-backs:
+//   * a producer lane that has stored values with largest magnitude v writes the byte  table[image][exponent(v)] = 1  -- a plain store,
+//     idempotent, no ordering between lanes, waves or launches needed (the parity classes of a stride-2 data gradient, an accumulation
+//     in place: later launches just add bytes); lines written on several XCDs merge byte-wise when the kernel ends;
+//   * a consumer wave reads the image's 256 bytes as one dword per lane and takes the highest non-zero byte (rn_amax_exp).
+// Per image, not per tensor, so that the scales -- and with them every bit of an image's result -- do not depend on which other images
+// share the launch (tests/test_gpu_batch8.py pins that); exact and deterministic: the largest exponent present, nothing else.
+// History of the round (profiles/r05_amax_protocol_ab.txt): one word per image raised by atomic max -- filtered by a read-back, at
+// device scope or inside the XCD's L2, per wave or per workgroup -- cost 7 to 20 % of the training step: the workgroups of a launch's
+// first round all read the word before any has raised it and their same-address atomics retire one after the other, and a read-back
+// early in an epilogue holds up every later load of the wave (vmcnt returns in order); fire-and-forget atomics were 2x slower still.
+#define RN_AMAX_BYTES 256
 __device__ __forceinline__ float rn_wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
-// one lane's maximum into word n (any subset of the wave)
-__device__ __forceinline__ void rn_amax_lane(void *words, int64_t n, float v) {
-    unsigned *p = reinterpret_cast<unsigned *>(words) + n;
-    const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
-    const unsigned seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((b >> 23) > (seen >> 23)) atomicMax(p, b);
+// producer: this lane stored values of largest magnitude v in image n
+#ifndef RN_AMAX_KO               // knock-out (timing only, wrong scales downstream): producers write nothing
+#define RN_AMAX_KO 0
+#endif
+__device__ __forceinline__ void rn_amax_note(void *tables, int64_t n, float v) {
+    if (tables == nullptr || RN_AMAX_KO) return;
+    reinterpret_cast<unsigned char *>(tables)[n * RN_AMAX_BYTES + ((__builtin_bit_cast(unsigned, v) >> 23) & 0xffu)] = 1;
 }
-// a whole wave's maximum into word n (all 64 lanes active, n wave-uniform)
-__device__ __forceinline__ void rn_amax_commit(void *words, int64_t n, float lane_max) {
-    if (words == nullptr) return;
-    unsigned *p = reinterpret_cast<unsigned *>(words) + n;
-    const unsigned seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned b = __builtin_bit_cast(unsigned, rn_wave_max(lane_max)) & 0x7fffffffu;
-    if ((threadIdx.x & 63) == 0 && (b >> 23) > (seen >> 23)) atomicMax(p, b);
+// consumer: the largest exponent field present in image n's table; all 64 lanes of the wave take part, the result is wave-uniform
+__device__ __forceinline__ int rn_amax_exp(const void *tables, int64_t n) {
+    const unsigned d = reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(tables) + n * RN_AMAX_BYTES)[threadIdx.x & 63];
+    int e = d ? 4 * (int)(threadIdx.x & 63) + ((31 - __builtin_clz(d)) >> 3) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(e, off, 64); e = o > e ? o : e; }
+    return __builtin_amdgcn_readfirstlane(e);
 }
-// the word of a tensor derived from another's by a linear map whose gain is below 2^gain_log2 (the Winograd transforms): exponent + gain
-__host__ __device__ __forceinline__ unsigned rn_amax_gain(unsigned word, int gain_log2) {
-    const int e = (int)((word >> 23) & 0xffu);
-    if (e == 0) return 0u;
+// the same over images 0 .. count-1 (the weight gradient: one scale for a reduction that runs over all images)
+__device__ __forceinline__ int rn_amax_exp_all(const void *tables, int count) {
+    int e = 0;
+    for (int i = 0; i < count; ++i) {
+        const unsigned d = reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(tables) + (int64_t)i * RN_AMAX_BYTES)[threadIdx.x & 63];
+        const int ei = d ? 4 * (int)(threadIdx.x & 63) + ((31 - __builtin_clz(d)) >> 3) : 0;
+        e = ei > e ? ei : e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(e, off, 64); e = o > e ? o : e; }
+    return __builtin_amdgcn_readfirstlane(e);
+}
+// every lane gets the exponent of ITS OWN table (table_lane = tables + image * RN_AMAX_BYTES; nullptr: 0) -- the lanes of a wave lie in
+// one or two images, rarely more; all 64 lanes take part
+__device__ __forceinline__ int rn_amax_exp_lanes(const void *table_lane) {
+    const unsigned long long me = (unsigned long long)(uintptr_t)table_lane;
+    int mine = 0;
+    unsigned long long pending = __ballot(table_lane != nullptr);
+    while (pending != 0ull) {
+        const int first = __builtin_ctzll(pending);
+        const unsigned long long p0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(me >> 32), first) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)me, first);
+        const int e0 = rn_amax_exp(reinterpret_cast<const void *>((uintptr_t)p0), 0);
+        if (me == p0) mine = e0;
+        pending &= ~__ballot(me == p0);
+    }
+    return mine;
+}
+// a word (fp32 bit pattern) with exponent field e and a full mantissa: what the derived (Winograd-domain) words are made of
+__host__ __device__ __forceinline__ unsigned rn_amax_word_of_exp(int e, int gain_log2) {
+    if (e <= 0) return 0u;
     const int g = e + gain_log2 > 254 ? 254 : e + gain_log2;
     return ((unsigned)g << 23) | 0x7fffffu;
 }

@@ -125,15 +125,15 @@ SIGNATURES.update({
     "rn_pack_weights": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp] + [c_i32] * 4 + [c_vp]),
     "rn_unpack_wgrad": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp] * 7),
     "rn_bn_fold": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "rn_nchw_to_nhwc4": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "rn_nchw_to_nhwc4": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rn_maxpool_fwd": (c_i32, [c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
-    "rn_maxpool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
+    "rn_maxpool_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
     "rn_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rn_colsum_workspace_bytes": (c_i64, [c_i64, c_i32]),
-    "rn_upsample_add_bwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp]),
+    "rn_upsample_add_bwd": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_vp, c_vp]),
     "rn_relu_mask": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
-    "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp]),
-    "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rn_sigmoid_bwd_pad": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp]),
+    "rn_add_inplace": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rn_wino_input": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp]),
     "rn_wino_output": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "rn_wino_weights": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -253,14 +253,27 @@ def _w_operand(w_packed, d=None):
 _AMAX_CHUNK = {}
 
 
-def amax_slot(device, n=1):
-    """n fresh zeroed amax words (int32 tensor) on `device`."""
+AMAX_SUB = 64                                    # int32 words of one image's exponent table (csrc/mfma_split.h: RN_AMAX_BYTES = 256)
+
+
+def _amax_alloc(device, nwords):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
+    nwords = (nwords + 7) // 8 * 8                    # blocks start on 32-byte boundaries
     c = _AMAX_CHUNK.get(key)
-    if c is None or c[1] + n > c[0].numel():
-        c = _AMAX_CHUNK[key] = [torch.zeros(max(4096, n), dtype=torch.int32, device=device), 0]
-    c[1] += n
-    return c[0][c[1] - n:c[1]]
+    if c is None or c[1] + nwords > c[0].numel():
+        c = _AMAX_CHUNK[key] = [torch.zeros(max(1 << 18, nwords), dtype=torch.int32, device=device), 0]     # 1 MB: ~500 tensors of 8 images
+    c[1] += nwords
+    return c[0][c[1] - nwords:c[1]]
+
+
+def amax_slot(device, n=1):
+    """Fresh zeroed amax words for a tensor of n images (AMAX_SUB sub-words each) on `device`."""
+    return _amax_alloc(device, n * AMAX_SUB)
+
+
+def amax_single(device):
+    """One fresh zeroed plain word (a Winograd-domain tensor's, for the weight gradient)."""
+    return _amax_alloc(device, 1)[:1]
 
 
 def amax_attach(t, words):
@@ -271,13 +284,21 @@ def amax_attach(t, words):
 def amax_words(t):
     """The amax words [N] of a dense fp32 tensor [N, ...]: its producer's (see above) or computed now (cached on the tensor object)."""
     a = getattr(t, "_rn_amax", None)
-    if a is not None and a[1] == t._version and a[0].numel() == t.shape[0]:
+    if a is not None and a[1] == t._version and a[0].numel() == t.shape[0] * AMAX_SUB:
         return a[0]
     assert t.is_contiguous() and t.dtype == torch.float32
     words = amax_slot(t.device, t.shape[0])
     if t.numel():
         _hip.check(_hip.load().rn_amax(t.data_ptr(), t.numel() // t.shape[0], t.shape[0], words.data_ptr(), _hip.stream()), "rn_amax")
     return amax_attach(t, words)
+
+
+def amax_carry(view, src):
+    """A reshaped view of a tensor whose producer left amax words (the padded head-gradient slices) takes them along."""
+    w = getattr(src, "_rn_amax_words", None)
+    if w is not None and w.numel() == view.shape[0] * AMAX_SUB:
+        amax_attach(view, w)
+    return view
 
 
 def amax_drop(t):
@@ -313,7 +334,8 @@ def set_deterministic(on=True):
 def _wgrad_call(lib, dev, dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, geom, amax=(None, None)):
     """rn_conv_wgrad_batched, or its fixed-order form with a slab workspace when the deterministic option is on.
     geom = (N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, in_relu); amax = the amax words of (dy, x) (split3 mode) or Nones."""
-    am = (_hip.ptr(amax[0]), 0 if amax[0] is None else amax[0].numel(), _hip.ptr(amax[1]), 0 if amax[1] is None else amax[1].numel())
+    cnt = lambda a: 0 if a is None else (-1 if a.numel() == 1 else a.numel() // AMAX_SUB)      # tables of n images, or one plain word
+    am = (_hip.ptr(amax[0]), cnt(amax[0]), _hip.ptr(amax[1]), cnt(amax[1]))
     if not lib.rn_get_option(OPT_DETERMINISTIC):
         return lib.rn_conv_wgrad_batched(dy_ptr, ldy, x_ptr, dw_ptr, cs_ptr, nbatch, dy_bs, x_bs, dw_bs, cs_batch, *geom, *am, _hip.stream())
     N, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw = geom[:9]
@@ -369,7 +391,7 @@ def _wino_transform_in(xs, V, C, Tpad, dy_form, want_rows=False, want_tensor=Fal
     off = 0
     am = want_amax() and (want_rows or want_tensor)
     rows = torch.zeros(Tpad, dtype=torch.int32, device=V.device) if am and want_rows else None
-    tword = amax_slot(V.device) if am and want_tensor else None
+    tword = amax_single(V.device) if am and want_tensor else None
     for k in range(0, len(xs), _hip.RN_MAX_GROUP):
         part = xs[k:k + _hip.RN_MAX_GROUP]
         t = sum(x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in part)
@@ -489,7 +511,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
         am_on = want_amax()
         g = _wino_group(gs, srcs=gs, amaxs=[amax_words(t) for t in gs] if am_on else None)
         vd_rows = torch.zeros(Tpad, dtype=torch.int32, device=dev) if am_on else None
-        z_tw = amax_slot(dev) if am_on else None
+        z_tw = amax_single(dev) if am_on else None
         nb = 4.0 * (sum(t.numel() for t in gs) + 2 * 36 * T * cout)
         _hip.check(prof.timed("wino_input", nb, lambda: lib.rn_wino_input_both_group(
             ctypes.byref(g), Vd.data_ptr(), Z.data_ptr(), cout, 0, Tpad, _hip.ptr(vd_rows), _hip.ptr(z_tw), _hip.stream())),
@@ -668,7 +690,10 @@ def nchw_to_nhwc4(img):
     if C != 3:
         raise RuntimeError("the stem takes 3-channel images (D/model.py:213), got %d" % C)
     out = torch.empty((N, H, W, 4), dtype=torch.float32, device=img.device)
-    _hip.check(lib.rn_nchw_to_nhwc4(img.data_ptr(), out.data_ptr(), N, H, W, _hip.stream()), "rn_nchw_to_nhwc4")
+    am = amax_slot(img.device, N) if want_amax() else None
+    _hip.check(lib.rn_nchw_to_nhwc4(img.data_ptr(), out.data_ptr(), N, H, W, _hip.ptr(am), _hip.stream()), "rn_nchw_to_nhwc4")
+    if am is not None:
+        amax_attach(out, am)
     return out
 
 
@@ -681,6 +706,9 @@ def maxpool_fwd(x, want_argmax=False):
     arg = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if want_argmax else None
     _hip.check(lib.rn_maxpool_fwd(x.data_ptr(), y.data_ptr(), _hip.ptr(arg), N, H, W, C, Ho, Wo, _hip.stream()),
                "rn_maxpool_fwd")
+    a = getattr(x, "_rn_amax", None)
+    if a is not None and a[1] == x._version:         # every input pixel lies in a window: for the ReLU outputs it pools, the pooled
+        amax_attach(y, a[0])                         # tensor's largest magnitude per image is the input's (in general: at most it)
     return (y, arg) if want_argmax else y
 
 
@@ -689,9 +717,12 @@ def maxpool_bwd(x, dy, argmax, relu_mask=True):
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
     bits = getattr(x, "_rn_sign", None) if (relu_mask and BITMASKS) else None      # the stem's sign bits instead of re-reading it
+    am = amax_slot(x.device, N) if want_amax() else None
     _hip.check(lib.rn_maxpool_bwd(x.data_ptr() if bits is None else bits.data_ptr(), dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(),
-                                  N, H, W, C, dy.shape[1], dy.shape[2], (2 if bits is not None else int(relu_mask)), _hip.stream()),
-               "rn_maxpool_bwd")
+                                  N, H, W, C, dy.shape[1], dy.shape[2], (2 if bits is not None else int(relu_mask)), _hip.ptr(am),
+                                  _hip.stream()), "rn_maxpool_bwd")
+    if am is not None:
+        amax_attach(dx, am)
     return dx
 
 
@@ -714,10 +745,17 @@ def upsample_add_bwd(src, dst):
     """dst[n,h,w,:] += sum of the (in-bounds) 2x2 children in src."""
     lib = _hip.load()
     N, Hs, Ws, C = src.shape
-    fn = lib.rn_upsample_add_bwd_bf16 if src.dtype == torch.bfloat16 else lib.rn_upsample_add_bwd
     assert src.dtype == dst.dtype
-    _hip.check(fn(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C, _hip.stream()), "rn_upsample_add_bwd")
     amax_drop(dst)
+    if src.dtype == torch.bfloat16:
+        _hip.check(lib.rn_upsample_add_bwd_bf16(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C, _hip.stream()),
+                   "rn_upsample_add_bwd_bf16")
+        return dst
+    am = amax_slot(dst.device, N) if want_amax() else None      # the sums' own amax words (the old ones no longer bound them)
+    _hip.check(lib.rn_upsample_add_bwd(src.data_ptr(), dst.data_ptr(), N, Hs, Ws, dst.shape[1], dst.shape[2], C, _hip.ptr(am), _hip.stream()),
+               "rn_upsample_add_bwd")
+    if am is not None:
+        amax_attach(dst, am)
     return dst
 
 
@@ -732,14 +770,25 @@ def sigmoid_bwd_pad(dy_ptr, s_ptr, B, rows_per_image, C, ld, src_batch_stride, d
     multiplied by s(1-s) when the sigmoid output pointer is given."""
     lib = _hip.load()
     out = torch.empty((B * rows_per_image, ld), dtype=torch.bfloat16 if bf16 else torch.float32, device=device)
-    fn = lib.rn_sigmoid_bwd_pad_bf16 if bf16 else lib.rn_sigmoid_bwd_pad
-    _hip.check(fn(dy_ptr, s_ptr, out.data_ptr(), B, rows_per_image, C, ld, src_batch_stride, _hip.stream()), "rn_sigmoid_bwd_pad")
+    if bf16:
+        _hip.check(lib.rn_sigmoid_bwd_pad_bf16(dy_ptr, s_ptr, out.data_ptr(), B, rows_per_image, C, ld, src_batch_stride, _hip.stream()),
+                   "rn_sigmoid_bwd_pad_bf16")
+        return out
+    am = amax_slot(device, B) if want_amax() else None
+    _hip.check(lib.rn_sigmoid_bwd_pad(dy_ptr, s_ptr, out.data_ptr(), B, rows_per_image, C, ld, src_batch_stride, _hip.ptr(am), _hip.stream()),
+               "rn_sigmoid_bwd_pad")
+    if am is not None:
+        out._rn_amax_words = am                      # the caller reshapes to [B, H, W, ld]: amax_carry(view, out) hands the words on
     return out
 
 
 def add_(dst, src):
-    _hip.check(_hip.load().rn_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), _hip.stream()), "rn_add_inplace")
     amax_drop(dst)
+    am = amax_slot(dst.device, dst.shape[0]) if want_amax() and dst.dim() == 4 else None
+    _hip.check(_hip.load().rn_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), dst.numel() // max(dst.shape[0], 1), _hip.ptr(am),
+                                          _hip.stream()), "rn_add_inplace")
+    if am is not None:
+        amax_attach(dst, am)
     return dst
 
 

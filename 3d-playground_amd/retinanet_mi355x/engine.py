@@ -651,8 +651,8 @@ class Engine:
             add(2, j, src.numel())
             return dst
 
-        mode = cv.get_fp32_mfma()
-        presplit = cv.PRESPLIT and mode != "native" and not self.bf16
+        fp32_mode = cv.get_fp32_mfma()                # ("mode" is a loop variable further down)
+        presplit = cv.PRESPLIT and fp32_mode != "native" and not self.bf16
 
         def split_job(src, force=False, f16=None):
             """split modes: the pre-split twin of a packed fp32 buffer (cv.split_weights' / split_weights_f16's attribute), filled by
@@ -664,7 +664,7 @@ class Engine:
             rows = src.numel() // src.shape[-1]
             j = _hip.PrepJob()
             j.rows, j.Kpad, j.src = rows, src.shape[-1], src.data_ptr()
-            if not force and mode == "split3" and f16 is not None and cv.f16_shape_ok(*f16):
+            if not force and fp32_mode == "split3" and f16 is not None and cv.f16_shape_ok(*f16):
                 dst = (torch.empty(src.numel() * 4, dtype=torch.uint8, device=dev), torch.empty(rows, dtype=torch.float32, device=dev))
                 j.kind, j.dst, j.bn_scale = 5, dst[0].data_ptr(), dst[1].data_ptr()
                 add(2, j, (rows + 3) // 4 * 256)
@@ -1034,7 +1034,7 @@ class Engine:
                     g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
                                            B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device,
                                            bf16=self.bf16)
-                    gs.append(g.view(B, Hh, Ww, Lout.cout_pad))
+                    gs.append(cv.amax_carry(g.view(B, Hh, Ww, Lout.cout_pad), g))
                     off += cnt
                 Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
                 gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])

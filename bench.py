@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TF = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TF = 2500.0        # dense bf16 MFMA (same guide): the kernels of --dtype bf16, and --
 PEAK_SPLIT_TF = PEAK_BF16_MFMA_TF / 6   # -- the fp32 kernels in split-operand mode: six bf16 MFMAs per fp32 product (csrc/mfma_split.h)
+PEAK_SPLIT3_TF = PEAK_BF16_MFMA_TF / 3  # -- and in split3 mode: three fp16 MFMAs (same rate as bf16) per fp32 product
 PEAK_HBM_GBS = 8000.0             # HBM3E spec; 6.29 TB/s measured copy
 
 
@@ -69,7 +70,7 @@ def parse():
                     help="headline: ONLY the benchmark's own steps (warm-up, timed steps, the same steps with per-kernel events) -- no "
                          "native-MFMA / bf16 / fp8 sections, no forward-only passes, no loss micro-benchmark -- so that a rocprofv3 "
                          "--kernel-trace --stats of this command divides by (warmup + 2 * steps) into the line's kernels.*.ms_per_step")
-    ap.add_argument("--fp32-mfma", default="", choices=["", "split", "native"],
+    ap.add_argument("--fp32-mfma", default="", choices=["", "split", "split3", "native"],
                     help="how the fp32 convolution kernels form their products (include/retinanet_mi355x.h: RN_FP32_SPLIT / "
                          "RN_FP32_NATIVE); default: the library's (RN_FP32_DEFAULT, or the environment's RN_FP32_MFMA)")
     ap.add_argument("--graph", action="store_true",
@@ -554,8 +555,8 @@ def main():
     if args.fp32_mfma:
         cv.set_fp32_mfma(args.fp32_mfma)
     fp32_mode = cv.get_fp32_mfma()
-    split = fp32_mode == "split" and args.dtype == "fp32"
-    conv_peak = PEAK_SPLIT_TF if split else PEAK_F32_MFMA_TF      # what the fp32 conv kernels are priced against
+    split = fp32_mode in ("split", "split3") and args.dtype == "fp32"
+    conv_peak = (PEAK_SPLIT3_TF if fp32_mode == "split3" else PEAK_SPLIT_TF) if split else PEAK_F32_MFMA_TF      # what the fp32 conv kernels are priced against
 
     net = getattr(modules, args.arch)(num_classes=8)
     net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))          # same weights on every rank

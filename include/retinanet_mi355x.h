@@ -269,17 +269,18 @@ typedef struct rn_conv_desc {
                                       = (y[e] > 0) for every stored element at float offset e -- what the backward pass needs of a ReLU
                                       output (D/utils.py:60-80), at 1/32 of the bytes.  Needs Cout % 32 == 0 and y_batch_stride % 32
                                       == 0.  mask_mode | RN_MASK_BITS (4): `mask` points to such words (the consumer's side). */
-    const void *x_amax;            /* RN_FP32_SPLIT3 (round 5): the AMAX WORDS of x -- uint32 words each holding the fp32 bit pattern of a value
-                                      whose exponent is that of the largest |element| of one IMAGE of x (what a producer's y_amax left, or
-                                      rn_amax) -- from which the kernel takes the power-of-two scales of its fp16 split, row by row: the word
-                                      of GEMM row (image n, pixel r of it) is x_amax[n * x_amax_img_stride + r * x_amax_row_stride].
-                                      (1, 0): one word per image, the usual form -- an image's result then does not depend on what else
-                                      is in the batch; (0, 1): one word per row, the same for every "image": the Winograd-stage GEMM, whose
-                                      rows are tiles (rn_wino_input_group writes them).  Required when w_format == 3. */
-    void *y_amax;                  /* NULL, or the amax words of the RESULT, one per image [N]: every kernel that finishes elements raises
-                                      word n (atomic max at device scope) to the largest |y| it stored in image n; the caller zeroes them
-                                      before the launch.  Any product mode; not by the raw Winograd-stage GEMM (its result feeds a
-                                      transform, not a convolution). */
+    const void *x_amax;            /* RN_FP32_SPLIT3 (round 5): the AMAX TABLES of x: per image 256 bytes, byte e != 0 iff some element of the
+                                      image has fp32 exponent field e (what a producer's y_amax left, or rn_amax) -- the kernel takes the
+                                      largest exponent present as the image's power-of-two scale for its fp16 split, row by row: GEMM
+                                      row (image n, pixel r) uses table n * x_amax_img_stride when x_amax_row_stride == 0 (the usual
+                                      form, img stride 1: an image's result then does not depend on what else is in the batch), or the
+                                      plain uint32 WORD x_amax[r * x_amax_row_stride] (an fp32 bit pattern whose exponent field bounds
+                                      the row) when it is not: the Winograd-stage GEMM, whose rows are tiles (rn_wino_input_group
+                                      writes the words).  Required when w_format == 3. */
+    void *y_amax;                  /* NULL, or the amax tables of the RESULT, one per image [N][256]: every kernel that finishes elements
+                                      sets the byte of the largest exponent it stored in image n (plain stores, idempotent: several
+                                      launches may fill one tensor); the caller zeroes the tables before the first.  Any product mode;
+                                      not by the raw Winograd-stage GEMM (its result feeds a transform, not a convolution). */
     const float *w_unscale;        /* w_format == 3: per weight row the inverse 2^-s of the power-of-two scale its fp16 terms were
                                       written with (rn_split_weights_f16); [batch * Cout] when w_batch_stride != 0 */
     int x_amax_img_stride, x_amax_row_stride;
@@ -345,8 +346,9 @@ int rn_split_weights(const float *w_packed, void *w_split, int64_t rows, int Kpa
  * a K-step, written with the row's own power-of-two scale (largest |value| of the row -> [2^14, 2^15)); row_unscale[rows] receives
  * the inverse scales.  Pass as w_packed with rn_conv_desc.w_format = 3 and w_unscale = row_unscale.  (rn_prep_batched: job kind 5.) */
 int rn_split_weights_f16(const float *w_packed, void *w_split, float *row_unscale, int64_t rows, int Kpad, void *stream);
-/* The amax words of a tensor (rn_conv_desc.x_amax) for tensors no producer left them for: x = n_images images of per_image floats,
- * amax[i] = max(amax[i], bits of the largest |element| of image i); zero the words first.  One pass over x. */
+/* The amax tables of a tensor (rn_conv_desc.x_amax) for tensors no producer left them for: x = n_images images of per_image floats,
+ * amax = [n_images][256] bytes, byte e of table i set when an element of image i has exponent field e (only the largest matters; the
+ * kernel sets the largest per thread); zero the tables first.  One pass over x. */
 int rn_amax(const float *x, int64_t per_image, int n_images, void *amax, void *stream);
 /* 1 when rn_conv_igemm would run this problem on an fp16-split kernel in RN_FP32_SPLIT3 mode (so: wants w_format 3, x_amax, w_unscale),
  * 0 when it keeps the three-term kernels (w_format 0 / 1).  Depends on the geometry only. */
@@ -399,9 +401,10 @@ int rn_conv_wgrad_batched(const float *dy, int ldy, const float *x, float *dw, f
                           int64_t dy_bstride, int64_t x_bstride, int64_t dw_bstride, int colsum_batch, int N, int Hi, int Wi,
                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int in_relu,
                           const void *dy_amax, int dy_amax_n, const void *x_amax, int x_amax_n, void *stream);
-/* dy_amax / x_amax (round 5): the amax words of the two operands (rn_conv_desc.x_amax) and how many there are (one per image; one for a
- * whole Winograd-domain tensor, whatever the batch) -- with both given, RN_FP32_SPLIT3 mode runs the fp16 two-term kernels, each
- * operand scaled by the power of two of its LARGEST word (the reduction runs over all images); NULL: the three-term kernels. */
+/* dy_amax / x_amax (round 5): the amax of the two operands: count > 0 = amax tables (rn_conv_desc.x_amax) of that many images;
+ * count -1 = ONE plain uint32 word (an fp32 bit pattern whose exponent field bounds the tensor: a Winograd-domain tensor's, whatever the
+ * batch) -- with both given, RN_FP32_SPLIT3 mode runs the fp16 two-term kernels, each operand scaled by the power of two of its LARGEST
+ * exponent (the reduction runs over all images); NULL: the three-term kernels. */
 /* The same reduction in a FIXED order (RN_OPT_DETERMINISTIC; the host logic selects it when the option is on): every K slice
  * stores its partial result into its own slab of `workspace` (plain stores) and one ordered pass adds slabs 0, 1, 2 ... and the
  * slices' column sums into dw / colsum: bit-identical from run to run, as the reference's CPU autograd is.  Costs one write and
@@ -611,17 +614,20 @@ int rn_bn_fold(const float *gamma, const float *beta, const float *mean, const f
  *                       padded [B*rows_per_image, ld] matrix the GEMMs accept
  *   rn_add_inplace:     dst += src
  */
-int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *stream);
+int rn_nchw_to_nhwc4(const float *src, float *dst, int N, int H, int W, void *amax, void *stream);
 int rn_maxpool_fwd(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo, void *stream);
 int rn_maxpool_bwd(const float *x, const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
-                   int Ho, int Wo, int relu_mask, void *stream);
+                   int Ho, int Wo, int relu_mask, void *amax, void *stream);
 int rn_colsum(const float *g, int64_t rows, int C, int ld, float *out, int accumulate, void *workspace, void *stream);
 int64_t rn_colsum_workspace_bytes(int64_t rows, int C);
-int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *stream);
+int rn_upsample_add_bwd(const float *src, float *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, void *amax, void *stream);
 int rn_relu_mask(float *g, const float *z, int64_t n, void *stream);
 int rn_sigmoid_bwd_pad(const float *dy, const float *s, float *out, int B, int64_t rows_per_image, int C, int ld,
-                       int64_t src_batch_stride, void *stream);
-int rn_add_inplace(float *dst, const float *src, int64_t n, void *stream);
+                       int64_t src_batch_stride, void *amax, void *stream);
+int rn_add_inplace(float *dst, const float *src, int64_t n, int64_t per_image, void *amax, void *stream);
+/* `amax` of rn_nchw_to_nhwc4 / rn_maxpool_bwd / rn_upsample_add_bwd / rn_sigmoid_bwd_pad / rn_add_inplace (round 5): NULL, or the amax
+ * words of the tensor the call produces, one per image (rn_conv_desc.y_amax: raised by atomic max; the caller zeroes them first).
+ * rn_add_inplace: image of element i = i / per_image. */
 
 /* ---------------------------------------------------------------- optimizer step ---------------------------
  * clip_grad_norm_(params, max_norm) + Adam(lr, betas, eps).step() of the reference trainer

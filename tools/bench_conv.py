@@ -29,6 +29,8 @@ SHAPES = [  # name, cin, cout, k, stride, pad, H, W
     ("l3 1x1 1024->256", 1024, 256, 1, 1, 0, 68, 120),
     ("l4 3x3 512->512", 512, 512, 3, 1, 1, 34, 60),
     ("l4 1x1 512->2048", 512, 2048, 1, 1, 0, 34, 60),
+    ("l4 1x1 2048->512", 2048, 512, 1, 1, 0, 34, 60),
+    ("l3 1x1 256->1024", 256, 1024, 1, 1, 0, 68, 120),
     ("l2.0 3x3 s2 128->128", 128, 128, 3, 2, 1, 270, 480),
     ("gemm-like 1x1 256->256 P3", 256, 256, 1, 1, 0, 135, 240),      # K = 256: the Winograd stage's GEMM shape per position
     ("ksweep 1x1 64->256 P3", 64, 256, 1, 1, 0, 135, 240),
