@@ -304,7 +304,7 @@ typedef struct rn_conv_desc {
 #define RN_FP32_NATIVE 0
 #define RN_FP32_SPLIT 1
 #define RN_FP32_SPLIT3 2
-#define RN_FP32_DEFAULT RN_FP32_SPLIT
+#define RN_FP32_DEFAULT RN_FP32_SPLIT3
 int rn_get_fp32_mfma(void);
 int rn_set_fp32_mfma(int mode);
 /* Process-wide run-time options; initial value from the environment variable named (read ONCE, at the option's first use --

@@ -482,13 +482,14 @@ def test_presplit_operand_is_refused_in_native_mode(cv, dev):
 
 
 def test_product_mode_follows_the_environment(dev):
-    """RN_FP32_MFMA selects the library's initial mode (include/retinanet_mi355x.h); without it: RN_FP32_DEFAULT = split."""
+    """RN_FP32_MFMA selects the library's initial mode (include/retinanet_mi355x.h); without it: RN_FP32_DEFAULT = split3."""
     import os
     import subprocess
     import sys
     code = "import sys; sys.path.insert(0, %r); from retinanet_mi355x import conv; print(conv.get_fp32_mfma())" % os.path.join(
         os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-playground_amd")
-    for env, want in (({"RN_FP32_MFMA": "native"}, "native"), ({"RN_FP32_MFMA": "split"}, "split"), ({}, "split")):
+    for env, want in (({"RN_FP32_MFMA": "native"}, "native"), ({"RN_FP32_MFMA": "split"}, "split"), ({"RN_FP32_MFMA": "split3"}, "split3"),
+                      ({}, "split3")):
         e = {k: v for k, v in os.environ.items() if k != "RN_FP32_MFMA"}
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
