@@ -344,11 +344,14 @@ def fp8_main(args, dev, rank, world):
         dist.destroy_process_group()
 
 
-def native_section(dev, args, B, H, W):
-    """Supplementary: the SAME training step with the fp32 convolutions on v_mfma_f32_32x32x2_f32 (RN_FP32_NATIVE), on this GPU
-    in this run -- the reader's yardstick for the split-operand headline."""
+def native_section(dev, args, B, H, W, mode="native"):
+    """Supplementary: the SAME training step with the fp32 convolutions in another product mode -- "native": v_mfma_f32_32x32x2_f32
+    (RN_FP32_NATIVE), "split": three bf16 terms / six MFMAs (RN_FP32_SPLIT, the default of rounds 2-4) -- on this GPU in this run:
+    the reader's yardsticks for the headline."""
     from retinanet_mi355x import conv as cv, modules, optim, prof, synth
-    cv.set_fp32_mfma("native")
+    before = cv.get_fp32_mfma()
+    cv.set_fp32_mfma(mode)
+    peak = PEAK_F32_MFMA_TF if mode == "native" else PEAK_SPLIT_TF
     try:
         net = getattr(modules, args.arch)(num_classes=8)
         net.load_state_dict(synth.state_dict(args.arch, 8, 12, seed=2))
@@ -376,7 +379,8 @@ def native_section(dev, args, B, H, W):
         torch.cuda.synchronize()
         dt = time.time() - t0
         out = {"value": round(B * n / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / n, 2), "steps": n,
-               "final_loss": round(float(loss.detach()), 5), "products": "v_mfma_f32_32x32x2_f32"}
+               "final_loss": round(float(loss.detach()), 5),
+               "products": "v_mfma_f32_32x32x2_f32" if mode == "native" else "three bf16 terms per operand, six v_mfma_f32_*_bf16 per product"}
         t = prof.ACTIVE = prof.KernelTimer()
         for _ in range(2):
             step()
@@ -386,7 +390,7 @@ def native_section(dev, args, B, H, W):
             a = summ.get(kind)
             if a and a["ms_total"] > 0:
                 tf = a["work_total"] / (a["ms_total"] * 1e-3) / 1e12
-                out[kind] = {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TF, 4),
+                out[kind] = {"achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                              "ms_per_step": round(a["ms_total"] / 2, 2)}
         # north_star's forward target on the fp32 MFMA: conv kernels of forward-only passes, DIRECT kernels everywhere
         eng = net._engine
@@ -401,13 +405,13 @@ def native_section(dev, args, B, H, W):
         fwork, fms = sum(a["work_total"] for a in fs), sum(a["ms_total"] for a in fs)
         if fms > 0:
             ftf = fwork / (fms * 1e-3) / 1e12
-            out["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                                    "frac": round(ftf / PEAK_F32_MFMA_TF, 4), "ms_per_pass": round(fms / 3, 2),
+            out["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                    "frac": round(ftf / peak, 4), "ms_per_pass": round(fms / 3, 2),
                                     "gflop_per_image": round(fwork / 3 / B / 1e9, 1)}
         return out
     finally:
         prof.ACTIVE = None
-        cv.set_fp32_mfma("split")
+        cv.set_fp32_mfma(before)
 
 
 def pmc_traffic(kind):
@@ -678,13 +682,19 @@ def main():
                                    "value_eager_label_check: the library's default, one host read per step as the reference's loss raises "
                                    "inside the forward")
         if args.dtype == "fp32":
-            line["config"]["fp32_products"] = (
-                "split operands: every fp32 operand as three bf16 terms (h + m + l == x exactly), six v_mfma_f32_32x32x16_bf16 "
-                "products per block into the fp32 accumulator, dropped terms <= 2^-23 of a product (2^-25 rms); operands, accumulation, "
-                "epilogues, gradients and optimizer fp32; measured against fp64: kernels within -15..+25 % of the fp32 MFMA kernels' error, "
-                "whole-model gradients 7e-7..1e-6 vs 3e-7..5e-7 (DESIGN.md 4.6, profiles/r02_fp32_split_errors.txt, r02_grad_vs_fp64.txt); "
-                "fp32_native_mfma below = the same step on v_mfma_f32_32x32x2_f32"
-                if split else "v_mfma_f32_32x32x2_f32")
+            line["config"]["fp32_products"] = {
+                "split3": "split operands, two fp16 terms: every fp32 operand, scaled by a power of two so that its image's (weights: its output "
+                          "channel's) largest magnitude lands in [2^14, 2^15), as hi + lo fp16 terms (|error| <= 2^-23 of the value down to 2^-18 "
+                          "of that maximum), three v_mfma_f32_16x16x32_f16 / 32x32x16_f16 products per block into the fp32 accumulator; operands, "
+                          "accumulation, epilogues, gradients and optimizer fp32; measured against fp64: rms error of every kernel 0.55-1.17 x the "
+                          "fp32 MFMA kernels' on N(0,1), ReLU and 40-binade data (profiles/r05_fp32_split3_errors.txt), every parity test at the "
+                          "tolerances of the other modes; layers without an fp16 kernel (<= 64 output channels, the 4-channel stem, the padded "
+                          "head-output gradients) run the three-term bf16 form; fp32_split_bf16x3 / fp32_native_mfma below = the same step in "
+                          "the other two modes",
+                "split": "split operands: every fp32 operand as three bf16 terms (h + m + l == x exactly), six v_mfma_f32_32x32x16_bf16 "
+                         "products per block into the fp32 accumulator, dropped terms <= 2^-23 of a product (2^-25 rms); operands, accumulation, "
+                         "epilogues, gradients and optimizer fp32 (DESIGN.md 4.6); fp32_native_mfma below = the same step on v_mfma_f32_32x32x2_f32",
+                "native": "v_mfma_f32_32x32x2_f32"}[fp32_mode]
         if graph_note:
             line["config"]["launch"] = graph_note
         if timer is not None:
@@ -707,8 +717,10 @@ def main():
                                  "frac": round(tf / peak, 4), "launches_per_step": a["launches"] // args.steps,
                                  "ms_per_step": round(a["ms_total"] / args.steps, 2), "avg_launch_ms": round(a["ms_avg"], 4)}
                 if split and not is_bf16:
-                    # achieved = fp32 FLOPs of the convolution; the kernel executes 6 bf16 MFMA FLOPs for each of them
-                    kernels[kind]["peak_note"] = "2500 TF dense bf16 MFMA / 6 MFMAs per fp32 product"
+                    # achieved = fp32 FLOPs of the convolution; the kernel executes 3 (split3) or 6 (split) 16-bit MFMA FLOPs for each of them
+                    kernels[kind]["peak_note"] = ("2500 TF dense fp16 MFMA / 3 MFMAs per fp32 product (launches that run the three-term "
+                                                  "bf16 kernels in this mode execute 6)" if fp32_mode == "split3"
+                                                  else "2500 TF dense bf16 MFMA / 6 MFMAs per fp32 product")
                     kernels[kind]["frac_of_fp32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TF, 4)
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             r = dict(kernels[dom])
@@ -744,12 +756,13 @@ def main():
             eng.use_wino = wino_was
             fwork, fms = sum(a["work_total"] for a in fs), sum(a["ms_total"] for a in fs)
             ftf = fwork / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
-            kernels["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": round(conv_peak, 1),
-                                        "unit": "TFLOP/s", "frac": round(ftf / conv_peak, 4),
+            fpeak = PEAK_BF16_MFMA_TF if args.dtype == "bf16" else conv_peak     # the bf16 engine's convolutions run on the bf16 MFMA
+            kernels["forward_convs"] = {"bound": "mfma", "achieved": round(ftf, 2), "peak": round(fpeak, 1),
+                                        "unit": "TFLOP/s", "frac": round(ftf / fpeak, 4),
                                         "ms_per_pass": round(fms / 3, 2), "gflop_per_image": round(fwork / 3 / B / 1e9, 1)}
             if split:
                 kernels["forward_convs"]["frac_of_fp32_mfma_peak"] = round(ftf / PEAK_F32_MFMA_TF, 4)
-            if wino_was:
+            if wino_was and args.dtype != "bf16":                  # (the bf16 engine never takes the Winograd path)
                 # the forward as the training step runs it (Winograd F(4x4,3x3) in the head towers): same algorithmic FLOPs
                 # over the time of every conv-path kernel, transforms included -- a throughput, not an MFMA utilisation
                 wms = sum(a["ms_total"] for a in forward_passes().values())
@@ -763,9 +776,14 @@ def main():
             if split:
                 try:                                                # supplementary sections never cost the headline its line
                     line["fp32_native_mfma"] = native_section(dev, args, B, H, W)
-                    line["note"] = ("value: fp32 step with split-operand products on the bf16 MFMA (config.fp32_products); the same step "
-                                    "with every product on v_mfma_f32_32x32x2_f32, same run: %s images/sec (fp32_native_mfma)"
-                                    % line["fp32_native_mfma"].get("value"))
+                    if fp32_mode == "split3":
+                        torch.cuda.empty_cache()
+                        line["fp32_split_bf16x3"] = native_section(dev, args, B, H, W, mode="split")
+                    line["note"] = ("value: fp32 step with split-operand products on the 16-bit matrix cores (config.fp32_products); the same "
+                                    "step with every product on v_mfma_f32_32x32x2_f32, same run: %s images/sec (fp32_native_mfma)%s"
+                                    % (line["fp32_native_mfma"].get("value"),
+                                       "; with three bf16 terms / six MFMAs per product (the default of rounds 2-4): %s (fp32_split_bf16x3)"
+                                       % line["fp32_split_bf16x3"].get("value") if fp32_mode == "split3" else ""))
                 except Exception as e:
                     line["fp32_native_mfma"] = {"error": str(e)[:300]}
             try:
