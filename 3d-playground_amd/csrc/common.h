@@ -7,6 +7,29 @@
 
 #define RN_WAVE 64
 
+// Diagnostic builds.  The kernels carry compile-time knock-outs, stamps and ablations (timing only, most give wrong results) that the
+// measurements in DESIGN.md / profiles/ were made with: RN_KO, RN_SPLIT_ABL, RN_STAMP, RN_SGB, RN_PIN_MFMA, RN_SPLIT_NBUF (conv_igemm_tile.h,
+// mfma_split.h), RN_WINO_ABL (conv_wino.hip), P8_ABL / P8_STAGGER (conv_bf16_p8.hip), Q8_ABL (conv_fp8_p8.hip), RN_AMAX_KO (mfma_split.h),
+// RN_MF16H_OCC (conv_igemm_mf16.hip).  They are honoured ONLY in a build with -DRN_EXPERIMENT=1 (tools/build_variant.sh adds it and writes
+// the library beside the product one); any other build drops them here, before the files that test them are read.
+#ifndef RN_EXPERIMENT
+#define RN_EXPERIMENT 0
+#endif
+#if !RN_EXPERIMENT
+#undef RN_KO
+#undef RN_SPLIT_ABL
+#undef RN_STAMP
+#undef RN_SGB
+#undef RN_PIN_MFMA
+#undef RN_SPLIT_NBUF
+#undef RN_WINO_ABL
+#undef P8_ABL
+#undef P8_STAGGER
+#undef Q8_ABL
+#undef RN_AMAX_KO
+#undef RN_MF16H_OCC
+#endif
+
 #define RN_LAUNCH_CHECK()                         \
     do {                                          \
         hipError_t e__ = hipGetLastError();       \

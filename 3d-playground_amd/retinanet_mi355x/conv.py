@@ -55,7 +55,12 @@ MASK_BITS = 4                                    # RN_MASK_BITS of include/retin
 
 
 def _sign_words(y, want):
-    """-> int32 tensor for the sign bits of the dense fp32 / bf16 tensor y (attached as y._rn_sign), or None."""
+    """-> int32 tensor for the sign bits of the dense fp32 / bf16 tensor y (attached as y._rn_sign), or None.  Called by every producer
+    for its result: words an EARLIER producer left on the same tensor object (a caller reusing it through ``out=``) are dropped first,
+    so a consumer never reads bits of a tensor that has been rewritten since.  (In-place edits of a producer's output by anything else
+    -- torch operations included -- invalidate the bits as well: drop ``._rn_sign`` or use a fresh tensor.)"""
+    if hasattr(y, "_rn_sign"):
+        del y._rn_sign
     if not (want and BITMASKS) or y.dtype not in (torch.float32, torch.bfloat16) or y.shape[-1] % 32 or not y.is_contiguous():
         return None
     bits = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)

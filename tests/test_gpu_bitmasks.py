@@ -70,6 +70,24 @@ def test_producer_writes_the_sign_of_what_it_stored(cv, dev, case):
     assert torch.equal(y, y2) and getattr(y2, "_rn_sign", None) is None       # asking for the bits changes nothing else
 
 
+def test_reusing_an_output_tensor_drops_the_old_bits(cv, dev):
+    """A producer that writes into a tensor an EARLIER producer left sign bits on (the public conv_* API with its own destination) and
+    is not asked for bits itself must not leave the old ones behind: a consumer would mask with the signs of a tensor that no longer
+    exists.  With sign=True the new bits replace the old."""
+    cin, cout, N, H, W = 64, 128, 1, 17, 19
+    x1, x2 = nhwc(rnd((N, cin, H, W), 1)).to(dev), nhwc(rnd((N, cin, H, W), 2)).to(dev)
+    wp = cv.pack_weights(rnd((cout, cin, 1, 1), 3, 0.2).to(dev), 0)
+    y = torch.empty((N, H, W, cout), device=dev)
+    geom = (H, W, cout, 1, 1, 1, 1, 0, 0)
+    cv.conv_igemm(x1, wp, y, geom, act=cv.ACT_RELU, sign=True)
+    first = y._rn_sign.clone()
+    assert torch.equal(first, packed_sign(y))
+    cv.conv_igemm(x2, wp, y, geom, act=cv.ACT_RELU, sign=False)              # same destination, no bits asked for
+    assert getattr(y, "_rn_sign", None) is None
+    cv.conv_igemm(x2, wp, y, geom, act=cv.ACT_RELU, sign=True)
+    assert torch.equal(y._rn_sign, packed_sign(y)) and not torch.equal(y._rn_sign, first)
+
+
 def _with_and_without_bits(cv, z, fn):
     """fn(mask tensor) with z's sign bits attached and with the plain fp32 z: must be bit-identical."""
     zb = z.clone()

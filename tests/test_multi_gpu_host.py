@@ -111,6 +111,60 @@ def test_trainer_loop_world2_gloo(tmp_path):
     assert dict(out) == {0: True, 1: True}
 
 
+def _unequal_worker(rank, world, port, tmp, out):
+    """Shards of unequal length (rank 0: three batches, rank 1: two): the exhausted rank keeps answering the per-iteration all-reduce,
+    nobody hangs, both ranks count the same iterations and end with identical weights."""
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from retinanet_mi355x import ddp, trainer
+    ddp.init_from_env(backend="gloo")
+    net = _Stand_in(world)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+
+    def batches(epoch):
+        g = torch.Generator().manual_seed(7 * epoch + rank)
+        for _ in range(3 - rank):
+            yield torch.randn(5, 6, generator=g), torch.randn(5, 3, generator=g)
+    hist = trainer.train(net, opt, None, batches, 2, rank=rank, log=lambda m: None)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    ok = torch.equal(both[0], both[1])
+    ok &= [h["iterations"] for h in hist] == [2, 2] and [h["skipped"] for h in hist] == [1, 1]     # the third iteration: one rank short
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_trainer_unequal_shards_do_not_hang_world2_gloo(tmp_path):
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_unequal_worker, args=(world, port, str(tmp_path), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_checkpoint_with_dataparallel_keys_round_trip(tmp_path):
+    """train(..., dataparallel_keys=True) writes the ``module.``-prefixed keys of the reference's multi-GPU trainer
+    (train_detector_3D_angle.py:415-417); stripping the prefix (what its to_cpu helper does by hand, :39-59, and what this package's
+    load_state_dict does itself) gives back the weights.  (No reference fixture covers the round trip: parity unpinned.)"""
+    sys.path.insert(0, PKG)
+    from retinanet_mi355x import trainer
+    net = _Stand_in(1)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+
+    def batches(epoch):
+        g = torch.Generator().manual_seed(epoch)
+        yield torch.randn(4, 6, generator=g), torch.randn(4, 3, generator=g)
+    trainer.train(net, opt, None, batches, 1, checkpoint=str(tmp_path / "dp_e{}.pt"), dataparallel_keys=True, log=lambda m: None)
+    sd = torch.load(tmp_path / "dp_e0.pt", weights_only=True)
+    assert sd and all(k.startswith("module.") for k in sd)
+    twin = _Stand_in(1)
+    twin.load_state_dict({k[len("module."):]: v for k, v in sd.items()})
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), twin.state_dict().values()))
+    trainer.train(net, opt, None, batches, 1, checkpoint=str(tmp_path / "bare_e{}.pt"), log=lambda m: None)
+    assert not any(k.startswith("module.") for k in torch.load(tmp_path / "bare_e0.pt", weights_only=True))
+
+
 def test_trainer_single_process_skips_like_the_reference():
     """World 1: an iteration whose forward raises is printed and skipped (train_detector_3D_angle.py:406-408), a zero loss is
     skipped before backward (:380-381); nothing else changes."""

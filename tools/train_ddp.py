@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--patience", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "train_ddp"))
     ap.add_argument("--resume", default=None, help="checkpoint (state_dict, with or without the DataParallel 'module.' prefix)")
+    ap.add_argument("--dataparallel-keys", action="store_true",
+                    help="write checkpoints with the 'module.' key prefix of the reference's multi-GPU trainer (train_detector_3D_angle.py:415-417)")
     return ap.parse_args()
 
 
@@ -95,7 +97,7 @@ def main():
 
     t0 = time.time()
     hist = trainer.train(net, opt, sched, batches, args.epochs, checkpoint=os.path.join(args.out, "corrected_data_e{}.pt"),
-                         rank=rank, log=lambda m: print(m, flush=True))
+                         rank=rank, log=lambda m: print(m, flush=True), dataparallel_keys=args.dataparallel_keys)
     torch.cuda.synchronize()
     dt = time.time() - t0
     # every rank holds the same weights: compare a checksum across ranks
