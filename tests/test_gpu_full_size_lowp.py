@@ -143,3 +143,30 @@ def test_fp8_resnet101_cfg5_size_against_oracle(dev):
     # the post-processing branches run on these tensors at this size
     s, c, b, im = net(img.to(dev), MULTI_FRAME=True)
     assert s.shape[0] == c.shape[0] == b.shape[0] == im.shape[0] and (im.numel() == 0 or int(im.max()) <= B - 1)
+
+
+def test_fp8_resnet101_batch16(dev):
+    """configs[4] at ITS batch: ResNet-101, 1920x1080, 16 images per GPU through the e4m3 forward (what `bench.py --arch resnet101 --dtype
+    fp8 --batch 16` times).  The scales are calibrated constants and every output element is one K loop in a fixed order whatever the
+    number of images in the launch (persistent workgroups walk tiles, they do not split reductions), so image i inside the batch-16
+    launch must be BIT-IDENTICAL to image i alone -- batch strides, the grouped pyramid launches' tile tables and the persistent tile
+    walk at B = 16 are witnessed element by element; image 0 alone is what test_fp8_resnet101_cfg5_size_against_oracle checks against
+    the oracle."""
+    from retinanet_mi355x import modules, synth
+    B = 16
+    net = modules.resnet101(num_classes=8)
+    net.load_state_dict(synth.state_dict("resnet101", 8, 12, seed=2))
+    net = net.to(dev).eval()
+    calib = torch.cat([synth.frames(1, H, W, seed=123), synth.frames(1, H, W, seed=124)]).to(dev)
+    net.calibrate_fp8(calib, margin=1.25)
+    assert net._engine.fp8
+    img = synth.frames(B, H, W, seed=0).to(dev)
+    with torch.no_grad():
+        boxes, cls = net(img, LOCALIZE=True)
+        assert cls.shape == (B, 389205, 8) and boxes.shape[0] == B and torch.isfinite(cls).all() and torch.isfinite(boxes).all()
+        for i in (0, 7, 15):
+            b1, c1 = net(img[i:i + 1], LOCALIZE=True)
+            assert torch.equal(cls[i:i + 1], c1), "scores of image %d differ inside the batch" % i
+            assert torch.equal(boxes[i:i + 1], b1), "boxes of image %d differ inside the batch" % i
+        # different images give different outputs (the comparison above is not vacuous)
+        assert not torch.equal(cls[0], cls[7])
