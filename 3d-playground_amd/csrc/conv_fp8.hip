@@ -67,6 +67,57 @@ extern "C" int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float s
     return RN_OK;
 }
 
+// e4m3 -> bf16 with the tensor's scale (round 5: the fp8-forward TRAINING step keeps its activations as e4m3 and hands them to the bf16
+// data / weight gradient kernels; 16 values per thread: one 16-byte load, two 16-byte stores).  q * scale is rounded once, to bf16.
+typedef __bf16 rn_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void fp8_to_bf16_kernel(const int4 *__restrict__ src, rn_bf16x8 *__restrict__ dst, int64_t n16, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const int4 q = src[i];
+    const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        rn_bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = w[2 * h + j];
+            o[4 * j + 0] = (__bf16)(__builtin_amdgcn_cvt_f32_fp8(d, 0) * scale);
+            o[4 * j + 1] = (__bf16)(__builtin_amdgcn_cvt_f32_fp8(d, 1) * scale);
+            o[4 * j + 2] = (__bf16)(__builtin_amdgcn_cvt_f32_fp8(d, 2) * scale);
+            o[4 * j + 3] = (__bf16)(__builtin_amdgcn_cvt_f32_fp8(d, 3) * scale);
+        }
+        dst[2 * i + h] = o;
+    }
+}
+extern "C" int rn_fp8_to_bf16(const void *src, void *dst, int64_t n, float scale, void *stream) {
+    if (n <= 0 || (n & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return RN_EINVAL;
+    hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(rn_blocks(n / 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const int4 *>(src), reinterpret_cast<rn_bf16x8 *>(dst), n / 16, scale);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// bf16 -> e4m3: dst[i] = fp8(src[i] * inv_scale), saturating; 16 values per thread.  The fp8 engine's bf16 residual stream (round 5: the
+// last convolution of a bottleneck and the FPN run in bf16, tools/fp8_error_budget.py) enters the next block's e4m3 convolutions here.
+__global__ void bf16_to_fp8_kernel(const rn_bf16x8 *__restrict__ src, int4 *__restrict__ dst, int64_t n16, float inv_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const rn_bf16x8 a = src[2 * i], b = src[2 * i + 1];
+    int4 q;
+    q.x = f8_pack4((float)a[0] * inv_scale, (float)a[1] * inv_scale, (float)a[2] * inv_scale, (float)a[3] * inv_scale);
+    q.y = f8_pack4((float)a[4] * inv_scale, (float)a[5] * inv_scale, (float)a[6] * inv_scale, (float)a[7] * inv_scale);
+    q.z = f8_pack4((float)b[0] * inv_scale, (float)b[1] * inv_scale, (float)b[2] * inv_scale, (float)b[3] * inv_scale);
+    q.w = f8_pack4((float)b[4] * inv_scale, (float)b[5] * inv_scale, (float)b[6] * inv_scale, (float)b[7] * inv_scale);
+    dst[i] = q;
+}
+extern "C" int rn_bf16_to_fp8(const void *src, void *dst, int64_t n, float inv_scale, void *stream) {
+    if (n <= 0 || (n & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return RN_EINVAL;
+    hipLaunchKernelGGL(bf16_to_fp8_kernel, dim3(rn_blocks(n / 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const rn_bf16x8 *>(src), reinterpret_cast<int4 *>(dst), n / 16, inv_scale);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 // 3x3 / stride 2 / pad 1 max-pool of the fp32 stem output, written as e4m3 with one scale: what max-pool followed by rn_fp8_quantize
 // computes (bit for bit), without the fp32 pooled tensor in between (D/model.py:232: the boundary where the fp8 engine's fp32 stem ends).
 __global__ void maxpool_fwd_fp8out_kernel(const float4 *__restrict__ x, int *__restrict__ y, int H, int W, int C4, int Ho, int Wo,

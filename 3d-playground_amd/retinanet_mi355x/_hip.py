@@ -153,6 +153,8 @@ SIGNATURES.update({
     "rn_conv_igemm_bf16_tile": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
     "rn_fp8_quantize": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "rn_fp8_dequantize": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "rn_fp8_to_bf16": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "rn_bf16_to_fp8": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "rn_fp8_quantize_rows": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "rn_conv_igemm_fp8": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp]),
     "rn_conv_igemm_fp8_grouped": (c_i32, [ctypes.POINTER(ConvGroup), c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp]),

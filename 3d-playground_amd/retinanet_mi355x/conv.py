@@ -1029,6 +1029,31 @@ def fp8_dequantize(q, scale=None):
     return out
 
 
+def bf16_to_fp8(t, scale):
+    """bf16 device tensor -> e4m3 bytes with ONE scale (q = fp8(t / scale), saturating): fp8_quantize for a bf16 source, one pass."""
+    _hip.need_gpu(t)
+    t = t.contiguous()
+    n = t.numel()
+    if n % 16 or not n:
+        return fp8_quantize(to_f32(t), scale)
+    out = torch.empty(t.shape, dtype=torch.uint8, device=t.device)
+    _hip.check(_hip.load().rn_bf16_to_fp8(t.data_ptr(), out.data_ptr(), n, 1.0 / float(scale), _hip.stream()), "rn_bf16_to_fp8")
+    out._rn_scale = float(scale)
+    return out
+
+
+def fp8_to_bf16(q, scale=None):
+    """e4m3 tensor (uint8, ._rn_scale) -> bf16 tensor of the same shape: the fp8-forward training step's hand-over to the bf16 gradients."""
+    scale = q._rn_scale if scale is None else scale
+    out = torch.empty(q.shape, dtype=torch.bfloat16, device=q.device)
+    n = q.numel()
+    if n % 16 == 0 and n:
+        _hip.check(_hip.load().rn_fp8_to_bf16(q.data_ptr(), out.data_ptr(), n, float(scale), _hip.stream()), "rn_fp8_to_bf16")
+    elif n:                                          # (odd sizes: tiny tensors of the test networks)
+        out.copy_(fp8_dequantize(q, scale))
+    return out
+
+
 def fp8_quantize_weights(w_packed):
     """Packed fp32 weight rows [rows][Kpad] -> (e4m3 rows [rows][round64(Kpad)], per-row scale [rows] = max|row| / 448)."""
     rows, kp = w_packed.shape

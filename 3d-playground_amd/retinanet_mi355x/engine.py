@@ -35,6 +35,41 @@ S2_SHORTCUT_COMPACT = os.environ.get("RN_S2_SHORTCUT_COMPACT", "1") != "0"
 STEM_BF16_PRODUCTS = os.environ.get("RN_STEM_BF16_PRODUCTS", "1") != "0"
 
 
+# ---- mixed precision inside the fp8 engine (round 5).  Every layer of an fp8 engine can run its FORWARD in "fp8" (the default), "bf16"
+# or "fp32" (Layer.fwd_mode; Engine.set_fp8_layers): tools/fp8_error_budget.py turns ONE group of layers to fp8 at a time to see where
+# the end-to-end error comes from, and a group can be kept out of fp8 for good.  Tensors change format at the boundaries: every layer
+# output carries the e4m3 scale calibrated for it (._rn_qscale; e4m3 tensors: ._rn_scale), so any consumer can quantise it.
+def _qscale(t):
+    return getattr(t, "_rn_scale", None) or getattr(t, "_rn_qscale", None)
+
+
+def _as_fp8(t):
+    if t is None or t.dtype == torch.uint8:
+        return t
+    sc = _qscale(t)
+    assert sc, "a tensor entering an fp8 layer needs its calibrated scale (Layer.fwd tags its outputs)"
+    return cv.fp8_quantize(t, sc) if t.dtype == torch.float32 else cv.bf16_to_fp8(t, sc)
+
+
+def _as_f32(t):
+    if t is None or t.dtype == torch.float32:
+        return t
+    y = cv.fp8_dequantize(t) if t.dtype == torch.uint8 else cv.to_f32(t)
+    y._rn_qscale = _qscale(t)
+    return y
+
+
+def _as_bf16(t):
+    if t is None or t.dtype == torch.bfloat16:
+        return t
+    y = cv.fp8_to_bf16(t) if t.dtype == torch.uint8 else cv.to_bf16(t)
+    y._rn_qscale = _qscale(t)
+    return y
+
+
+_AS = {"fp8": _as_fp8, "bf16": _as_bf16, "fp32": _as_f32}
+
+
 class Layer:
     """One convolution with its fused batch-norm / bias, the per-step packed weights and gradient accumulators."""
 
@@ -113,6 +148,10 @@ class Layer:
         self.uf, self.ud = wino if wino is not None else (None, None)
         self.wd16 = wd16                              # bf16 twins from the batched preparation (launch 2), else on demand
         self.wf16 = wf16 if wf16 is not None else (cv.to_bf16(self.wf) if self.bf16 else None)
+        if self.fp8:                                   # fp8-forward training: this step's weights as e4m3 rows + per-channel scales
+            self.wq, sw = cv.fp8_quantize_weights(self.wf)
+            self.wscale = (sw * self.scale) if self.scale is not None else sw
+            self._fp8_scales = {}
 
     def wino_weights(self, mode):
         """Winograd-transformed weights of this step (mode 0 forward, 1 data gradient with the batch-norm scale folded in)."""
@@ -151,16 +190,21 @@ class Layer:
         sign = (self.sign and act == cv.ACT_RELU) if sign is None else (sign and self.sign)
         N, Hi, Wi, _ = x.shape
         Ho, Wo = cv.out_size(Hi, s.k, s.stride, s.pad), cv.out_size(Wi, s.k, s.stride, s.pad)
-        if self.fp8:
+        mode = self.mode()
+        if self.fp8:                                   # a layer of an fp8 engine: operands in the format this layer's forward runs in
+            x, add = _AS[mode](x), _AS[mode](add)
+        if mode == "fp8":
             assert not in_relu, "fp8: the caller applies the input ReLU"
             return self._fwd_fp8(x, (Ho, Wo), act, add, add_mode, add_hw, out, y_batch_stride)
-        if self.bf16:
+        if mode == "bf16":
             assert not in_relu, "bf16: the caller applies the input ReLU (cv.relu_bf16)"
             if out is None:
                 out = torch.empty((N, Ho, Wo, s.cout), dtype=torch.bfloat16, device=x.device)
-            return cv.conv_igemm_bf16(x, self.wf16, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
-                                      scale=self.scale, shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
-                                      y_batch_stride=y_batch_stride, flops=self.flops(N, Ho, Wo), sign=sign)
+            cv.conv_igemm_bf16(x, self.wf16, out, (Ho, Wo, s.cout, s.k, self.kw_pad, s.stride, 1, -s.pad, 0),
+                               scale=self.scale, shift=self.shift, add=add, add_mode=add_mode, add_hw=add_hw, act=act,
+                               y_batch_stride=y_batch_stride, flops=self.flops(N, Ho, Wo), sign=sign)
+            out._rn_qscale = self.out_scale
+            return out
         if self.wino_active and out is None and add is None and not in_relu and y_batch_stride is None \
                 and act in (cv.ACT_NONE, cv.ACT_RELU) and x.is_contiguous():
             r = cv.wino_conv_group([x], self.wino_weights(0), scale=self.scale, shift=self.shift, act=act, keep_v=self.keep_v, sign=sign)
@@ -173,7 +217,12 @@ class Layer:
                       y_batch_stride=y_batch_stride, in_relu=in_relu, flops=self.flops(N, Ho, Wo), sign=sign,
                       bf16_products=getattr(self, "bf16_products", False))
         self._tap(out if y_batch_stride is None else None)
+        out._rn_qscale = self.out_scale
         return out
+
+    def mode(self):
+        """The format this layer's FORWARD runs in: "fp8" / "bf16" / "fp32" (an fp8 engine may keep single layers out of fp8: fwd_mode)."""
+        return getattr(self, "fwd_mode", None) or ("fp8" if self.fp8 else ("bf16" if self.bf16 else "fp32"))
 
     def _tap(self, out):
         """Calibration of the fp8 path (Engine.calibrate): remember the largest magnitude this layer's output has taken."""
@@ -200,7 +249,10 @@ class Layer:
         (with y_batch_stride) or None for fresh dense outputs.  wino: Winograd path (dense outputs only).  shared_v: the kept
         input transform of ANOTHER layer that read the same xs (both towers' conv1 read the pyramid): reused, not recomputed."""
         s = self.spec
-        if self.fp8:                                   # the levels of a head layer as one grouped e4m3 launch
+        mode = self.mode()
+        if self.fp8:
+            xs = [_AS[mode](x) for x in xs]
+        if mode == "fp8":                              # the levels of a head layer as one grouped e4m3 launch
             scales = {float(x._rn_scale) for x in xs}
             if len(scales) > 1 or len(xs) > _hip.RN_MAX_GROUP:      # different input scales cannot share one folded scale vector
                 return [self._fwd_fp8(x, (x.shape[1], x.shape[2]), act, None, 0, (0, 0), None if outs is None else outs[i], y_batch_stride)
@@ -218,7 +270,7 @@ class Layer:
                 probs.append({"x": x, "y": y, "geom": (Hi, Wi, s.cout, s.k, self.kw_pad, 1, 1, -s.pad, 0), "y_batch_stride": y_batch_stride})
             cv.conv_igemm_fp8_grouped(probs, self.wq, scale, shift=self.shift, act=act, out_scale=self.out_scale, flops=fl)
             return ys
-        if self.bf16:                                  # the levels of a head layer as one grouped bf16 launch
+        if mode == "bf16":                             # the levels of a head layer as one grouped bf16 launch
             probs, ys, fl = [], [], 0.0
             for i, x in enumerate(xs):
                 N, Hi, Wi, _ = x.shape
@@ -228,6 +280,8 @@ class Layer:
                 probs.append({"x": x, "y": y, "geom": (Hi, Wi, s.cout, s.k, self.kw_pad, 1, 1, -s.pad, 0),
                               "y_batch_stride": y_batch_stride, "sign": self.sign and act == cv.ACT_RELU})
             cv.conv_igemm_bf16_grouped(probs, self.wf16, scale=self.scale, shift=self.shift, act=act, flops=fl)
+            for y in ys:
+                y._rn_qscale = self.out_scale
             return ys
         if (wino or self.wino_active) and self.wino_ok and (outs is None or y_batch_stride is not None):
             fl = sum(self.flops(x.shape[0], x.shape[1], x.shape[2]) for x in xs)
@@ -249,6 +303,7 @@ class Layer:
         if outs is None:
             for y in ys:
                 self._tap(y)
+                y._rn_qscale = self.out_scale
         return ys
 
     def bwd_data_group(self, gs, in_hws, adds=None, masks=None, wino=False):
@@ -432,9 +487,21 @@ class Engine:
             raise ValueError("dtype must be 'fp32', 'bf16' or 'fp8'")
         self.bf16 = dtype == "bf16"
         self.fp8 = dtype == "fp8"
+        # the backward pass of the fp8 engine (round 5: fp8 forward, bf16 data / weight gradients) is the bf16 engine's: its layers are
+        # built with both flags -- Layer.fwd / fwd_group look at fp8 first, every bwd_* at bf16 -- and carry both weight forms
+        self.bwd16 = self.bf16 or self.fp8
         self.fp8_scales = None                     # {layer name / "pool": largest magnitude seen} from calibrate()
+        # Which layers of the fp8 engine run in e4m3.  "stream_bf16" (default since round 5): all but the RESIDUAL STREAM -- the last
+        # convolution of every bottleneck, the shortcuts -- and the FPN, which run in bf16 (bf16 result and addend): as e4m3 the stream
+        # is re-quantised at every block, 33 times through ResNet-101, and together with the pyramid that is where the end-to-end error
+        # comes from (tools/fp8_error_budget.py, profiles/r05_fp8_error_budget.txt: scores 14.7 % max / 5.7 % rms of the fp32 forward
+        # with every layer in e4m3, 8.0 % / 2.0 % this way) -- and the regression tower's last layer, whose e4m3 result feeds an
+        # unbounded regression output (training: the smooth-L1 loss 2.4 % off the bf16 step's with it in e4m3, 1.8 % without;
+        # tools/dbg/fp8_train_variants.py).  "all": every layer in e4m3 (round 4's configuration, the fastest).
+        self.fp8_policy = os.environ.get("RN_FP8_POLICY", "stream_bf16")
         if self.bf16 and arch.LAYERS[arch_name][0] != "bottleneck":
             raise NotImplementedError("the bf16 schedule is built for the bottleneck networks (resnet50/101/152)")
+        self.fp8_trainable = self.fp8 and arch.LAYERS[arch_name][0] == "bottleneck"      # (the bf16 backward's condition)
         self.arch = arch_name
         self.num_classes = num_classes
         self.n_reg = n_reg
@@ -466,14 +533,14 @@ class Engine:
                 # the first bf16 terms of both operands (rn_conv_desc.w_format 2): the engine's arithmetic, one MFMA instead of six
                 self.layers[spec.name].bf16_products = (self.bf16 or self.fp8) and STEM_BF16_PRODUCTS
                 continue
-            self.layers[spec.name] = Layer(spec, bf16=self.bf16, fp8=self.fp8)
+            self.layers[spec.name] = Layer(spec, bf16=self.bwd16, fp8=self.fp8)
             if cur is None or cur[0] != pre:
                 cur = (pre, {})
                 self.blocks.append(cur)
             cur[1][role] = self.layers[spec.name]
         for spec in arch.fpn_convs(arch_name) + arch.head_convs("regressionModel", n_reg) + \
                 arch.head_convs("classificationModel", num_classes):
-            self.layers[spec.name] = Layer(spec, bf16=self.bf16, fp8=self.fp8)
+            self.layers[spec.name] = Layer(spec, bf16=self.bwd16, fp8=self.fp8)
         self.param_names = [k for k, shp in arch.state_dict_shapes(arch_name, num_classes, n_reg).items()
                             if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
 
@@ -652,7 +719,7 @@ class Engine:
             return dst
 
         fp32_mode = cv.get_fp32_mfma()                # ("mode" is a loop variable further down)
-        presplit = cv.PRESPLIT and fp32_mode != "native" and not self.bf16
+        presplit = cv.PRESPLIT and fp32_mode != "native" and not self.bwd16
 
         def split_job(src, force=False, f16=None):
             """split modes: the pre-split twin of a packed fp32 buffer (cv.split_weights' / split_weights_f16's attribute), filled by
@@ -782,7 +849,7 @@ class Engine:
         """Weight-gradient and column-sum accumulators of every layer -- and the Winograd-domain accumulators dU of the layers that
         take that path -- as views of ONE buffer, zeroed by one fill per step (they are atomically accumulated into: ~160 separate
         zero-fills per step otherwise)."""
-        wino = self.use_wino and not self.bf16
+        wino = self.use_wino and not self.bwd16
         sizes = []
         for L in self.layers.values():
             s = L.spec
@@ -830,6 +897,22 @@ class Engine:
         e4m3 (all but the fp32 stem and the fp32 head outputs)."""
         return ["pool"] + [n for n in self.layers if n != "conv1" and not n.endswith(".output")]
 
+    def set_fp8_layers(self, fp8=None, other="fp32"):
+        """fp8 engine: which layers run their forward in fp8 (names, or a predicate on the name; None = all, the default), the others in
+        `other` ("fp32" or "bf16").  The stem is fp32 and the head outputs are fp32 results in any case.  Formats change at the
+        boundaries by themselves (Layer.fwd).  -> the names that run in fp8."""
+        assert self.fp8 and other in ("fp32", "bf16")
+        pick = (lambda n: True) if fp8 is None else (fp8 if callable(fp8) else (lambda n, names=set(fp8): n in names))
+        self._fp8_explicit = True                           # from now on the caller's choice stands (not fp8_policy)
+        on = []
+        for n, L in self.layers.items():
+            if n == "conv1":
+                continue
+            L.fwd_mode = "fp8" if pick(n) else other
+            if L.fwd_mode == "fp8":
+                on.append(n)
+        return on
+
     # ------------------------------------------------------------------------------------------- forward
     def forward(self, P, img, save, x4=None):
         """img [B,3,H,W] on device -> (reg [B,A,n_reg], cls [B,A,C], saved activations or None).  x4: the input already
@@ -840,14 +923,23 @@ class Engine:
         else:
             self._prepare(P)
         if self.fp8:
-            if save:
-                raise RuntimeError("the fp8 engine is inference-only (no backward pass): train in fp32 / bf16")
+            if save and not self.fp8_trainable:
+                raise RuntimeError("the fp8 training step (fp8 forward, bf16 gradients) is built for the bottleneck networks "
+                                   "(resnet50/101/152), like the bf16 schedule")
             if not self.fp8_scales:
                 raise RuntimeError("the fp8 engine needs activation scales: net.calibrate_fp8(frames) first")
             missing = [n_ for n_ in self.fp8_scale_names() if not self.fp8_scales.get(n_, 0.0) > 0.0]
             if missing:                                     # a scale of 0 would saturate every activation to +-448: finite garbage
                 raise RuntimeError("fp8 activation scales are missing (or zero) for %d tensors, e.g. %s: run net.calibrate_fp8(frames) "
                                    "on representative frames" % (len(missing), ", ".join(missing[:4])))
+            if getattr(self, "_fp8_explicit", None) is None:    # (set_fp8_layers overrides the policy)
+                stream = (lambda n_: n_.endswith(".conv3") or ".downsample." in n_ or n_.startswith("fpn.") or n_ == "regressionModel.conv4") \
+                    if self.fp8_policy == "stream_bf16" else (lambda n_: False)
+                for n_, L in Ls.items():
+                    if n_ != "conv1":
+                        L.fwd_mode = "bf16" if stream(n_) else "fp8"
+            if save and any(L.mode() == "fp32" for n_, L in Ls.items() if n_ != "conv1"):
+                raise RuntimeError("the fp8 training step saves e4m3 / bf16 activations for the bf16 gradient kernels: no fp32-format layers")
             for n_, L in Ls.items():
                 L.out_scale = max(self.fp8_scales.get(n_, 0.0), 1e-30) / cv.FP8_MAX
             # the five pyramid maps share ONE scale, so that the towers' first layer takes them in one grouped launch
@@ -908,8 +1000,9 @@ class Engine:
         p3 = Ls["fpn.P3_2"].fwd(p3sum)
         p6 = Ls["fpn.P6"].fwd(c5, sign=True)               # stored before its ReLU; P7_2's data gradient is masked by its sign
         p6r = cv.relu_bf16(p6) if self.bf16 else None                      # fp32: the ReLU rides on the fragments (in_relu)
-        if self.fp8:                                                       # (a 17 x 30 map: through fp32, same scale)
-            p6r = cv.fp8_quantize(torch.relu(cv.fp8_dequantize(p6)), p6._rn_scale)
+        if self.fp8:                                                       # (a 17 x 30 map: through fp32, same scale; any format P6 ran in)
+            p6r = torch.relu(_as_f32(p6))
+            p6r._rn_qscale = _qscale(p6)
         p7 = Ls["fpn.P7_2"].fwd(p6r) if (self.bf16 or self.fp8) else Ls["fpn.P7_2"].fwd(p6, in_relu=True)
         pyramid = [p3, p4, p5, p6, p7]
         if save:
@@ -1007,7 +1100,9 @@ class Engine:
                     self.bucket_hook(next_bucket, flat[buckets[next_bucket][0]:buckets[next_bucket][1]])
                 next_bucket += 1
 
-        pyramid, counts = S["pyramid"], S["counts"]
+        # fp8-forward training: the saved activations are e4m3; the bf16 gradient kernels read bf16 (rn_fp8_to_bf16 at the point of use)
+        ACT = _as_bf16 if self.fp8 else (lambda t: t)
+        pyramid, counts = [ACT(t) for t in S["pyramid"]], S["counts"]
         B = dreg.shape[0]
         A = dreg.shape[1]
         dpyr = [None] * 5
@@ -1024,28 +1119,28 @@ class Engine:
                                                          ("classificationModel", dcls, self.num_classes, cls))):
             Lout = Ls[prefix + ".output"]
             tower = [Ls["%s.conv%d" % (prefix, i)] for i in range(1, 5)]
-            acts = S["towers"][prefix]                                    # acts[level][i]
             if side is not None:
                 side[ti].wait_event(fork)
             with torch.cuda.stream(side[ti] if side is not None else main):
+                acts = [[ACT(t) for t in lvl] for lvl in S["towers"][prefix]]   # acts[level][i] (fp8 training: as bf16)
                 gs, off = [], 0
                 for (Hh, Ww), cnt in zip(hws, counts):                    # head-output gradient slices -> dense, padded
                     byte_off = 4 * off * width
                     g = cv.sigmoid_bwd_pad(dout.data_ptr() + byte_off, None if sig is None else sig.data_ptr() + byte_off,
                                            B, Hh * Ww, arch.NUM_ANCHORS * width, Lout.cout_pad, A * width, dout.device,
-                                           bf16=self.bf16)
+                                           bf16=self.bwd16)
                     gs.append(cv.amax_carry(g.view(B, Hh, Ww, Lout.cout_pad), g))
                     off += cnt
                 Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
                 gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
                 for i in (3, 2, 1):
-                    tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
-                    gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bf16)
-                tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino and not self.bf16)
+                    tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bwd16)
+                    gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bwd16)
+                tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino and not self.bwd16)
                 first = dpyr[0] is None
                 if side is not None and not first:
                     side[ti].wait_stream(side[0])                         # the other tower's pyramid gradient is complete
-                dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino and not self.bf16)
+                dpyr = tower[0].bwd_data_group(gs, hws, adds=None if first else dpyr, wino=self.use_wino and not self.bwd16)
             S["towers"][prefix] = None
             retired.append(Lout)
             retired.extend(reversed(tower))
@@ -1055,12 +1150,12 @@ class Engine:
         for L in retired:
             done(L)
         # ---- FPN
-        c3, c4, c5, p5lat, p4sum, p3sum, p6 = S["fpn"]
+        c3, c4, c5, p5lat, p4sum, p3sum, p6 = (ACT(t) for t in S["fpn"])
         dp3, dp4, dp5, dp6, dp7 = dpyr
         hw = lambda t: (t.shape[1], t.shape[2])
         L = Ls["fpn.P7_2"]
-        if self.bf16:
-            L.bwd_params(dp7, S["p6r"])
+        if self.bwd16:
+            L.bwd_params(dp7, ACT(S["p6r"]))
         else:
             L.bwd_params(dp7, p6, in_relu=True)
         dp6 = L.bwd_data(dp7, hw(p6), add=dp6, mask=p6, mask_mode=1)     # d relu(p6) masked, heads' part added raw
@@ -1101,7 +1196,7 @@ class Engine:
         nblocks = len(self.blocks)
         for bi in range(nblocks - 1, -1, -1):
             pre, roles = self.blocks[bi]
-            xin, t1, t2, z = S["blocks"][bi]
+            xin, t1, t2, z = (ACT(t) for t in S["blocks"][bi])
             S["blocks"][bi] = None
             in_hw = hw(xin)
             last = roles["conv2"] if self.kind == "basic" else roles["conv3"]
@@ -1123,7 +1218,7 @@ class Engine:
             dcompact = None
             if "down" in roles:
                 roles["down"].bwd_params(g, xin)
-                if roles["down"].spec.stride == 2 and roles["conv1"].spec.stride == 1 and not self.bf16:
+                if roles["down"].spec.stride == 2 and roles["conv1"].spec.stride == 1 and not self.bwd16:
                     dcompact = roles["down"].bwd_data_compact(g)       # bottleneck: conv1 is 1x1 s1, takes add2
                     dres = extra
                 else:
@@ -1137,7 +1232,7 @@ class Engine:
             done(roles["conv1"])
             del layer_name
         # ---- stem
-        gstem = (cv.maxpool_bwd_bf16 if self.bf16 else cv.maxpool_bwd)(S["stem"], g, S["pool_arg"], relu_mask=True)
+        gstem = (cv.maxpool_bwd_bf16 if self.bwd16 else cv.maxpool_bwd)(S["stem"], g, S["pool_arg"], relu_mask=True)
         Ls["conv1"].bwd_params(gstem, S["x4"])
         done(Ls["conv1"])
         assert flat is None or next_bucket == len(buckets), "backward finished layers in an order finish_order() does not describe"

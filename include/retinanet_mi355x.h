@@ -453,6 +453,14 @@ int rn_fp8_quantize(const float *src, void *dst, int64_t n, float inv_scale, voi
  * rn_fp8_quantize, bit for bit, in one pass (the fp8 engine's stem boundary). */
 int rn_maxpool_fwd_fp8out(const float *x, void *y, int N, int H, int W, int C, int Ho, int Wo, float inv_scale, void *stream);
 int rn_fp8_dequantize(const void *src, float *dst, int64_t n, float scale, void *stream);
+/* e4m3 -> bf16: dst[i] = bf16(q[i] * scale), n a multiple of 16, both pointers 16-byte aligned.  The fp8-forward training step (round 5:
+ * BASELINE configs[4] as a TRAINING configuration) saves its activations as e4m3 and runs its data / weight gradients on the bf16
+ * kernels (rn_conv_igemm_bf16, rn_conv_wgrad_bf16): this is the hand-over. */
+int rn_fp8_to_bf16(const void *src, void *dst, int64_t n, float scale, void *stream);
+/* bf16 -> e4m3 with one scale: dst[i] = fp8(src[i] * inv_scale), saturating at +-448; n a multiple of 16, pointers 16-byte aligned.  The
+ * fp8 engine's bf16 residual stream (the last convolution of every bottleneck, the shortcuts and the FPN run in bf16 by default since
+ * round 5: profiles/r05_fp8_error_budget.txt) enters the next e4m3 convolution through this. */
+int rn_bf16_to_fp8(const void *src, void *dst, int64_t n, float inv_scale, void *stream);
 int rn_fp8_quantize_rows(const float *w_packed, void *w_q, float *row_scale, int64_t rows, int Kpad, void *stream);
 int rn_conv_igemm_fp8(const rn_conv_desc *d, const void *x_q, const void *w_q, void *y, int y_is_f32, const float *scale,
                       const float *shift, const void *add_q, float add_scale, float out_inv_scale, void *stream);

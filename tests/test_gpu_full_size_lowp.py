@@ -7,9 +7,12 @@ test_gpu_model_fp8.py):
   configs[2] -- equal to the mean of its eight single-image runs (the pattern of test_gpu_batch8.py: the forward of image i
   inside the batch is bit-identical to image i alone; the batch's losses and parameter gradients are the means).
 * cfg5's per-GPU leg -- ResNet-101, 1920x1080, fp8 (e4m3) forward, batch 2, against the oracle's fp32 forward on the CPU with
-  activation scales calibrated on frames the evaluation does not see: decoded boxes within DESIGN.md 4.7's 8 % of the largest
-  coordinate; the scores' bound is wider than the 12 % of the 72x104 goldens -- the maximum is taken over 6.2e6 scores instead of
-  1.1e4 and the network is the deepest (33 bottlenecks of e4m3 rounding): measured 15.0 % (5.7 % rms), bound 20 % and 8 % rms.
+  activation scales calibrated on frames the evaluation does not see.  Bounds = the design target of the round-5 error budget
+  (tools/fp8_error_budget.py, profiles/r05_fp8_error_budget.txt): scores within 8.5 % of the largest score and 3 % rms, boxes within
+  5 % -- met by keeping the residual stream and the FPN in bf16 (every layer in e4m3, round 4's configuration: 14.7 % / 5.7 %; the
+  budget run compares with the fp32 ENGINE and reads 7.97 %; the half per cent is the oracle's own CPU summation order on top).
+  Round 5 also: the same network at ITS batch (16, every image bit-identical to its single-image run) and as a TRAINING step (fp8
+  forward, bf16 gradients) against the bf16 engine's step.
 The reference has neither mode: parity of the low-precision arithmetic is unpinned by it; what is pinned is that these schedules
 compute the reference's FUNCTION at the benchmark's sizes (five real pyramid sizes, both FPN crop branches, grouped head launches).
 """
@@ -139,7 +142,7 @@ def test_fp8_resnet101_cfg5_size_against_oracle(dev):
     tgm.STATS["fp8_cfg5_full"] = {"scores_max": s_max, "scores_rms": s_rms, "boxes_max": b_max, "boxes_rms": b_rms,
                                   "scores_max_rms_by_margin": {str(k): v for k, v in res.items()}}
     tgm._dump()
-    assert s_max <= 0.20 and s_rms <= 0.08 and b_max <= 0.08, (s_max, s_rms, b_max)
+    assert s_max <= 0.085 and s_rms <= 0.03 and b_max <= 0.05, (s_max, s_rms, b_max)
     # the post-processing branches run on these tensors at this size
     s, c, b, im = net(img.to(dev), MULTI_FRAME=True)
     assert s.shape[0] == c.shape[0] == b.shape[0] == im.shape[0] and (im.numel() == 0 or int(im.max()) <= B - 1)
@@ -170,3 +173,46 @@ def test_fp8_resnet101_batch16(dev):
             assert torch.equal(boxes[i:i + 1], b1), "boxes of image %d differ inside the batch" % i
         # different images give different outputs (the comparison above is not vacuous)
         assert not torch.equal(cls[0], cls[7])
+
+
+def test_fp8_training_step_cfg5_size_against_the_bf16_step(dev):
+    """configs[4] as a TRAINING configuration at its size: ResNet-101, 1920x1080, batch 2 -- forward on the fp8 kernels (e4m3 activations,
+    bf16 residual stream), activations saved in those formats, the three losses in fp32, data and weight gradients on the bf16 kernels --
+    against the SAME step on the bf16 engine (whose 1080p step is pinned to the oracle by test_bf16_cfg2_size_against_oracle): every
+    loss within 2 %, every head / pyramid gradient tensor within cosine 0.95 (VERDICT r4 item 3c's criterion), all gradients finite."""
+    from retinanet_mi355x import modules, synth
+    B = 2
+    sd = synth.state_dict("resnet101", 8, 12, seed=2)
+    img = synth.frames(B, H, W, seed=0).to(dev)
+    ann = synth.labels_dir(B, 10, H, W, 8, seed=1).to(dev)
+
+    def build():
+        net = modules.resnet101(num_classes=8)
+        net.load_state_dict(sd)
+        return net.to(dev)
+    ref = build()
+    ref.set_compute_dtype("bf16")
+    ref.train()
+    ref.freeze_bn()
+    l16, g16 = _step(ref, img, ann)
+    del ref
+    torch.cuda.empty_cache()
+    net = build().eval()
+    net.calibrate_fp8(torch.cat([synth.frames(1, H, W, seed=123), synth.frames(1, H, W, seed=124)]).to(dev), margin=1.25)
+    net.train()
+    net.freeze_bn()
+    l8, g8 = _step(net, img, ann)
+    rel = np.abs(np.array(l8) - np.array(l16)) / np.abs(np.array(l16))
+    cos = {}
+    for n, g in g8.items():
+        assert torch.isfinite(g).all(), n
+        a, b = g.double().reshape(-1), g16[n].double().reshape(-1)
+        if float(b.norm()) > 0:
+            cos[n] = float(a @ b / (a.norm() * b.norm() + 1e-300))
+    head = {n: c for n, c in cos.items() if n.startswith(("fpn.", "regressionModel.", "classificationModel."))}
+    back = np.array([c for n, c in cos.items() if n not in head])
+    print("fp8-forward training, resnet101 1080p batch 2: losses %s vs bf16 %s (rel %s); cosine heads + FPN min %.4f (%s); backbone min %.4f median %.4f"
+          % (l8, l16, rel, min(head.values()), min(head, key=head.get), back.min(), np.median(back)))
+    assert np.all(rel <= 2e-2), (l8, l16)
+    assert min(head.values()) >= 0.95, (min(head, key=head.get), min(head.values()))
+    assert np.median(back) >= 0.9
