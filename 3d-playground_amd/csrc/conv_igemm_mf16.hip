@@ -362,10 +362,11 @@ static int64_t mf16_tiles(const rn_conv_desc *d) {
     return ((M + 127) / 128) * ((d->Cout + 127) / 128);
 }
 
-// include/retinanet_mi355x.h: does this problem run on an fp16-split kernel in RN_FP32_SPLIT3 mode?  (Geometry only; the tile-count
-// threshold RN_OPT_MF16_MIN is an A/B knob whose default, 1, excludes nothing.)
+// include/retinanet_mi355x.h: does this problem run on an fp16-split kernel in RN_FP32_SPLIT3 mode?  Since the 128 x 128 / 256 x 64 tiles
+// of conv_igemm_tile.h have the two-term form too (round 5, second half): every problem the split kernels take -- a reduction of at
+// least rn_fp32_split_min_k() -- whatever its geometry.  (The split-K form, chosen by rn_conv_splitk_workspace_bytes, stays on the fp32 MFMA.)
 extern "C" int rn_conv_igemm_wants_f16(const rn_conv_desc *d) {
-    return rn_get_fp32_mfma() == RN_FP32_SPLIT3 && mf16_on() && mf16_geom_ok(d) && d->w_batch_stride >= 0 && mf16_tiles(d) >= mf16_min_tiles();
+    return rn_get_fp32_mfma() == RN_FP32_SPLIT3 && d->w_batch_stride >= 0;
 }
 
 // -> true if launched.  variant as rn_igemm_split_launch: 0 raw, 4 / 5 wide dense / general.

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_kernel
     conv_igemm_tile<WM, WN, GENERAL, BK, RELU, RAW, SPLIT, TERMS>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-template <int WM, int WN, int SPLIT, int BK = 16>
+template <int WM, int WN, int SPLIT, int BK = 16, int TERMS = 3>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_grouped_kernel(const rn_conv_group g, const float *__restrict__ w,
                                                                           const float *__restrict__ scale,
                                                                           const float *__restrict__ shift) {
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 3) void conv_igemm_split_groupe
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_igemm_tile<WM, WN, true, BK, false, false, SPLIT>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_igemm_tile<WM, WN, true, BK, false, false, SPLIT, TERMS>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // SPLIT 3 (conv_igemm_tile.h: the activation operand split once per workgroup into bf16 planes in LDS) for the 128 x 128 tile
@@ -78,7 +78,26 @@ int rn_igemm_split_launch(int variant, unsigned tiles, const rn_conv_desc *d, co
     {
         int rc = RN_OK;
         if (rn_igemm_mf16_launch(variant, d, x, w, y, scale, shift, add, mask, add2, s, &rc)) return rc;
-        if (d->w_format == 3) return RN_EINVAL;             // the fp16 pre-split form has no other consumer (rn_conv_igemm_wants_f16 says which problems take it)
+    }
+    if (d->w_format == 3) {
+        // RN_FP32_SPLIT3 for what the 16x16x32 kernel does not take (<= 64 output channels, the 4-channel stem, channel counts that are
+        // no multiple of 32, the input-ReLU form): the tile of conv_igemm_tile.h with two-term fp16 products (TERMS 2)
+        if (d->x_amax == nullptr || d->w_unscale == nullptr) return RN_EINVAL;
+        const dim3 grid2(tiles), block2(256);
+#define RN_HALF_LAUNCH(WM, WN, G, R, RAW) \
+        hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, G, R, RAW, 2, 16, 2>), grid2, block2, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
+        switch (variant) {
+            case 0: RN_HALF_LAUNCH(2, 2, false, false, true); break;
+            case 1: RN_HALF_LAUNCH(2, 2, true, true, false); break;
+            case 2: RN_HALF_LAUNCH(4, 1, false, false, false); break;
+            case 3: RN_HALF_LAUNCH(4, 1, true, false, false); break;
+            case 4: RN_HALF_LAUNCH(2, 2, false, false, false); break;
+            case 5: RN_HALF_LAUNCH(2, 2, true, false, false); break;
+            default: return RN_EINVAL;
+        }
+#undef RN_HALF_LAUNCH
+        RN_LAUNCH_CHECK();
+        return RN_OK;
     }
     const dim3 grid(tiles), block(256);
 #define RN_SPLIT_LAUNCH(WM, WN, G, R, RAW)                                                                                              \
@@ -108,7 +127,14 @@ int rn_igemm_split_grouped_launch(bool narrow, unsigned tiles, const rn_conv_gro
         int rc = RN_OK;
         if (rn_igemm_mf16_grouped_launch(g, w, scale, shift, s, &rc)) return rc;
     }
-    if (g->d[0].w_format == 3) return RN_EINVAL;
+    if (g->d[0].w_format == 3) {                             // the fp16 two-term tile (see rn_igemm_split_launch)
+        for (int i = 0; i < g->n; ++i)
+            if (g->d[i].w_format != 3 || g->d[i].x_amax == nullptr || g->d[i].w_unscale == nullptr) return RN_EINVAL;
+        if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2, 16, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+        else hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 2, 16, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
+        RN_LAUNCH_CHECK();
+        return RN_OK;
+    }
     if (!narrow && split_a_once(&g->d[0])) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<2, 2, 3>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow && pre) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 2>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);
     else if (narrow) hipLaunchKernelGGL((conv_igemm_split_grouped_kernel<4, 1, 1>), dim3(tiles), dim3(256), 0, s, *g, w, scale, shift);

@@ -149,6 +149,10 @@ __device__ __forceinline__ int lds_swz(int row) {
 //            vector ALU work of SPLIT 1.  Within a plane the two 16-byte chunks of a row swap places in rows 16-31 of
 //            every 32 (position 2*row + (chunk ^ ((row >> 4) & 1))), which makes the ds_read_b128 of [row = lane & 31]
 //            [chunk = lane >> 5] conflict-free (16 distinct 16-byte bank groups per servicing group of 16 lanes).
+// TERMS 2 (SPLIT 2 only; rn_conv_desc.w_format 3; round 5): the fp16 two-term form of RN_FP32_SPLIT3 (mfma_split.h, second half) for the
+// layers conv_igemm_mf16.hip does not take (at most 64 output channels, the 4-channel stem, channel counts that are no multiple of 32,
+// the input-ReLU form): two B planes (64-byte records), the A fragments scaled by their rows' power of two (the image's amax table)
+// inside the split, three v_mfma_f32_32x32x16_f16 per block, the inverse scales applied row by row / column by column in the epilogue.
 // TERMS 1 (SPLIT 2 only; rn_conv_desc.w_format 2): products from the operands' FIRST bf16 terms only -- one MFMA instead of six: the
 // arithmetic of the bf16 / fp8 engines (their fp32 stem), not of the fp32 path.
 template <int WM, int WN, bool GENERAL, int BK, bool RELU = false, bool RAW = false, int SPLIT = 0, int TERMS = 3>
@@ -162,16 +166,19 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     constexpr int CPK = BK / 4;                            // 16-byte chunks per staged row
     constexpr int RPI = 64 / CPK;                          // rows one wave instruction fills
     constexpr int SUB = BK / 16;                           // split forms: 16-wide MFMA steps per staged K-step
-    constexpr int BPL = BN * 8;                            // SPLIT 2 / 3: floats' worth of one bf16 plane of the B tile (BN rows x 32 bytes)
+    constexpr bool HALF = SPLIT == 2 && TERMS == 2;        // fp16 two-term products (RN_FP32_SPLIT3)
+    constexpr int NP = HALF ? 2 : 3;                       // planes of the pre-split B tile
+    constexpr int REC = 32 * NP, EB = 2 * NP;              // bytes of a pre-split record (16 values) / per weight element
+    constexpr int BPL = BN * 8;                            // SPLIT 2 / 3: floats' worth of one 16-bit plane of the B tile (BN rows x 32 bytes)
     constexpr int APL = BM * 8;                            // SPLIT 3: the same for the A tile
-    constexpr int NBI = SUB * 3 * BN / 32;                 // SPLIT 2 / 3: wave instructions that fill the B planes: (sub-step, plane, 32 rows)
+    constexpr int NBI = SUB * NP * BN / 32;                // SPLIT 2 / 3: wave instructions that fill the B planes: (sub-step, plane, 32 rows)
     constexpr bool PB = SPLIT >= 2;                        // B arrives pre-split
     constexpr int IA = SPLIT == 3 ? 1 : BM / RPI / 4, IB = PB ? (NBI + 3) / 4 : BN / RPI / 4;    // instructions per wave per K-step and operand (SPLIT 3: A rows per THREAD)
     constexpr int BOFF = SPLIT == 3 ? 3 * APL : BM * BK;   // floats: where the B part of a buffer starts
-    constexpr int STEP = SPLIT == 3 ? 3 * (APL + BPL) : (SPLIT == 2 ? BM * BK + SUB * 3 * BPL : (BM + BN) * BK);   // floats per buffer: A rows (planes), then B rows (planes)
+    constexpr int STEP = SPLIT == 3 ? 3 * (APL + BPL) : (SPLIT == 2 ? BM * BK + SUB * NP * BPL : (BM + BN) * BK);   // floats per buffer: A rows (planes), then B rows (planes)
     constexpr int UPT = BM * 2 / 256;                      // SPLIT 3: (row, 8-value half) units of the A tile per thread
     static_assert(SPLIT != 3 || (BK == 16 && UPT == 1), "SPLIT 3: 16-wide K-steps, 128-row tiles");
-    static_assert(TERMS == 3 || SPLIT == 2, "one-term products: the pre-split-weights form only");
+    static_assert(TERMS == 3 || SPLIT == 2, "one- and two-term products: the pre-split-weights form only");
     constexpr int LDT = BN + 4;                            // epilogue: padded output tile row
 #ifndef RN_SPLIT_NBUF
 #define RN_SPLIT_NBUF 2
@@ -209,7 +216,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                                  (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
     // per-image weights (w_batch_stride, in elements): a batch of GEMMs.  The pre-split form has 6 bytes per element.
     const v4i32 rs_b = PB
-        ? make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * 6, (unsigned)((int64_t)d.Cout * Kpad * 6))
+        ? make_rsrc(reinterpret_cast<const char *>(w) + (int64_t)n_first * d.w_batch_stride * EB, (unsigned)((int64_t)d.Cout * Kpad * EB))
         : make_rsrc(w + (int64_t)n_first * d.w_batch_stride, (unsigned)((int64_t)d.Cout * Kpad * 4));
 
     // ---- per-lane staging geometry: instruction j of this wave fills rows (wave*I + j)*RPI .. +RPI-1 of the operand;
@@ -243,9 +250,9 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     for (int j = 0; j < IB; ++j) {
         if constexpr (PB) {
             // instruction q fills 32 rows of one plane: lane -> (row, position), fetches chunk position ^ ((row >> 4) & 1)
-            const int q = wave * IB + j, sub = q / (3 * BN / 32), plane = (q / (BN / 32)) % 3, row = (q % (BN / 32)) * 32 + (lane >> 1);
+            const int q = wave * IB + j, sub = q / (NP * BN / 32), plane = (q / (BN / 32)) % NP, row = (q % (BN / 32)) * 32 + (lane >> 1);
             const int n = n0 + row;
-            b_voff[j] = (q < NBI && n < d.Cout) ? (unsigned)(n * Kpad * 6 + sub * 96 + plane * 32 + (((lane & 1) ^ ((row >> 4) & 1)) << 4)) : 0x80000000u;
+            b_voff[j] = (q < NBI && n < d.Cout) ? (unsigned)(n * Kpad * EB + sub * REC + plane * 32 + (((lane & 1) ^ ((row >> 4) & 1)) << 4)) : 0x80000000u;
         } else {
             const int row = (wave * IB + j) * RPI + rsub;
             const int n = n0 + row;
@@ -276,7 +283,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
         for (int j = 0; j < IB; ++j) {
             if constexpr (PB) {
-                if (4 * IB <= NBI || wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BOFF) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * SUB * 96));
+                if (4 * IB <= NBI || wave_u * IB + j < NBI) dma16(rs_b, lds0 + (unsigned)((buf * STEP + BOFF) * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * SUB * REC));
             } else {
                 dma16(rs_b, B + j * (RPI * BK * 4), b_voff[j], (unsigned)(ks * BK * 4));
             }
@@ -401,8 +408,62 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
         fbs[t] = BOFF + 4 * (2 * rb + ((lane >> 5) ^ ((rb >> 4) & 1)));
         fas[t] = 4 * (2 * ra + ((lane >> 5) ^ ((ra >> 4) & 1)));
     }
+    // TERMS 2: the power-of-two scale of each of this lane's two fragment rows (wm * 64 + t * 32 + (lane & 31)) from its image's amax
+    // table, and the inverses of all BM rows in a table of their own for the epilogue (written by the waves with wn == 0)
+    __shared__ float row_unscale[HALF ? BM : 1];
+    float a_scale[2] = {1.f, 1.f};
+    if constexpr (HALF) {
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(d.x_amax);
+        const void *tl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t m = (int64_t)m0 + wm * 64 + t * 32 + (lane & 31);
+            tl[t] = m < M ? tb + (int64_t)((unsigned)m / (unsigned)HoWo) * d.x_amax_img_stride * RN_AMAX_BYTES : nullptr;
+        }
+        int e[2];
+        if (d.x_amax_row_stride == 0) {                    // per image: its exponent table
+            e[0] = rn_amax_exp_lanes(tl[0]);
+            e[1] = __ballot(tl[1] != tl[0]) == 0ull ? e[0] : rn_amax_exp_lanes(tl[1]);
+        } else {                                           // per row: a plain word (the Winograd stage: rows are tiles)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t m = (int64_t)m0 + wm * 64 + t * 32 + (lane & 31);
+                e[t] = m < M ? (int)((reinterpret_cast<const unsigned *>(d.x_amax)[(int64_t)((unsigned)m % (unsigned)HoWo) * d.x_amax_row_stride] >> 23) & 0xffu) : 0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int se = rn_f16_scale_exp_of(e[t]);
+            a_scale[t] = rn_exp_to_float(se);
+            if (wn == 0 && lane < 32) row_unscale[wm * 64 + t * 32 + lane] = rn_exp_to_float(254 - se);
+        }
+    }
     auto multiply = [&](int buf) {
         const float *S = lds + buf * STEP;
+        if constexpr (HALF) {
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+                SplitH8 sa[2], sb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 p0 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub]), p1 = *reinterpret_cast<const float4 *>(S + fa[t][2 * sub + 1]);
+                    float av[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                    if (RELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) av[j] = fmaxf(av[j], 0.f);
+                    }
+                    sa[t] = split8h(av, a_scale[t]);
+                    const float *Bp = S + fbs[t] + sub * NP * BPL;
+                    sb[t].h = *reinterpret_cast<const f16x8 *>(Bp);
+                    sb[t].l = *reinterpret_cast<const f16x8 *>(Bp + BPL);
+                }
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) RN_SPLITH_MFMA(acc[tm][tn], sa[tm], sb[tn]);
+            }
+            return;
+        }
         if constexpr (SPLIT != 0) {
 #pragma unroll
             for (int sub = 0; sub < SUB; ++sub) {
@@ -424,7 +485,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                         sa[t] = split8(av);
                     }
                     if constexpr (PB) {
-                        const float *Bp = S + fbs[t] + sub * 3 * BPL;
+                        const float *Bp = S + fbs[t] + sub * NP * BPL;
                         sb[t].h = *reinterpret_cast<const bf16x8 *>(Bp);
                         sb[t].m = *reinterpret_cast<const bf16x8 *>(Bp + BPL);
                         sb[t].l = *reinterpret_cast<const bf16x8 *>(Bp + 2 * BPL);
@@ -616,7 +677,12 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t m = (int64_t)m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (m < M && col < d.Cout) y[m * d.Cout + col] = acc[tm][tn][e];
+                    if (m < M && col < d.Cout) {
+                        if constexpr (HALF) {                       // (row_unscale: written before the K loop's barriers)
+                            y[m * d.Cout + col] = acc[tm][tn][e] * row_unscale[m - m0] *
+                                                  d.w_unscale[(d.w_batch_stride != 0 ? (int64_t)n_first * d.Cout : 0) + col];
+                        } else y[m * d.Cout + col] = acc[tm][tn][e];
+                    }
                 }
             }
         return;
@@ -641,6 +707,7 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
     for (int j = 0; j < 4; ++j) {
         if (col_ok && j < ncol && scale != nullptr) sc[j] = scale[col + j];
         if (col_ok && j < ncol && shift != nullptr) sh[j] = shift[col + j];
+        if (HALF && col_ok && j < ncol) sc[j] *= d.w_unscale[(d.w_batch_stride != 0 ? (int64_t)n_first * d.Cout : 0) + col + j];
     }
 #pragma unroll
     for (int pass = 0; pass < EP; ++pass) {
@@ -685,7 +752,8 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
                         const int r = tid / CPR + (g + i) * RPP;
                         const int64_t m = (int64_t)m0 + pass * RP + r;
                         if (m < M) {
-                            const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                            float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                            if constexpr (HALF) { const float ru = row_unscale[pass * RP + r]; t.x *= ru; t.y *= ru; t.z *= ru; t.w *= ru; }
                             const int64_t off = off_[i];
                             float mk[4] = {mk_[i].x, mk_[i].y, mk_[i].z, mk_[i].w}, ad[4] = {ad_[i].x, ad_[i].y, ad_[i].z, ad_[i].w};
                             if (d.add2_mode == 3) {             // rare (1x1 stride-2 shortcut gradient): its address again, then the load
@@ -702,7 +770,8 @@ __device__ __forceinline__ void conv_igemm_tile(const rn_conv_desc &d, const flo
             for (int r = tid / CPR; r < RP; r += RPP) {
                 const int64_t m = (int64_t)m0 + pass * RP + r;
                 if (m >= M || !col_ok) break;
-                const float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
+                if constexpr (HALF) { const float ru = row_unscale[pass * RP + r]; t.x *= ru; t.y *= ru; t.z *= ru; t.w *= ru; }
                 if (partial != nullptr) {                        // split-K: raw partial tile, the finish kernel does the rest
                     float *pp = partial + m * d.Cout + col;
                     if (vec) *reinterpret_cast<float4 *>(pp) = t;

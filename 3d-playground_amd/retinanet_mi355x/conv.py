@@ -209,9 +209,9 @@ def split_weights_f16(w_packed):
 
 
 def f16_shape_ok(rows, cin, taps=1):
-    """Geometry half of rn_conv_igemm_wants_f16 (csrc/conv_igemm_mf16.hip: mf16_geom_ok) as the weight side sees it: which packed
-    tensors get the fp16 twin in split3 mode (the others keep the three-term bf16 twin and their kernels)."""
-    return rows > 64 and rows % 4 == 0 and cin % 32 == 0 and taps <= 24
+    """Which packed tensors get the fp16 twin in split3 mode: all of them (every split kernel has the two-term form since the second
+    half of round 5; before, the layers with at most 64 output channels / odd channel counts kept the three-term twin)."""
+    return True
 
 
 def _maybe_split(w_packed, rows=None, cin=None, taps=1):

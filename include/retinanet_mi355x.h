@@ -299,7 +299,7 @@ typedef struct rn_conv_desc {
  *                   of the tensor's maximum, an absolute 2^-40 of the maximum below that) and a product is hi*hi + hi*lo + lo*hi
  *                   on v_mfma_f32_16x16x32_f16 / 32x32x16_f16: THREE MFMAs instead of six (csrc/mfma_split.h, second half).  Weight
  *                   scales per output channel (rn_split_weights_f16), activation / gradient scales per tensor from amax words
- *                   (rn_conv_desc.x_amax).  Kernels that have no such form yet run the RN_FP32_SPLIT one in this mode.
+ *                   (rn_conv_desc.x_amax).  (The split-K form stays on the fp32 MFMA in every mode.)
  * Process-wide; initial value from the environment variable RN_FP32_MFMA = native | split | split3, else RN_FP32_DEFAULT. */
 #define RN_FP32_NATIVE 0
 #define RN_FP32_SPLIT 1
@@ -350,8 +350,9 @@ int rn_split_weights_f16(const float *w_packed, void *w_split, float *row_unscal
  * amax = [n_images][256] bytes, byte e of table i set when an element of image i has exponent field e (only the largest matters; the
  * kernel sets the largest per thread); zero the tables first.  One pass over x. */
 int rn_amax(const float *x, int64_t per_image, int n_images, void *amax, void *stream);
-/* 1 when rn_conv_igemm would run this problem on an fp16-split kernel in RN_FP32_SPLIT3 mode (so: wants w_format 3, x_amax, w_unscale),
- * 0 when it keeps the three-term kernels (w_format 0 / 1).  Depends on the geometry only. */
+/* 1 when rn_conv_igemm would run this problem on an fp16-split kernel (so: wants w_format 3, x_amax, w_unscale): in RN_FP32_SPLIT3 mode,
+ * every problem (the 16x16x32 kernel for the wide layers with Cin % 32 == 0, the two-term form of the 128 x 128 / 256 x 64 tile for the
+ * rest); 0 in the other modes. */
 int rn_conv_igemm_wants_f16(const rn_conv_desc *d);
 
 int rn_conv_igemm(const rn_conv_desc *d, const float *x, const float *w_packed, float *y,
