@@ -23,12 +23,15 @@ if [ "$part" = 2 ]; then
   python3 tools/summarize_traffic.py gpurun_out/traffic > "$O/pmc_traffic.json"
   echo "traffic done"
   timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 --dtype bf16 --no-cpu-baseline > "$O/bench_bf16.log" 2>&1
-  timeout -k 10 600 python3 bench.py --arch resnet101 --dtype fp8 --batch 16 --steps 10 --warmup 3 > "$O/bench_fp8_resnet101_b16.log" 2>&1
+  timeout -k 10 600 python3 bench.py --arch resnet101 --dtype fp8 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_fp8_train_resnet101_b16.log" 2>&1
+  timeout -k 10 400 python3 tools/fp8_error_budget.py > "$O/fp8_error_budget.txt" 2>&1
   timeout -k 10 300 python3 tools/bench_loss.py > "$O/loss_microbench.txt" 2>&1
   echo "part 2 done"
 fi
 if [ "$part" = 3 ]; then
+  timeout -k 10 300 python3 tools/bench_conv.py --mfma split3 > "$O/conv_microbench_split3.txt" 2>&1
   timeout -k 10 300 python3 tools/bench_conv.py --mfma split > "$O/conv_microbench_split.txt" 2>&1
+  for d in normal relu wide widepix; do timeout -k 10 200 python3 tools/fp32_mode_errors.py --data $d; done > "$O/fp32_split3_errors.txt" 2>&1
   timeout -k 10 300 python3 tools/profile_layers.py --dtype fp32 > "$O/fp32_step_by_shape.txt" 2>&1
   timeout -k 10 300 python3 tools/profile_layers.py > "$O/bf16_step_by_shape.txt" 2>&1
   timeout -k 10 300 python3 tools/profile_fp8_layers.py > "$O/fp8_forward_by_shape.txt" 2>&1
