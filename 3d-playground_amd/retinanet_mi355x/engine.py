@@ -46,9 +46,12 @@ def _qscale(t):
 def _as_fp8(t):
     if t is None or t.dtype == torch.uint8:
         return t
-    sc = _qscale(t)
-    assert sc, "a tensor entering an fp8 layer needs its calibrated scale (Layer.fwd tags its outputs)"
-    return cv.fp8_quantize(t, sc) if t.dtype == torch.float32 else cv.bf16_to_fp8(t, sc)
+    q = getattr(t, "_rn_q8", None)                  # a tensor read by several e4m3 layers (block input: conv1 and the shortcut) is quantised once
+    if q is None:
+        sc = _qscale(t)
+        assert sc, "a tensor entering an fp8 layer needs its calibrated scale (Layer.fwd tags its outputs)"
+        q = t._rn_q8 = cv.fp8_quantize(t, sc) if t.dtype == torch.float32 else cv.bf16_to_fp8(t, sc)
+    return q
 
 
 def _as_f32(t):
