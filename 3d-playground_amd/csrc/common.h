@@ -10,7 +10,7 @@
 // Diagnostic builds.  The kernels carry compile-time knock-outs, stamps and ablations (timing only, most give wrong results) that the
 // measurements in DESIGN.md / profiles/ were made with: RN_KO, RN_SPLIT_ABL, RN_STAMP, RN_SGB, RN_PIN_MFMA, RN_SPLIT_NBUF (conv_igemm_tile.h,
 // mfma_split.h), RN_WINO_ABL (conv_wino.hip), P8_ABL / P8_STAGGER (conv_bf16_p8.hip), Q8_ABL (conv_fp8_p8.hip), RN_AMAX_KO (mfma_split.h),
-// RN_MF16H_OCC (conv_igemm_mf16.hip).  They are honoured ONLY in a build with -DRN_EXPERIMENT=1 (tools/build_variant.sh adds it and writes
+// RN_MF16H_OCC / RN_MF16_KO (conv_igemm_mf16.hip).  They are honoured ONLY in a build with -DRN_EXPERIMENT=1 (tools/build_variant.sh adds it and writes
 // the library beside the product one); any other build drops them here, before the files that test them are read.
 #ifndef RN_EXPERIMENT
 #define RN_EXPERIMENT 0
@@ -28,6 +28,8 @@
 #undef Q8_ABL
 #undef RN_AMAX_KO
 #undef RN_MF16H_OCC
+#undef RN_MF16_KO
+#undef RN_MF16_PF
 #endif
 
 #define RN_LAUNCH_CHECK()                         \
@@ -144,6 +146,9 @@ __device__ __forceinline__ void dma16(v4i32 rsrc, unsigned lds_dst, unsigned vof
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void rn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... for all but the newest N vector-memory operations (they return in order)
+template <int N>
+__device__ __forceinline__ void rn_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }

@@ -44,6 +44,13 @@
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+#ifndef RN_MF16_PF
+#define RN_MF16_PF 1             // register sets of activation values in flight (A/B; RN_EXPERIMENT builds)
+#endif
+#ifndef RN_MF16_KO
+#define RN_MF16_KO 0             // knock-outs (RN_EXPERIMENT builds; timing only, wrong results): 1 no split / MFMAs, 2 no activation loads,
+#endif                           // 4 no result stores, 8 no weight DMA
+
 // acc += a * b for one 16 x 16 tile and 32 values of k: the six products, smallest first (mfma_split.h: RN_SPLIT_MFMA)
 #define RN_SPLIT_MFMA16(ACC, A, B)                                                        \
     do {                                                                                  \
@@ -126,6 +133,9 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     struct ARegs { f32x4v v[4]; };
     auto load_a = [&](ARegs &ar) {
+#if RN_MF16_KO & 2
+        if (f_c >= 0) { f_c += BK; return; }
+#endif
         const int t = f_r * d.kw + f_s;
         const int delta = (f_r * d.Wi + f_s) * d.b * d.Cin * 4;
 #pragma unroll
@@ -157,6 +167,9 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     }
     const unsigned lds0 = lds_addr(lds);
     auto dma_b = [&](int ks, int buf) {
+#if RN_MF16_KO & 8
+        if (ks > 0) return;
+#endif
 #pragma unroll
         for (int j = 0; j < IB; ++j)
             dma16(rs_b, lds0 + (unsigned)(buf * BSTEP * 4 + (wave_u * IB + j) * 1024), b_voff[j], (unsigned)(ks * 2 * REC));
@@ -174,8 +187,11 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // ---- K loop.  `cur` holds the A values of step ks (loaded during step ks - 1): split into the MFMA operands, then the same
     // registers receive step ks + 1 -- a whole MFMA phase to arrive.  Unconditional (one basic block): past the last step the loads
     // return zeros / stale weights nobody uses, and all have landed (vmcnt(0)) before the epilogue reuses the LDS.
-    ARegs cur;
-    load_a(cur); dma_b(0, 0);
+    constexpr int PF = RN_MF16_PF;                         // K-steps of activation values in flight (register sets)
+    ARegs ar[PF] = {};
+    load_a(ar[0]); dma_b(0, 0);
+#pragma unroll
+    for (int i = 1; i < PF; ++i) load_a(ar[i]);
     if constexpr (HALF) {
         // the rows' scales, while the first operands travel: per image from its exponent table (one 256-byte read per wave and image --
         // a wave's 32 rows lie in one image, rarely two), or per row from the plain words the Winograd input transform wrote
@@ -197,11 +213,20 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             if (lg == 0) row_unscale[32 * wave + 16 * sm + lr] = rn_exp_to_float(254 - se);      // (the wave's own rows: no other wave reads them)
         }
     }
-    rn_wait_dma();
+    rn_wait_but<4 * (PF - 1)>();
     __syncthreads();
-    auto k_step = [&](int ks, int rb) {
+    auto k_step = [&](int ks, int rb, ARegs &cur) {
         asm volatile("" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]));   // the compiler's wait for `cur` here, where it is free
         typename std::conditional<HALF, SplitH8, Split8>::type sa[2];
+#if RN_MF16_KO & 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q & 1][q >> 1] += cur.v[q];
+        dma_b(ks + 1, rb ^ 1);
+        load_a(cur);
+        rn_wait_dma();
+        __syncthreads();
+        if (ks >= 0) return;
+#endif
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm) {
             const float av[8] = {cur.v[2 * sm][0], cur.v[2 * sm][1], cur.v[2 * sm][2], cur.v[2 * sm][3],
@@ -230,12 +255,16 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             }
         }
         RN_PIN();
-        rn_wait_dma();                                      // B planes of step ks + 1 landed, A registers of step ks + 1 arrived
+        // B planes of step ks + 1 landed, A registers of step ks + 1 arrived: everything but the newest PF - 1 sets of four loads
+        // (the memory pipe returns in order, and the four loads of step ks + PF were issued last)
+        rn_wait_but<4 * (PF - 1)>();
         __syncthreads();
     };
-    for (int ks = 0; ks < nks; ks += 2) {
-        k_step(ks, 0);
-        if (ks + 1 < nks) k_step(ks + 1, 1);
+    constexpr int UN = PF > 2 ? PF : 2;
+    for (int ks = 0; ks < nks; ks += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (u == 0 || ks + u < nks) k_step(ks + u, u & 1, ar[u % PF]);
     }
 
     // ---- epilogue, WAVE-PRIVATE: a wave owns tile rows 32 w .. 32 w + 31 and all 128 columns, so it transposes its accumulators
@@ -303,6 +332,9 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                             { RN_EPI_ADDR(GENERAL) a2 = a2off; (void)aoff; (void)off; }
                             if (a2 >= 0) { const float4 q = *reinterpret_cast<const float4 *>(add2 + a2); ad[0] += q.x; ad[1] += q.y; ad[2] += q.z; ad[3] += q.w; }
                         }
+#if RN_MF16_KO & 4
+                        if (t.x != 1.2345f) continue;
+#endif
                         if (RAW) *reinterpret_cast<float4 *>(y + off) = HALF ? make_float4(t.x * sc[0], t.y * sc[1], t.z * sc[2], t.w * sc[3]) : t;
                         else { RN_EPI_FINISH() }
                     }
