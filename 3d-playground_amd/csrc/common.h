@@ -30,6 +30,7 @@
 #undef RN_MF16H_OCC
 #undef RN_MF16_KO
 #undef RN_MF16_PF
+#undef RN_MF16_STG
 #endif
 
 #define RN_LAUNCH_CHECK()                         \

@@ -37,6 +37,13 @@
 // power-of-two scale), the activation values are multiplied by the tensor's power-of-two scale (from its amax word, one scalar load per
 // workgroup) inside the split, and the epilogue multiplies every column by the two inverse scales (folded into the batch-norm scale it
 // multiplies by anyway; one extra multiplication per element in the plain-GEMM form).  32 KB of weight planes instead of 48.
+//
+// STG (round 5, second half; TERMS 2, launches with K >= 256): the activation operand IS staged after all -- not for the LDS's sake but for the
+// vector-memory pipe's, which pays per cache line a quarter-wave touches: the operand layout read straight from memory (16 consecutive lanes =
+// 16 rows) runs at 9.2 TB/s chip-wide even out of the L2, row-coalesced loads at 31 (tools/probes/a_pattern_probe.hip,
+// profiles/r05_mf16_bounds.txt).  A wave fetches its own 32 rows x 128 bytes of the K-step by four direct-to-LDS instructions of 8 rows each
+// into a 4 KB strip nobody else touches (no extra barrier: its own s_waitcnt orders it) and reads them back as operands, conflict-free
+// (conv_wgrad_geom.h: Mf16AGeom).  The rows' geometry -- the divisions -- is computed once per row into a table instead of once per reader.
 #include <type_traits>
 
 #include "conv_igemm_tile.h"
@@ -44,6 +51,9 @@
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+#ifndef RN_MF16_STG
+#define RN_MF16_STG 1            // the fp16 form stages its activations through the LDS (row-coalesced loads); 0: straight into registers (A/B)
+#endif
 #ifndef RN_MF16_PF
 #define RN_MF16_PF 1             // register sets of activation values in flight (A/B; RN_EXPERIMENT builds)
 #endif
@@ -62,7 +72,7 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
     } while (0)
 
-template <bool GENERAL, bool RAW, int TERMS>
+template <bool GENERAL, bool RAW, int TERMS, bool STG>
 __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
                                                float *__restrict__ y, const float *__restrict__ scale,
                                                const float *__restrict__ shift, const float *__restrict__ add,
@@ -106,10 +116,15 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     unsigned a_mask[2];
     int a_base[2];
     int a_n[2] = {-1, -1}, a_rem[2] = {0, 0};              // TERMS 2: the rows' images (absolute) and pixels; -1: a row past M
-#pragma unroll
-    for (int sm = 0; sm < 2; ++sm) {
-        const int row = 32 * wave + 16 * sm + lr;
+    // STG: the wave's 32 rows x 32 values of a K-step are STAGED -- row-coalesced direct-to-LDS loads into a 4 KB strip of the wave's own
+    // (conv_wgrad_geom.h: Mf16AGeom), read back in the operand layout.  A lane fills rows 8 j + (lane >> 3), j = 0 .. 3.
+    __shared__ __attribute__((aligned(16))) char a_stage[STG ? 4 * Mf16AGeom::WAVE_BYTES : 16];
+    __shared__ int4 row_tab[STG ? BM : 1];                 // per tile row: (byte offset of its pixel at tap (0, 0), tap mask, image, pixel)
+    unsigned s_mask[4] = {0u, 0u, 0u, 0u};
+    int s_base[4] = {0, 0, 0, 0};
+    auto row_geom = [&](int row, unsigned &mk, int &base, int &n_abs, int &rem_) {
         int a_h = -(1 << 28), a_w = 0, a_img = 0;
+        n_abs = -1; rem_ = 0;
         if ((int64_t)m0 + row < M) {
             const unsigned rel = (unsigned)(m0 - n_first * HoWo + row);
             const unsigned n = rel / (unsigned)HoWo;
@@ -118,16 +133,41 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             a_img = (int)((int64_t)n * d.x_batch_stride * 4);
             a_h = (int)oh * d.a + d.p;
             a_w = (int)ow * d.a + d.p_w;
-            if constexpr (HALF) { a_n[sm] = n_first + (int)n; a_rem[sm] = (int)rem; }
+            n_abs = n_first + (int)n; rem_ = (int)rem;
         }
-        unsigned mk = 0;
+        mk = 0;
         for (int r = 0, t = 0; r < d.kh; ++r)
             for (int s_ = 0; s_ < d.kw; ++s_, ++t) {
                 const int ih = a_h + r * d.b, iw = a_w + s_ * d.b;
                 mk |= (unsigned)(((ih | iw) >= 0) & (ih < d.Hi) & (iw < d.Wi)) << t;
             }
-        a_mask[sm] = mk;
-        a_base[sm] = a_img + ((a_h * d.Wi + a_w) * d.Cin + 8 * lg) * 4;
+        base = a_img + (a_h * d.Wi + a_w) * d.Cin * 4;
+    };
+    if constexpr (STG) {
+        if (tid < BM) {                                    // one thread per tile row: the divisions once, not once per reader
+            unsigned mk; int base, n_abs, rem_;
+            row_geom(tid, mk, base, n_abs, rem_);
+            row_tab[tid] = make_int4(base, (int)mk, n_abs, rem_);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int4 e = row_tab[32 * wave + Mf16AGeom::dma_row(lane, j)];
+            s_base[j] = e.x + 16 * Mf16AGeom::dma_chunk(lane, j);
+            s_mask[j] = (unsigned)e.y;
+        }
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const int4 e = row_tab[32 * wave + 16 * sm + lr];
+            a_n[sm] = e.z; a_rem[sm] = e.w;
+            a_mask[sm] = 0u; a_base[sm] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            row_geom(32 * wave + 16 * sm + lr, a_mask[sm], a_base[sm], a_n[sm], a_rem[sm]);
+            a_base[sm] += 8 * lg * 4;
+        }
     }
     int f_r = 0, f_s = 0, f_c = 0;                         // tap and channel offset of the next step to load
     typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -152,6 +192,40 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
         const bool wrap_s = f_s == d.kw;
         f_s = wrap_s ? 0 : f_s;
         f_r += wrap_s ? 1 : 0;
+    };
+
+    // STG: the K-step's 32 values of the wave's 32 rows -> its strip (four instructions of 8 rows x 128 bytes), and back as operands
+    const v4i32 rs_a4 = make_rsrc(x + (int64_t)n_first * d.x_batch_stride, (unsigned)(x_floats * 4 > 0x7FFFFFFF ? 0x7FFFFFFF : x_floats * 4));
+    const unsigned a_lds0 = lds_addr(a_stage) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * Mf16AGeom::WAVE_BYTES;
+    auto dma_a = [&]() {
+#if RN_MF16_KO & 2
+        if (f_c >= 0) { f_c += BK; return; }
+#endif
+        const int t = f_r * d.kw + f_s;
+        const int delta = (f_r * d.Wi + f_s) * d.b * d.Cin * 4;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(f_c * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned valid = 0u - ((s_mask[j] >> (t & 31)) & 1u);
+            dma16(rs_a4, a_lds0 + 1024u * j, ((unsigned)(s_base[j] + delta) & valid) | (0x80000000u & ~valid), soff);
+        }
+        f_c += BK;
+        const bool wrap = f_c >= d.Cin;
+        f_c = wrap ? 0 : f_c;
+        f_s += wrap ? 1 : 0;
+        const bool wrap_s = f_s == d.kw;
+        f_s = wrap_s ? 0 : f_s;
+        f_r += wrap_s ? 1 : 0;
+    };
+    const char *a_rd = a_stage + wave * Mf16AGeom::WAVE_BYTES;
+    const int a_ra[2][2] = {{Mf16AGeom::read_addr(lane, 0, 0), Mf16AGeom::read_addr(lane, 0, 1)},
+                            {Mf16AGeom::read_addr(lane, 1, 0), Mf16AGeom::read_addr(lane, 1, 1)}};
+    auto read_a = [&](ARegs &ar) {
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            ar.v[2 * sm] = *reinterpret_cast<const f32x4v *>(a_rd + a_ra[sm][0]);
+            ar.v[2 * sm + 1] = *reinterpret_cast<const f32x4v *>(a_rd + a_ra[sm][1]);
+        }
     };
 
     // ---- weight planes: instruction q of the workgroup fills 16 rows of one plane; lane -> row (lane >> 2), slot (lane & 3).
@@ -188,8 +262,10 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // registers receive step ks + 1 -- a whole MFMA phase to arrive.  Unconditional (one basic block): past the last step the loads
     // return zeros / stale weights nobody uses, and all have landed (vmcnt(0)) before the epilogue reuses the LDS.
     constexpr int PF = RN_MF16_PF;                         // K-steps of activation values in flight (register sets)
+    static_assert(!STG || PF == 1, "staged activations: one step in flight");
     ARegs ar[PF] = {};
-    load_a(ar[0]); dma_b(0, 0);
+    if constexpr (STG) dma_a(); else load_a(ar[0]);
+    dma_b(0, 0);
 #pragma unroll
     for (int i = 1; i < PF; ++i) load_a(ar[i]);
     if constexpr (HALF) {
@@ -213,16 +289,23 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             if (lg == 0) row_unscale[32 * wave + 16 * sm + lr] = rn_exp_to_float(254 - se);      // (the wave's own rows: no other wave reads them)
         }
     }
+    constexpr int CPR = BN / 4, RPI = 64 / CPR;              // 16-byte chunks per row, rows one wave instruction covers
+    const int c4 = lane % CPR;
+    const int col = n0 + 4 * c4;
+    const bool col_ok = col < d.Cout;
+    const bool vec = true;                                   // the launcher sends Cout % 4 == 0 only
+    const int ncol = 4;
     rn_wait_but<4 * (PF - 1)>();
     __syncthreads();
     auto k_step = [&](int ks, int rb, ARegs &cur) {
+        if constexpr (STG) read_a(cur);                     // step ks landed in the strip (the wait that ended the previous step)
         asm volatile("" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]));   // the compiler's wait for `cur` here, where it is free
         typename std::conditional<HALF, SplitH8, Split8>::type sa[2];
 #if RN_MF16_KO & 1
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q & 1][q >> 1] += cur.v[q];
         dma_b(ks + 1, rb ^ 1);
-        load_a(cur);
+        if constexpr (STG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dma_a(); } else load_a(cur);
         rn_wait_dma();
         __syncthreads();
         if (ks >= 0) return;
@@ -235,7 +318,12 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
             else sa[sm] = split8(av);
         }
         dma_b(ks + 1, rb ^ 1);
-        load_a(cur);
+        if constexpr (STG) {
+            // the strip is this wave's own: its reads above have returned (the split consumed them; the explicit wait is for the asm
+            // below, which the compiler does not order against them), so step ks + 1 may land on top
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_a();
+        } else load_a(cur);
         const float *S = lds + rb * BSTEP + fb0;
 #pragma unroll
         for (int sn = 0; sn < NSN; ++sn) {
@@ -273,12 +361,8 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // 16 x 16 tile; out of the strip a lane takes float4s: BN / 4 consecutive lanes one whole row segment, so out, add and mask all
     // move as 16-byte accesses (conv_igemm_tile.h: same arithmetic, same macros).
     float *T = lds + wave * (16 * LDT);
-    constexpr int CPR = BN / 4, RPI = 64 / CPR;              // 16-byte chunks per row, rows one wave instruction covers
-    const int c4 = lane % CPR;
-    const int col = n0 + 4 * c4;
-    const bool col_ok = col < d.Cout;
-    const bool vec = true;                                   // the launcher sends Cout % 4 == 0 only
-    const int ncol = 4;
+    // (requesting these factors BEFORE the K loop, to have their latency covered, costs 8 % of the family's time -- 29.8 -> 32.3 ms per
+    // training step, tools/dbg/ab_lib.sh -- they stay here)
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -350,13 +434,13 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
 #ifndef RN_MF16H_OCC
 #define RN_MF16H_OCC 3           // workgroups per CU the fp16 form's registers are cut for (120 registers, 33 KB of LDS: 4 fit; A/B below)
 #endif
-template <bool GENERAL, bool RAW, int TERMS>
+template <bool GENERAL, bool RAW, int TERMS, bool STG>
 __global__ __launch_bounds__(256, TERMS == 2 ? RN_MF16H_OCC : 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const float *__restrict__ add, const float *__restrict__ mask,
                                                               const float *__restrict__ add2) {
-    conv_mf16_tile<GENERAL, RAW, TERMS>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_mf16_tile<GENERAL, RAW, TERMS, STG>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 template <int TERMS>
@@ -374,7 +458,7 @@ __global__ __launch_bounds__(256, TERMS == 2 ? RN_MF16H_OCC : 3) void conv_igemm
 #pragma unroll
     for (int i = 1; i < RN_MAX_GROUP; ++i)
         if (p == i) { d = g.d[i]; x = g.x[i]; y = g.y[i]; add = g.add[i]; mask = g.mask[i]; first = g.tile_end[i - 1]; }
-    conv_mf16_tile<true, false, TERMS>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
+    conv_mf16_tile<true, false, TERMS, TERMS == 2 && RN_MF16_STG != 0>(d, x, w, y, scale, shift, add, mask, nullptr, tile - first);
 }
 
 // Which problems take this kernel: RN_OPT_MF16 = 0 turns it off (A/B); launches with fewer than RN_OPT_MF16_MIN tiles keep the
@@ -408,15 +492,19 @@ bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, co
     const int64_t tiles = mf16_tiles(d);
     if (tiles < mf16_min_tiles() || tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles), block(256);
-#define RN_MF16_LAUNCH(G, R, T) hipLaunchKernelGGL((conv_igemm_mf16_kernel<G, R, T>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
+#define RN_MF16_LAUNCH(G, R, T, S) hipLaunchKernelGGL((conv_igemm_mf16_kernel<G, R, T, S>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
     if (d->w_format == 3) {
-        if (variant == 0) RN_MF16_LAUNCH(false, true, 2);
-        else if (variant == 4) RN_MF16_LAUNCH(false, false, 2);
-        else RN_MF16_LAUNCH(true, false, 2);
+        // staged activations (row-coalesced direct-to-LDS loads) where the K loop is long enough to pay for the longer prologue: measured
+        // -4 % on the Winograd GEMMs (K = 256) and K >= 1024, +8 % on K = 64 / 128 (profiles/r05_mf16_bounds.txt, 4)
+        static const int stg_min_k = [] { const char *e = getenv("RN_MF16_STG_MIN_K"); return e ? atoi(e) : 256; }();
+        const bool stg = RN_MF16_STG != 0 && d->kh * d->kw * d->Cin >= stg_min_k;
+        if (variant == 0) { if (stg) RN_MF16_LAUNCH(false, true, 2, true); else RN_MF16_LAUNCH(false, true, 2, false); }
+        else if (variant == 4) { if (stg) RN_MF16_LAUNCH(false, false, 2, true); else RN_MF16_LAUNCH(false, false, 2, false); }
+        else { if (stg) RN_MF16_LAUNCH(true, false, 2, true); else RN_MF16_LAUNCH(true, false, 2, false); }
     } else {
-        if (variant == 0) RN_MF16_LAUNCH(false, true, 3);
-        else if (variant == 4) RN_MF16_LAUNCH(false, false, 3);
-        else RN_MF16_LAUNCH(true, false, 3);
+        if (variant == 0) RN_MF16_LAUNCH(false, true, 3, false);
+        else if (variant == 4) RN_MF16_LAUNCH(false, false, 3, false);
+        else RN_MF16_LAUNCH(true, false, 3, false);
     }
 #undef RN_MF16_LAUNCH
     const hipError_t e = hipGetLastError();

@@ -82,3 +82,23 @@ struct Mf16Geom {
     // the chunk a direct-to-LDS lane must FETCH so that it lands in its linear slot: lane -> row (lane >> 2) of a 16-row block, slot lane & 3
     static RN_HD int dma_chunk(int lane) { return (lane & 3) ^ (3 * ((lane >> 5) & 1)); }
 };
+
+// The ACTIVATION operand of the same kernel, staged (round 5): a wave's 32 tile rows x 32 fp32 values of a K-step = 128-byte rows of eight
+// 16-byte chunks, filled by direct-to-LDS loads that are ROW-COALESCED -- eight consecutive lanes fetch one row's 128 bytes, a wave
+// instruction eight rows -- because the vector-memory pipe pays per cache line a quarter-wave touches: the operand layout read straight
+// from memory (16 lanes = 16 rows, 16 bytes each) runs at 9.2 TB/s chip-wide even out of the L2, this one at 31
+// (tools/probes/a_pattern_probe.hip, profiles/r05_mf16_bounds.txt).  Lane (r = lane & 15, g = lane >> 4) then reads chunks 2g, 2g + 1 of
+// row 16 sm + r by ds_read_b128; chunk c of row `row` sits at slot c ^ fz(row), chosen so that every 16-lane group of the instruction
+// covers the 16 slots of the 256-byte bank row (two 128-byte rows) once.
+struct Mf16AGeom {
+    static constexpr int ROWB = 128, ROWS = 32, WAVE_BYTES = ROWS * ROWB;
+    static RN_HD int fz(int row) { const int i = (row >> 1) & 7; return i ^ (((i + 2) & 4) >> 1); }
+    // byte address (within the wave's stage) of the operand read `h` (0 / 1) of lane `lane` for row block sm
+    static RN_HD int read_addr(int lane, int sm, int h) {
+        const int row = 16 * sm + (lane & 15);
+        return ROWB * row + 16 * ((2 * (lane >> 4) + h) ^ fz(row));
+    }
+    // direct-to-LDS instruction j (0 .. 3) of a wave fills rows 8 j .. 8 j + 7 linearly: lane -> row 8 j + (lane >> 3), slot lane & 7
+    static RN_HD int dma_row(int lane, int j) { return 8 * j + (lane >> 3); }
+    static RN_HD int dma_chunk(int lane, int j) { return (lane & 7) ^ fz(dma_row(lane, j)); }      // the chunk it must fetch
+};

@@ -367,6 +367,18 @@ def wino_weights(weight, mode=0, scale=None):
 
 
 _WINO_WS = {}
+_WINO_ODD_PLANES = os.environ.get("RN_WINO_ODD_PLANES", "1") != "0"
+
+
+def wino_tpad(T):
+    """Rows of one of the 36 planes of V / M / Z for T tiles: a multiple of 256 (no GEMM tile straddles two planes) -- and an ODD one.
+    The 36 values a thread of the output transform combines lie one plane apart; with an even count the planes of the head towers are
+    43 x 512 KiB apart, the same low 19 address bits 36 times, and the transform reads at 4.6 instead of 5.0 TB/s
+    (tools/dbg/wino_stride.py, profiles/r05_wino_plane_stride.txt).  RN_WINO_ODD_PLANES=0: the plain round-up (A/B)."""
+    n = (T + 255) // 256
+    if _WINO_ODD_PLANES and n % 2 == 0:
+        n += 1
+    return n * 256
 
 
 def _wino_group(xs, srcs=None, dsts=None, adds=None, masks=None, mask_bits=False, signs=None, amaxs=None):
@@ -432,7 +444,7 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     cout = U.shape[1]                                # rows of the transformed weights = output channels
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
-    Tpad = (T + 255) // 256 * 256
+    Tpad = wino_tpad(T)
     V, M = _wino_workspace(dev, 0 if keep_v else 36 * Tpad * C, 36 * Tpad * cout)
     shapes = tuple(tuple(x.shape) for x in xs)
     reuse = keep_v and V_in is not None and V_in[1] == shapes and V_in[0].numel() == 36 * Tpad * C   # (V, shapes) of the same inputs
@@ -496,7 +508,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
     C, cout = xs[0].shape[3], gs[0].shape[3]
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
-    Tpad = (T + 255) // 256 * 256
+    Tpad = wino_tpad(T)
     # V: (B^T d B of the forward's inputs, their shapes) kept by wino_conv_group(keep_v=True); used only for the same grouping
     have_v = V is not None and V[1] == tuple(tuple(x.shape) for x in xs) and V[0].numel() == 36 * Tpad * C
     v_tw = V[2][1] if have_v and len(V) > 2 and V[2] is not None else None      # split3: the kept transform's tensor word

@@ -391,6 +391,14 @@ def pmc_traffic(kind):
     return int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n) if n else None
 
 
+def step_traffic():
+    """HBM bytes of one whole training step (all kernels) from the same PMC collection, or None when it is not this run's sources."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path) or not traffic_source()["matches_current_sources"]:
+        return None
+    return json.load(open(path)).get("_meta", {}).get("step_total_hbm_bytes")
+
+
 _TRAFFIC_SOURCE = {}
 
 
@@ -686,6 +694,20 @@ def main():
                                                   "bf16 kernels in this mode execute 6)" if fp32_mode == "split3"
                                                   else "2500 TF dense bf16 MFMA / 6 MFMAs per fp32 product")
                     kernels[kind]["frac_of_fp32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TF, 4)
+                if a.get("bytes_total") and a["ms_total"] > 0:
+                    # Which roof bounds the family (the roofline model's own rule): its arithmetic intensity -- algorithmic FLOPs over
+                    # algorithmic bytes, every operand once -- against the ridge point peak / 8 TB/s.  Below the ridge the attainable rate
+                    # is intensity x bandwidth and the family is priced against HBM; the matrix-core fraction stays beside it.
+                    k = kernels[kind]
+                    gbs = a["bytes_total"] / (a["ms_total"] * 1e-3) / 1e9
+                    intensity = a["work_total"] / a["bytes_total"]
+                    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+                    k["intensity_flop_per_byte"], k["ridge_flop_per_byte"] = round(intensity, 1), round(ridge, 1)
+                    k["attainable_tflops"] = round(min(peak, intensity * PEAK_HBM_GBS * 1e-3), 1)
+                    k["mfma_frac"], k["hbm_gbs"], k["hbm_frac"] = k["frac"], round(gbs, 1), round(gbs / PEAK_HBM_GBS, 4)
+                    if intensity < ridge:
+                        k.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "achieved_tflops": round(tf, 2), "mfma_peak_tflops": round(peak, 1)})
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             r = dict(kernels[dom])
             r["kernel"] = dom
@@ -700,6 +722,13 @@ def main():
                     r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
             line["roofline"] = r
             line["kernels"] = kernels
+            step_bytes = step_traffic()
+            if step_bytes and world == 1:
+                # the WHOLE step against the memory roof: every kernel's HBM bytes (same PMC passes) over the step's wall time
+                gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+                line["step_hbm"] = {"bytes_per_step": step_bytes, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                    "note": "all kernels of one training step, HBM bytes from the PMC passes named in roofline.traffic_source"}
         if timer is not None and args.sections == "all":
             kernels.update(loss_kernel_roofline(dev, B, H, W))
             # north_star target "MFMA roofline on the ResNet-50-FPN forward": conv kernels of forward-only passes, with the

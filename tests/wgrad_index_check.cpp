@@ -152,6 +152,44 @@ static void check_mf16() {
     std::printf("ok mf16: weight planes of 64-byte rows, ds_read_b128 lane groups conflict-free\n");
 }
 
+// conv_igemm_mf16.hip, staged activations: the 16-lane groups of both operand reads conflict-free, the fill consistent with the reads
+static void check_mf16_a() {
+    using G = Mf16AGeom;
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    for (int sm = 0; sm < 2; ++sm)
+        for (int h = 0; h < 2; ++h)
+            for (int g = 0; g < 4; ++g) {
+                std::set<int> slots;
+                for (int i = 0; i < 16; ++i) {
+                    const int a = G::read_addr(groups[g][i], sm, h);
+                    CHECK(a >= 0 && a + 16 <= G::WAVE_BYTES && a % 16 == 0, "mf16 A: read address %d of lane %d", a, groups[g][i]);
+                    slots.insert((a % 256) / 16);
+                }
+                CHECK((int)slots.size() == 16, "mf16 A: lane group %d (block %d, read %d) covers %d of the 16 slots", g, sm, h, (int)slots.size());
+            }
+    // every (row, chunk) is fetched exactly once, into the slot its reader expects; a lane reads chunks 2g, 2g + 1 of its row
+    std::set<int> filled;
+    for (int j = 0; j < 4; ++j)
+        for (int l = 0; l < 64; ++l) {
+            const int row = G::dma_row(l, j), c = G::dma_chunk(l, j);
+            CHECK(row >= 0 && row < G::ROWS && c >= 0 && c < 8, "mf16 A: instruction %d lane %d fetches row %d chunk %d", j, l, row, c);
+            CHECK((c ^ G::fz(row)) == (l & 7), "mf16 A: instruction %d lane %d: chunk %d of row %d belongs at slot %d", j, l, c, row, c ^ G::fz(row));
+            CHECK(G::ROWB * row + 16 * (l & 7) == 1024 * j + 16 * l, "mf16 A: instruction %d lane %d does not land linearly", j, l);
+            filled.insert(row * 8 + c);
+        }
+    CHECK((int)filled.size() == 32 * 8, "mf16 A: %d of 256 (row, chunk) pairs fetched", (int)filled.size());
+    for (int sm = 0; sm < 2; ++sm)
+        for (int l = 0; l < 64; ++l)
+            for (int h = 0; h < 2; ++h) {
+                const int a = G::read_addr(l, sm, h), row = a / G::ROWB, c = ((a % G::ROWB) / 16) ^ G::fz(row);
+                CHECK(row == 16 * sm + (l & 15) && c == 2 * (l >> 4) + h, "mf16 A: lane %d reads row %d chunk %d", l, row, c);
+            }
+    std::printf("ok mf16 A: staged activation rows of 128 bytes, ds_read_b128 lane groups conflict-free, row-coalesced fill\n");
+}
+
 int main() {
     check_fp32<1, 4, 16>("fp32 64x256");       // the three instances rn_conv_wgrad_batched launches (conv_wgrad.hip)
     check_fp32<4, 1, 16>("fp32 256x64");
@@ -160,6 +198,7 @@ int main() {
     check_bf16();
     check_split_once();
     check_mf16();
+    check_mf16_a();
     if (fails) std::printf("%d violation(s)\n", fails);
     return fails ? 1 : 0;
 }
