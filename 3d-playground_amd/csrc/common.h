@@ -31,6 +31,7 @@
 #undef RN_MF16_KO
 #undef RN_MF16_PF
 #undef RN_MF16_STG
+#undef RN_WG_KO
 #endif
 
 #define RN_LAUNCH_CHECK()                         \

@@ -28,6 +28,17 @@
 #include "common.h"
 #include "conv_wgrad_geom.h"
 
+#ifndef RN_WG_KO
+#define RN_WG_KO 0       // conv_wgrad.hip: 1 no tile atomics, 2 workgroup-scope atomics (RN_EXPERIMENT builds, timing only)
+#endif
+#if RN_WG_KO == 1
+#define RN_WG_ATOMIC(P, V) do { if ((V) == 1.2345e-30f) atomicAdd((P), (V)); } while (0)
+#elif RN_WG_KO == 2
+#define RN_WG_ATOMIC(P, V) __hip_atomic_fetch_add((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define RN_WG_ATOMIC(P, V) atomicAdd((P), (V))
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -827,7 +838,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradBf16Args &p, con
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < p.Cout && col < p.Kflat) atomicAdd(p.dw + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
+                if (row < p.Cout && col < p.Kflat) RN_WG_ATOMIC(p.dw + (int64_t)row * p.Kpad + col, acc[tm][tn][e]);
             }
         }
 }

@@ -39,6 +39,18 @@
 
 #include "common.h"
 #include "conv_wgrad_geom.h"
+
+// RN_WG_KO (RN_EXPERIMENT builds; timing only, wrong results): 1 = the tile-sized atomic accumulation left out, 2 = workgroup-scope atomics
+#ifndef RN_WG_KO
+#define RN_WG_KO 0
+#endif
+#if RN_WG_KO == 1
+#define RN_WG_ATOMIC(P, V) do { if ((V) == 1.2345e-30f) atomicAdd((P), (V)); } while (0)
+#elif RN_WG_KO == 2
+#define RN_WG_ATOMIC(P, V) __hip_atomic_fetch_add((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define RN_WG_ATOMIC(P, V) atomicAdd((P), (V))
+#endif
 #include "mfma_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_kernel(const WgradArgs p)
                 if (row < p.Cout && col < p.Kflat) {
                     const float v = HALF ? acc[tm][tn][e] * us : acc[tm][tn][e];
                     if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = v;
-                    else atomicAdd(out + (int64_t)row * p.Kpad + col, v);
+                    else RN_WG_ATOMIC(out + (int64_t)row * p.Kpad + col, v);
                 }
             }
         }
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_once_kernel(const WgradArgs
                 if (row < p.Cout && col < p.Kflat) {
                     const float v = HALF ? acc[tm][tn][e] * us : acc[tm][tn][e];
                     if (p.slab != nullptr) out[(int64_t)row * p.Kpad + col] = v;
-                    else atomicAdd(out + (int64_t)row * p.Kpad + col, v);
+                    else RN_WG_ATOMIC(out + (int64_t)row * p.Kpad + col, v);
                 }
             }
         }

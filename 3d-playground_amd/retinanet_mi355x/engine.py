@@ -681,6 +681,19 @@ class Engine:
             st = self._tower_streams[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
         return st
 
+    def wgrad_streams(self, device):
+        """The side streams the backbone's and the pyramid's weight gradients run on (taken in turn), or None (RN_WGRAD_STREAMS=0, and
+        where tower_streams gives None).  A weight gradient needs only its layer's output gradient and saved input -- nothing downstream
+        waits for it but the gradient bookkeeping -- and every launch ends in a tail (the last round's workgroups draining tile-sized
+        atomics: 14 % of the weight-gradient time, profiles/r05_wgrad_stream.txt) that the data gradients of the main stream run under."""
+        n = int(os.environ.get("RN_WGRAD_STREAMS", "1"))
+        if n <= 0 or self.tower_streams(device) is None:
+            return None
+        st = self._tower_streams.get(("wgrad", device, n))
+        if st is None:
+            st = self._tower_streams[("wgrad", device, n)] = [torch.cuda.Stream(device) for _ in range(n)]
+        return st
+
     def anchors(self, H, W, device):
         key = (H, W, str(device))
         if key not in self.anchor_cache:
@@ -1085,6 +1098,29 @@ class Engine:
         batched = flat is not None and self.grad_hook is None and os.environ.get("RN_BATCHED_UNPACK", "1") != "0"
         pending = []
 
+        # Weight gradients on a stream of their own (wgrad_stream), joined where their results are first read: the bucket's unpack launch.
+        # (Only with the batched unpack: a per-layer finish would join after every layer.)
+        main0 = torch.cuda.current_stream(dreg.device) if dreg.is_cuda else None
+        wss = self.wgrad_streams(dreg.device) if batched else None
+        wg_count = 0
+
+        def wg(L, g, x, in_relu=False):
+            """L.bwd_params(g, x) -- on the weight-gradient stream unless the layer's Winograd pass also prepares its data gradient."""
+            nonlocal wg_count
+            if wss is None or (L.wino_active and not L.bf16):
+                L.bwd_params(g, x, in_relu=in_relu)
+                return
+            ws = wss[wg_count % len(wss)]
+            wg_count += 1
+            ws.wait_event(torch.cuda.current_stream(g.device).record_event())      # g, x and the zeroed accumulators are ready
+            with torch.cuda.stream(ws):
+                L.bwd_params(g, x, in_relu=in_relu)
+            for t in (g, x):                               # their memory is not to be reused before the side stream is through
+                t.record_stream(ws)
+                a = getattr(t, "_rn_amax", None)
+                if a is not None:
+                    a[0].record_stream(ws)
+
         def done(layer):
             nonlocal next_bucket
             if batched:
@@ -1097,6 +1133,8 @@ class Engine:
                     self.grad_hook(g)
             if flat is not None and layer.spec.name == buckets[next_bucket][2]:
                 if batched:
+                    for ws in wss or ():
+                        main0.wait_stream(ws)
                     self._unpack_bucket(next_bucket, pending, views)
                     pending.clear()
                 if self.bucket_hook is not None:             # every gradient of this slice is final: release it
@@ -1158,39 +1196,39 @@ class Engine:
         hw = lambda t: (t.shape[1], t.shape[2])
         L = Ls["fpn.P7_2"]
         if self.bwd16:
-            L.bwd_params(dp7, ACT(S["p6r"]))
+            wg(L, dp7, ACT(S["p6r"]))
         else:
-            L.bwd_params(dp7, p6, in_relu=True)
+            wg(L, dp7, p6, in_relu=True)
         dp6 = L.bwd_data(dp7, hw(p6), add=dp6, mask=p6, mask_mode=1)     # d relu(p6) masked, heads' part added raw
         done(L)
         L = Ls["fpn.P6"]
-        L.bwd_params(dp6, c5)
+        wg(L, dp6, c5)
         dc5 = L.bwd_data(dp6, hw(c5))
         done(L)
         L = Ls["fpn.P3_2"]
-        L.bwd_params(dp3, p3sum)
+        wg(L, dp3, p3sum)
         dp3sum = L.bwd_data(dp3, hw(p3sum))
         done(L)
         L = Ls["fpn.P3_1"]
-        L.bwd_params(dp3sum, c3)
+        wg(L, dp3sum, c3)
         dc3 = L.bwd_data(dp3sum, hw(c3))
         done(L)
         L = Ls["fpn.P4_2"]
-        L.bwd_params(dp4, p4sum)
+        wg(L, dp4, p4sum)
         dp4sum = L.bwd_data(dp4, hw(p4sum))
         cv.upsample_add_bwd(dp3sum, dp4sum)
         done(L)
         L = Ls["fpn.P4_1"]
-        L.bwd_params(dp4sum, c4)
+        wg(L, dp4sum, c4)
         dc4 = L.bwd_data(dp4sum, hw(c4))
         done(L)
         L = Ls["fpn.P5_2"]
-        L.bwd_params(dp5, p5lat)
+        wg(L, dp5, p5lat)
         dp5lat = L.bwd_data(dp5, hw(p5lat))
         cv.upsample_add_bwd(dp4sum, dp5lat)
         done(L)
         L = Ls["fpn.P5_1"]
-        L.bwd_params(dp5lat, c5)
+        wg(L, dp5lat, c5)
         dc5 = L.bwd_data(dp5lat, hw(c5), add=dc5, mask=c5)                # both consumers in: ReLU mask of C5
         done(L)
         # ---- backbone, last block first.  `g` = gradient w.r.t. the block's pre-ReLU output, already masked.
@@ -1204,11 +1242,11 @@ class Engine:
             in_hw = hw(xin)
             last = roles["conv2"] if self.kind == "basic" else roles["conv3"]
             tin = t1 if self.kind == "basic" else t2
-            last.bwd_params(g, tin)
+            wg(last, g, tin)
             gt = last.bwd_data(g, hw(tin), mask=tin)
             done(last)
             if self.kind != "basic":
-                roles["conv2"].bwd_params(gt, t1)
+                wg(roles["conv2"], gt, t1)
                 gt = roles["conv2"].bwd_data(gt, hw(t1), mask=t1)
                 done(roles["conv2"])
             # gradient reaching the block input: conv1 path + residual path (+ FPN lateral on layer outputs)
@@ -1220,7 +1258,7 @@ class Engine:
                 extra = lateral.get(prev_layer)
             dcompact = None
             if "down" in roles:
-                roles["down"].bwd_params(g, xin)
+                wg(roles["down"], g, xin)
                 if roles["down"].spec.stride == 2 and roles["conv1"].spec.stride == 1 and not self.bwd16:
                     dcompact = roles["down"].bwd_data_compact(g)       # bottleneck: conv1 is 1x1 s1, takes add2
                     dres = extra
@@ -1229,14 +1267,16 @@ class Engine:
                 done(roles["down"])
             else:
                 dres = g if extra is None else cv.add_(extra, g)
-            roles["conv1"].bwd_params(gt, xin)
+            wg(roles["conv1"], gt, xin)
             # the block input is a ReLU output (previous block) except for the very first block (max-pool output)
             g = roles["conv1"].bwd_data(gt, in_hw, add=dres, mask=xin if bi > 0 else None, add2=dcompact)
             done(roles["conv1"])
             del layer_name
         # ---- stem
         gstem = (cv.maxpool_bwd_bf16 if self.bwd16 else cv.maxpool_bwd)(S["stem"], g, S["pool_arg"], relu_mask=True)
-        Ls["conv1"].bwd_params(gstem, S["x4"])
+        wg(Ls["conv1"], gstem, S["x4"])
         done(Ls["conv1"])
+        for ws in wss or ():
+            main0.wait_stream(ws)
         assert flat is None or next_bucket == len(buckets), "backward finished layers in an order finish_order() does not describe"
         return grads

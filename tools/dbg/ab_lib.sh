@@ -7,7 +7,7 @@ for spec in $1; do
   [ "$spec" != "$v" ] && envs=$(echo ${spec#*:} | tr ':' ' ')
   if [ $v = product ]; then lib=""; else lib="RN_LIB_PATH=3d-playground_amd/retinanet_mi355x/lib/ab/lib$v.so"; fi
   echo "== $spec" | tee -a gpurun_out/ab/libs.txt
-  env $lib $envs timeout -k 10 300 python bench.py --steps 10 --warmup 3 --sections headline --no-cpu-baseline 2>/dev/null | python -c "
+  env $lib $envs timeout -k 10 300 python bench.py --steps 10 --warmup 3 --sections headline --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
