@@ -499,13 +499,34 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
     return (outs, (V, tuple(tuple(x.shape) for x in xs), v_am)) if keep_v else outs   # V + the shapes it belongs to (+ its amax word)
 
 
-def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_input=False):
+_WINO_Z = {}
+
+
+def _wino_z_buffer(device, floats):
+    """A dedicated buffer for A dy A^T when the weight gradient that reads it runs on a SIDE stream (wino_wgrad_group(side=...)): the shared
+    workspace's M half is overwritten by the very next GEMM of the calling stream.  Two per (device, calling stream), taken in turn; the
+    caller's stream first waits for the side-stream launch that last read the one it gets.  -> (state, index)."""
+    cur = torch.cuda.current_stream(device)
+    st = _WINO_Z.setdefault((device, cur.cuda_stream), {"bufs": [None, None], "ev": [None, None], "i": 0})
+    k = st["i"]
+    st["i"] ^= 1
+    if st["bufs"][k] is None or st["bufs"][k].numel() < floats:
+        st["bufs"][k] = torch.empty(floats, dtype=torch.float32, device=device)
+    if st["ev"][k] is not None:
+        cur.wait_event(st["ev"][k])
+    return st, k
+
+
+def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_input=False, side=None):
     """Weight gradient of a 3x3 / stride 1 / padding 1 convolution over several problems (gs[i] = dY [N,H,W,Cout],
     xs[i] = its input [N,H,W,Cin]) by Winograd F(4x4,3x3): dw (packed [Cout][Kpad], accumulated into) and colsum.
-    Returns None, or with fuse_dgrad_input the (B^T dy B, shapes) pair for wino_conv_group(V_ready=...) of the same layer's data gradient."""
+    Returns None, or with fuse_dgrad_input the (B^T dy B, shapes) pair for wino_conv_group(V_ready=...) of the same layer's data gradient.
+    side: a stream for the 36 reductions and the back-transform of dU (the fused form only: the transforms of dy stay on the caller's
+    stream, which goes on to the data gradient while the reductions run beside it)."""
     lib = _hip.load()
     dev = xs[0].device
     C, cout = xs[0].shape[3], gs[0].shape[3]
+    zst = None
     tiles = [x.shape[0] * ((x.shape[1] + 3) // 4) * ((x.shape[2] + 3) // 4) for x in xs]
     T = sum(tiles)
     Tpad = wino_tpad(T)
@@ -525,6 +546,9 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
         # (rn_wino_input_both_group).  B^T dy B goes to the V half of the workspace (idle here: the forward's V was kept), and
         # the (tensor, shapes) pair goes back to the caller for wino_conv_group(V_ready=...).
         Vd, Z = _wino_workspace(dev, 36 * Tpad * cout, 36 * Tpad * cout)
+        if side is not None:
+            zst, zk = _wino_z_buffer(dev, 36 * Tpad * cout)
+            Z = zst["bufs"][zk]
         am_on = want_amax()
         g = _wino_group(gs, srcs=gs, amaxs=[amax_words(t) for t in gs] if am_on else None)
         vd_rows = torch.zeros(Tpad, dtype=torch.int32, device=dev) if am_on else None
@@ -541,11 +565,22 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
     ku = (C + 31) // 32 * 32
     if dU is None or tuple(dU.shape) != (36, cout, ku):      # dU: a ZEROED [36, cout, ku] accumulator of the caller (used once)
         dU = torch.zeros((36, cout, ku), dtype=torch.float32, device=dev)
-    rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: _wgrad_call(    # executed FLOPs
-        lib, dev, Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
-        (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0), amax=am))
-    _hip.check(rc, "rn_conv_wgrad_batched")
-    _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
+    def reductions():
+        rc = prof.timed("conv_wgrad" + (" winograd T%d %d->%d" % (T, C, cout) if prof.BY_SHAPE else ""), 2.0 * 36 * T * cout * C, lambda: _wgrad_call(    # executed FLOPs
+            lib, dev, Z.data_ptr(), cout, V.data_ptr(), dU.data_ptr(), _hip.ptr(colsum), 36, Tpad * cout, Tpad * C, cout * ku, 7,
+            (1, 1, T, C, 1, T, cout, 1, 1, 1, 0, 0), amax=am))
+        _hip.check(rc, "rn_conv_wgrad_batched")
+        _hip.check(lib.rn_wino_dw(dU.data_ptr(), dw.data_ptr(), cout, C, _hip.stream()), "rn_wino_dw")
+    if zst is None:
+        reductions()
+    else:
+        side.wait_event(torch.cuda.current_stream(dev).record_event())
+        with torch.cuda.stream(side):
+            reductions()
+            zst["ev"][zk] = side.record_event()
+        for t in (V, dU) + tuple(am):                 # (the kept forward transform is released by the caller right after this call)
+            if t is not None:
+                t.record_stream(side)
     return v_dy                                      # (B^T dy B, shapes) for the data gradient that follows, or None when not fused
 
 

@@ -346,8 +346,9 @@ class Layer:
         return 2.0 * N * Ho * Wo * s.cout * s.cin * s.k * s.k
 
     # ---- backward
-    def bwd_params(self, g, x, in_relu=False):
-        """Accumulate wgrad(g, x) and colsum(g).  g: [N,Ho,Wo,ld] with ld >= cout."""
+    def bwd_params(self, g, x, in_relu=False, side=None):
+        """Accumulate wgrad(g, x) and colsum(g).  g: [N,Ho,Wo,ld] with ld >= cout.  side: a stream for the reductions of the Winograd form
+        (cv.wino_wgrad_group); the other forms run where they are called."""
         s = self.spec
         if self.dw is None:
             self.dw = torch.zeros_like(self.wf)
@@ -360,13 +361,13 @@ class Layer:
         if self.wino_active and not in_relu and g.shape[3] == s.cout and g.is_contiguous() and x.is_contiguous():
             du, self.du = getattr(self, "du", None), None          # the zeroed slot is good for one accumulation
             # (the data gradient of this layer follows: its input transform of g rides along -- bwd_data picks it up)
-            self.dy_v = cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY)
+            self.dy_v = cv.wino_wgrad_group([g], [x], self.dw, self.cs, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY, side=side)
             self.saved_v = None
             return
         cv.wgrad(g, x, self.dw, s.cout, s.k, s.stride, s.pad, kw_pad=self.kw_pad, in_relu=in_relu,
                  flops=self.flops(g.shape[0], g.shape[1], g.shape[2]), colsum=self.cs)
 
-    def bwd_params_group(self, gs, xs, wino=False):
+    def bwd_params_group(self, gs, xs, wino=False, side=None):
         """bwd_params over several problems (pyramid levels); wino: one Winograd weight-gradient pass over all of them."""
         s = self.spec
         if (wino or self.wino_active) and self.wino_ok and all(g.shape[3] == s.cout and g.is_contiguous() for g in gs):
@@ -375,7 +376,7 @@ class Layer:
                 self.cs = torch.zeros(s.cout, dtype=torch.float32, device=gs[0].device)
             fl = sum(self.flops(g.shape[0], g.shape[1], g.shape[2]) for g in gs)
             du, self.du = getattr(self, "du", None), None
-            self.dy_v = cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY)
+            self.dy_v = cv.wino_wgrad_group(gs, xs, self.dw, self.cs, flops=fl, V=self.saved_v, dU=du, fuse_dgrad_input=FUSE_DY, side=side)
             self.saved_v = None
             return
         if self.bf16 and GROUPED_WGRAD_BF16 and 1 < len(gs) <= 5 and all(g.is_contiguous() and x.is_contiguous() for g, x in zip(gs, xs)) \
@@ -1104,22 +1105,38 @@ class Engine:
         wss = self.wgrad_streams(dreg.device) if batched else None
         wg_count = 0
 
-        def wg(L, g, x, in_relu=False):
-            """L.bwd_params(g, x) -- on the weight-gradient stream unless the layer's Winograd pass also prepares its data gradient."""
+        def aside(fn, tensors):
+            """fn() on the weight-gradient stream, after everything queued so far on the current one; `tensors`: what it reads."""
             nonlocal wg_count
-            if wss is None or (L.wino_active and not L.bf16):
-                L.bwd_params(g, x, in_relu=in_relu)
-                return
             ws = wss[wg_count % len(wss)]
             wg_count += 1
-            ws.wait_event(torch.cuda.current_stream(g.device).record_event())      # g, x and the zeroed accumulators are ready
+            ws.wait_event(torch.cuda.current_stream(dreg.device).record_event())   # the operands and the zeroed accumulators are ready
             with torch.cuda.stream(ws):
-                L.bwd_params(g, x, in_relu=in_relu)
-            for t in (g, x):                               # their memory is not to be reused before the side stream is through
+                fn()
+            for t in tensors:                              # their memory is not to be reused before the side stream is through
                 t.record_stream(ws)
                 a = getattr(t, "_rn_amax", None)
                 if a is not None:
                     a[0].record_stream(ws)
+
+        def wg(L, g, x, in_relu=False):
+            """L.bwd_params(g, x) beside the data gradients.  A Winograd layer transforms g here (its data gradient wants one of the two
+            transforms) and only the reductions go aside (cv.wino_wgrad_group(side=...))."""
+            if wss is None:
+                L.bwd_params(g, x, in_relu=in_relu)
+            elif L.wino_active and not L.bf16:
+                L.bwd_params(g, x, in_relu=in_relu, side=wss[0] if os.environ.get("RN_WGRAD_WINO", "1") != "0" else None)
+            else:
+                aside(lambda: L.bwd_params(g, x, in_relu=in_relu), (g, x))
+
+        def wg_group(L, gs, xs, wino=False):
+            """L.bwd_params_group likewise (the head towers' layers over the pyramid levels)."""
+            if wss is None or os.environ.get("RN_WGRAD_TOWERS", "0") == "0":
+                L.bwd_params_group(gs, xs, wino=wino)
+            elif wino or L.wino_active:
+                L.bwd_params_group(gs, xs, wino=wino, side=wss[0])
+            else:
+                aside(lambda: L.bwd_params_group(gs, xs), tuple(gs) + tuple(xs))
 
         def done(layer):
             nonlocal next_bucket
@@ -1172,12 +1189,12 @@ class Engine:
                                            bf16=self.bwd16)
                     gs.append(cv.amax_carry(g.view(B, Hh, Ww, Lout.cout_pad), g))
                     off += cnt
-                Lout.bwd_params_group(gs, [acts[li][3] for li in range(5)])   # direct: one launch per level (K slices fill the GPU)
+                wg_group(Lout, gs, [acts[li][3] for li in range(5)])          # direct: one launch per level (K slices fill the GPU)
                 gs = Lout.bwd_data_group(gs, hws, masks=[acts[li][3] for li in range(5)])
                 for i in (3, 2, 1):
-                    tower[i].bwd_params_group(gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bwd16)
+                    wg_group(tower[i], gs, [acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bwd16)
                     gs = tower[i].bwd_data_group(gs, hws, masks=[acts[li][i - 1] for li in range(5)], wino=self.use_wino and not self.bwd16)
-                tower[0].bwd_params_group(gs, pyramid, wino=self.use_wino and not self.bwd16)
+                wg_group(tower[0], gs, pyramid, wino=self.use_wino and not self.bwd16)
                 first = dpyr[0] is None
                 if side is not None and not first:
                     side[ti].wait_stream(side[0])                         # the other tower's pyramid gradient is complete
