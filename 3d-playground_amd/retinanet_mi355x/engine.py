@@ -669,13 +669,20 @@ class Engine:
         return arena, {n: arena[o:o + k].view(shp) for n, (o, k, shp) in f["slots"].items()}
 
     # ------------------------------------------------------------------------------------------- helpers
+    def _side_streams_ok(self, device):
+        """Side streams at all?  Not on the CPU, not during a stream capture (a captured graph keeps the single-stream order), not under
+        per-kernel timing (prof.ACTIVE: a kernel's duration means something only when nothing else shares the GPU)."""
+        return device.type == "cuda" and prof.ACTIVE is None and not torch.cuda.is_current_stream_capturing()
+
     def tower_streams(self, device):
-        """The two side streams the head towers run on (forward and backward), or None: RN_TOWER_STREAMS=0, CPU tensors, a stream
-        capture in progress (a captured graph keeps the single-stream order) or per-kernel timing (prof.ACTIVE: a kernel's
-        duration means something only when nothing else shares the GPU)."""
-        if device.type != "cuda" or os.environ.get("RN_TOWER_STREAMS", "1") == "0" or prof.ACTIVE is not None:
-            return None
-        if torch.cuda.is_current_stream_capturing():
+        """The two side streams the head towers run on (forward and backward), or None: RN_TOWER_STREAMS=0, where _side_streams_ok says no,
+        and -- unless RN_TOWER_STREAMS=2 -- in a data-parallel run (bucket_hook set).  The process must stay within FOUR busy hardware
+        queues: HIP maps streams onto that many, and beyond them the queues are time-sliced -- measured: the same step at 155 ms instead of
+        64 with GPU_MAX_HW_QUEUES=8, and at 146 ms on one box with a fifth stream (profiles/r05_wgrad_stream.txt, 4 and 5).  Single GPU:
+        main + two towers + weight gradients = 4.  Data-parallel: RCCL brings its own, so the towers give theirs up (they are worth
+        +0.9 %, the weight-gradient stream +3.6 %): main + weight gradients + communication."""
+        mode = os.environ.get("RN_TOWER_STREAMS", "1")
+        if mode == "0" or not self._side_streams_ok(device) or (self.bucket_hook is not None and mode != "2"):
             return None
         st = self._tower_streams.get(device)
         if st is None:
@@ -683,12 +690,12 @@ class Engine:
         return st
 
     def wgrad_streams(self, device):
-        """The side streams the backbone's and the pyramid's weight gradients run on (taken in turn), or None (RN_WGRAD_STREAMS=0, and
-        where tower_streams gives None).  A weight gradient needs only its layer's output gradient and saved input -- nothing downstream
+        """The side stream(s) the backbone's and the pyramid's weight gradients run on (taken in turn), or None (RN_WGRAD_STREAMS=0, and
+        where _side_streams_ok says no).  A weight gradient needs only its layer's output gradient and saved input -- nothing downstream
         waits for it but the gradient bookkeeping -- and every launch ends in a tail (the last round's workgroups draining tile-sized
         atomics: 14 % of the weight-gradient time, profiles/r05_wgrad_stream.txt) that the data gradients of the main stream run under."""
         n = int(os.environ.get("RN_WGRAD_STREAMS", "1"))
-        if n <= 0 or self.tower_streams(device) is None:
+        if n <= 0 or not self._side_streams_ok(device):
             return None
         st = self._tower_streams.get(("wgrad", device, n))
         if st is None:
