@@ -14,4 +14,4 @@ def test_wgrad_lds_indices_stay_in_range(tmp_path):
                            os.path.join(REPO, "tests", "wgrad_index_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert r.stdout.count("ok ") == 7, r.stdout
+    assert r.stdout.count("ok ") == 8, r.stdout
