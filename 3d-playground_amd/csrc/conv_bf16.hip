@@ -510,27 +510,11 @@ static inline int check_ptrs_bf16(const rn_conv_desc *d, const void *x, const vo
     return RN_OK;
 }
 
-// Tile choice: 256 x 256 (one 1024-thread workgroup per CU) when the result is bf16, Cout fills a 256-wide tile and the
-// problem (all problems of a group together) has at least ~one round of 256-tiles for the 256 CUs; else 128 x 128.
-// RN_BF16_BIG_TILE=1 forces it, =2 applies the size rule, unset / 0 = never (A/B measurements).
-// Measured (tools/bench_conv_bf16.py, RN_BF16_BIG_TILE=0 / 1): the big tile wins where the K loop is long -- 3x3 from
-// >= 256 channels: 626 -> 785 (fprop), 777 -> 921 (dgrad), 725 -> 903 TFLOP/s (68x120) -- and loses 15-30 % on the 1x1 layers
-// (short K: the epilogue of a lone 1024-thread workgroup has nothing to overlap with) and on problems with fewer tiles than CUs.
-// In the WHOLE training step, selected by that rule (RN_BF16_BIG_TILE=2), it LOSES: 171.1 against 180.0 images/s with the small
-// tile everywhere (the grouped head launches carry the small pyramid levels in 256-tiles, and a lone workgroup per CU drains
-// its epilogue alone) -- so the kernel stays in the library for A/B runs and the launcher does not pick it.
-static inline bool bf16_big_tile(int64_t rows_total_tiles256, int Cout, int K, int y_is_f32) {
-    static const int force = [] { const char *e = getenv("RN_BF16_BIG_TILE"); return e ? atoi(e) : -1; }();
-    if (y_is_f32 || (Cout & 255) != 0) return false;
-    if (force == 1) return true;
-    if (force == 2) return rows_total_tiles256 >= 224 && K >= 2048;
-    return false;                                                         // default OFF: see below
-}
-static inline bool bf16_tile_is_big(const rn_conv_group *g, int y_is_f32) {
-    int64_t t = 0;
-    for (int i = 0; i < g->n; ++i) t += (((int64_t)g->d[i].N * g->d[i].Ho * g->d[i].Wo + 255) / 256) * ((g->d[i].Cout + 255) / 256);
-    return bf16_big_tile(t, g->d[0].Cout, g->d[0].kh * g->d[0].kw * g->d[0].Cin, y_is_f32);
-}
+// (Rounds 2-4 also carried a 256 x 256 tile of sixteen waves, one 1024-thread workgroup per CU, behind RN_BF16_BIG_TILE: +25 % on long-K 3x3
+// layers alone, -5 % on the whole step (171.1 against 180.0 images/s), and superseded by the eight-wave phased kernel of conv_bf16_p8.hip
+// in round 4.  Its instances left the library in round 5; the 256 x 256 tile rows below are the phased kernel's.)
+static inline bool bf16_big_tile(int64_t, int, int, int) { return false; }
+static inline bool bf16_tile_is_big(const rn_conv_group *, int) { return false; }
 // 256 x 128 tile for a group: dense bf16 results, Cout a multiple of 128, a long K loop and enough tiles (see the single launcher)
 static inline bool bf16_group_is_tall(const rn_conv_group *g, int y_is_f32) {
     static const int tall_env = [] { const char *e = getenv("RN_BF16_TALL_TILE"); return e ? atoi(e) : -1; }();
@@ -585,10 +569,7 @@ extern "C" int rn_conv_igemm_bf16_grouped(const rn_conv_group *g, const void *w_
     bool dense = true;
     for (int i = 0; i < g->n; ++i) dense = dense && bf16_desc_is_dense(&g->d[i]);
     if (p8) return rn_bf16_p8_launch_grouped(g, prev, w_packed, scale, shift, (hipStream_t)stream);
-    if (big) {
-        const dim3 grid((unsigned)prev), block(1024);
-        hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 4, 4, false>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
-    } else {
+    {
         const dim3 grid((unsigned)prev), block(256);
         if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<true, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
         else if (tall) hipLaunchKernelGGL((conv_igemm_bf16_grouped_kernel<false, 2, 2, true, 4>), grid, block, 0, (hipStream_t)stream, *g, wb, scale, shift);
@@ -625,8 +606,7 @@ extern "C" int rn_conv_igemm_bf16(const rn_conv_desc *d, const void *x, const vo
     const dim3 grid((unsigned)tiles), block(big ? 1024 : 256);
     const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *wb = reinterpret_cast<const __bf16 *>(w_packed);
     const __bf16 *ab = reinterpret_cast<const __bf16 *>(add), *mb = reinterpret_cast<const __bf16 *>(mask);
-    if (big) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 4, 4, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
-    else if (tall) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true, 4>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
+    if (tall) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true, 4>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (narrow) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 4, 1, true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (y_is_f32) hipLaunchKernelGGL((conv_igemm_bf16_kernel<true, 2, 2, false>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);
     else if (bf16_desc_is_dense(d)) hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 2, 2, true>), grid, block, 0, (hipStream_t)stream, *d, xb, wb, y, scale, shift, ab, mb);

@@ -1033,7 +1033,7 @@ def conv_igemm_bf16_grouped(problems, w_packed, scale=None, shift=None, act=ACT_
         M = d.N * d.Ho * d.Wo
         total += ((M + trm - 1) // trm) * ((d.Cout + trn - 1) // trn)
         g.tile_end[i] = total
-    kind = "conv_igemm_bf16" + ("_p8" if (trm, trn) == (256, 256) and os.environ.get("RN_BF16_BIG_TILE", "0") in ("", "0") else "") \
+    kind = "conv_igemm_bf16" + ("_p8" if (trm, trn) == (256, 256) else "") \
         + (" grouped %d->%d k%d" % (g.d[0].Cin, g.d[0].Cout, g.d[0].kh) if prof.BY_SHAPE else "")
     rc = prof.timed(kind, flops, lambda: lib.rn_conv_igemm_bf16_grouped(
         ctypes.byref(g), w_packed.data_ptr(), int(yf32), _hip.ptr(scale), _hip.ptr(shift), _hip.stream()))

@@ -12,11 +12,17 @@ all on inputs already resident in HBM.  With N > 1 every rank trains on its own 
 gradients are averaged over RCCL inside backward (retinanet_mi355x.ddp).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel (implicit-GEMM conv, 128x128 tile): algorithmic (fp32) FLOPs of its launches inside the
-                timed steps / their HIP-event durations, against the peak of the instruction it runs on: 2500 / 6 = 416.7 TF
-                in split-operand mode (six bf16 MFMAs per fp32 product), 157.3 TF on the fp32 MFMA
-  fp32_native_mfma  (split mode) the same step on v_mfma_f32_32x32x2_f32, measured in the same run
+  roofline      the dominant kernel family (implicit-GEMM conv, 128x128 tile): algorithmic (fp32) FLOPs and algorithmic bytes (every
+                operand once) of its launches inside the timed steps / their HIP-event durations.  Which roof prices it is the roofline
+                model's own rule: arithmetic intensity against the ridge peak / 8 TB/s, where peak is that of the instruction the kernels
+                run on -- 2500 / 3 = 833 TF in the default mode (split3: three fp16 MFMAs per fp32 product), 2500 / 6 with three bf16
+                terms, 157.3 TF on the fp32 MFMA.  Below the ridge: bound "hbm", achieved / peak in GB/s, the matrix-core fraction beside
+                it (mfma_frac); above: bound "mfma".  traffic: HBM bytes per launch from the committed PMC passes of this command.
+  step_hbm      the whole step's HBM bytes (same PMC passes) over its wall time, against 8 TB/s
+  fp32_native_mfma / fp32_split_bf16x3   the same step in the other two product modes, measured in the same run
   kernels       the same for the other timed kernels, plus the fused IoU+focal loss against the HBM roof
+  bf16 / fp8    (--sections all) BASELINE configs[2] / configs[4]: the bf16 engine's step; the fp8 engine's forward.  --dtype bf16 / fp8 make
+                them the headline: --dtype fp8 is a TRAINING step (e4m3 forward, bf16 gradients, fp32 master weights)
   cpu_baseline  the CPU restatement (oracle/, torch CPU kernels = what the reference runs on a GPU-less host)
                 timed on this box's host cores on a bounded sample (1 image, forward+loss+backward), rank 0, N=1 only
 """

@@ -92,7 +92,7 @@ def test_forward_with_epilogue(cv, dev, case):
 
 def launcher_tile(cv, x_shape, cout, k, stride, pad):
     """The tile the launcher takes for this layer (rn_conv_igemm_bf16_tile_rows on a group of one): 256256 = this kernel (the other
-    256 x 256 tile is off unless RN_BF16_BIG_TILE asks for it), 128128 / 256128 = conv_bf16.hip's."""
+    256 x 256 tile left the library in round 5), 128128 / 256128 = conv_bf16.hip's."""
     import ctypes
     from retinanet_mi355x import _hip
     N, H, W, cin = x_shape

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: the 256 x 256 tile this script compares with is quarantined beside it -- kept for the record of profiles/r03_split_knockout.txt)
 # Knock-out timing of the split-operand implicit-GEMM kernels (wrong results, timing only): which part of a K-step is additive.
 # K3 no loads after the prologue, K4 one MFMA of six, K8 no split arithmetic, K15 all of them; each with the 128 x 128 tile
 # (RN_BIG_TILE=0) and the 256 x 256 tile (=1).  Usage: tools/ab_knockout.sh OUTDIR
