@@ -14,9 +14,9 @@ if [ "$part" = 1 ]; then
   echo "bench done"
 fi
 if [ "$part" = 2 ]; then
-  # the headline's own steps only, the towers on ONE stream (a kernel's duration in the trace means something only when nothing else
+  # the headline's own steps only, towers and weight gradients on ONE stream (a kernel's duration in the trace means something only when nothing else
   # shares the GPU): Sum(duration) / (warmup + 2 * steps) of a family = kernels.<family>.ms_per_step of the line it prints
-  RN_TOWER_STREAMS=0 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 bench.py --steps 5 --warmup 2 --sections headline --no-cpu-baseline > "$O/bench_headline_under_rocprof.log" 2>&1
+  RN_TOWER_STREAMS=0 RN_WGRAD_STREAMS=0 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 bench.py --steps 5 --warmup 2 --sections headline --no-cpu-baseline > "$O/bench_headline_under_rocprof.log" 2>&1
   cp "$(ls $O/stats/*/*kernel_stats.csv | head -1)" "$O/kernel_stats_headline.csv"
   echo "stats done"
   bash tools/collect_traffic.sh
