@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoTable g, float *
 
 // ---------------------------------------------------------------------------------------------- output transform
 // mask_mode / add / act as in rn_conv_desc (mask and add have the geometry of y, dense [N,H,W,Cout]).
-__global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const float *__restrict__ M, int Cout, int64_t t0,
+template <bool PBITS, bool PADD>
+__global__ __launch_bounds__(256, 2) void wino_out_kernel(const WinoTable g, const float *__restrict__ M, int Cout, int64_t t0,
                                                        int64_t Tpad, const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int mask_mode, int act, int64_t y_bs) {
     const int cq = Cout >> 2;
@@ -209,12 +210,28 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
     if (scale) sc = *reinterpret_cast<const float4 *>(scale + c4);
     if (shift) sh = *reinterpret_cast<const float4 *>(shift + c4);
     const int64_t ybs = y_bs ? y_bs : (int64_t)H * W * Cout;
+    // PBITS: the launch reads ReLU-mask bits; PADD: every problem of the launch has an addend (the launcher's choice of instance).  Their
+    // operands are requested a ROW of four pixels at a time, in one batch: loaded pixel by pixel every load sat between two stores with an
+    // s_waitcnt vmcnt(0) of its own -- sixteen (with an addend: thirty-two) memory round trips one after the other per thread, and the
+    // data-gradient form ran 12 % (with an addend: 68 %) behind the plain one (tools/dbg/wino_out_variants.py).  All sixteen at once
+    // need 280-340 registers (one wave per SIMD) or spill; a row costs 4 + 16.  Pixels past the edge read the edge pixel's operands.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float4 o[4];
         at6(t[i], o);
         const int oh = 4 * th + i;
         if (oh >= H) break;
+        unsigned mkw[4];
+        float4 adv[4];
+        if constexpr (PBITS || PADD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int owc = 4 * tw + j < W ? 4 * tw + j : W - 1;
+                const int64_t off = (((int64_t)n * H + oh) * W + owc) * Cout + c4;
+                if constexpr (PBITS) mkw[j] = reinterpret_cast<const unsigned *>(mask)[off >> 5] >> ((unsigned)off & 28u);
+                if constexpr (PADD) adv[j] = *reinterpret_cast<const float4 *>(add + off);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ow = 4 * tw + j;
@@ -223,8 +240,12 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoTable g, const 
             const int64_t yoff = (int64_t)n * ybs + ((int64_t)oh * W + ow) * Cout + c4;   // y: batch stride (a slice of [B, A, n])
             float v[4] = {sc.x * o[j].x + sh.x, sc.y * o[j].y + sh.y, sc.z * o[j].z + sh.z, sc.w * o[j].w + sh.w};
             float mk[4] = {1.f, 1.f, 1.f, 1.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
-            if (mask_mode != 0) { const float4 q4 = rn_mask_load4(mask, off, mbits); mk[0] = q4.x; mk[1] = q4.y; mk[2] = q4.z; mk[3] = q4.w; }
-            if (add) { const float4 q4 = *reinterpret_cast<const float4 *>(add + off); ad[0] = q4.x; ad[1] = q4.y; ad[2] = q4.z; ad[3] = q4.w; }
+            if constexpr (PBITS) {
+                const unsigned nb = mkw[j];
+                mk[0] = (nb & 1u) ? 1.f : 0.f; mk[1] = (nb & 2u) ? 1.f : 0.f; mk[2] = (nb & 4u) ? 1.f : 0.f; mk[3] = (nb & 8u) ? 1.f : 0.f;
+            } else if (mask_mode != 0) { const float4 q4 = rn_mask_load4(mask, off, mbits); mk[0] = q4.x; mk[1] = q4.y; mk[2] = q4.z; mk[3] = q4.w; }
+            if constexpr (PADD) { const float4 q4 = adv[j]; ad[0] = q4.x; ad[1] = q4.y; ad[2] = q4.z; ad[3] = q4.w; }
+            else if (add) { const float4 q4 = *reinterpret_cast<const float4 *>(add + off); ad[0] = q4.x; ad[1] = q4.y; ad[2] = q4.z; ad[3] = q4.w; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float u = v[k];
@@ -506,8 +527,18 @@ extern "C" int rn_wino_output_group(const rn_wino_group *g, const float *M, int 
         if (((mask_mode & RN_MASK_BITS) || t.sign[i]) && (Cout & 31)) return RN_EINVAL;     // whole words per pixel
         if (y_batch_stride && y_batch_stride < (int64_t)t.p[i].H * t.p[i].W * Cout) return RN_EINVAL;
     }
-    hipLaunchKernelGGL(wino_out_kernel, dim3(rn_blocks(t.tile_end[t.n - 1] * (Cout >> 2), 256)), dim3(256), 0,
-                       (hipStream_t)stream, t, M, Cout, tile_offset, Tpad, scale, shift, mask_mode, act, y_batch_stride);
+    // the instance that requests a launch's mask bits / addends in one batch (wino_out_kernel): addends only when every problem has one
+    const bool pbits = (mask_mode & RN_MASK_BITS) != 0;
+    bool padd = true;
+    for (int i = 0; i < t.n; ++i) padd = padd && t.add[i] != nullptr;
+    const dim3 grid(rn_blocks(t.tile_end[t.n - 1] * (Cout >> 2), 256));
+#define RN_WINO_OUT(B, A) hipLaunchKernelGGL((wino_out_kernel<B, A>), grid, dim3(256), 0, (hipStream_t)stream, t, M, Cout, tile_offset, Tpad, \
+                                             scale, shift, mask_mode, act, y_batch_stride)
+    if (pbits && padd) RN_WINO_OUT(true, true);
+    else if (pbits) RN_WINO_OUT(true, false);
+    else if (padd) RN_WINO_OUT(false, true);
+    else RN_WINO_OUT(false, false);
+#undef RN_WINO_OUT
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

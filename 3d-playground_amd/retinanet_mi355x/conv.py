@@ -500,6 +500,12 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
 
 
 _WINO_Z = {}
+SIDE_HELD = []                                        # operands of side-stream launches (wino_wgrad_group(side=...)) until side_release()
+
+
+def side_release():
+    """After the allocating stream has waited for the side stream: the held operands may be freed / reused."""
+    SIDE_HELD.clear()
 
 
 def _wino_z_buffer(device, floats):
@@ -578,9 +584,12 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
         with torch.cuda.stream(side):
             reductions()
             zst["ev"][zk] = side.record_event()
-        for t in (V, dU) + tuple(am):                 # (the kept forward transform is released by the caller right after this call)
-            if t is not None:
-                t.record_stream(side)
+        # What the side launches read must not be handed out again before they are through.  NOT record_stream: with some sixty side
+        # launches per step it makes the caching allocator's reuse depend on how far the host runs ahead of the GPU -- blocks whose
+        # events have not completed are replaced by fresh device allocations -- and the step time bimodal (64 or 90-140 ms from run to
+        # run, profiles/r05_wgrad_stream.txt 7).  The tensors are held here instead and released by the caller (side_release) once the
+        # stream they were allocated on has waited for the side stream.
+        SIDE_HELD.append((V, dU) + tuple(am))
     return v_dy                                      # (B^T dy B, shapes) for the data gradient that follows, or None when not fused
 
 

@@ -1111,6 +1111,14 @@ class Engine:
         main0 = torch.cuda.current_stream(dreg.device) if dreg.is_cuda else None
         wss = self.wgrad_streams(dreg.device) if batched else None
         wg_count = 0
+        held = []
+
+        def join():
+            """The main stream waits for the weight gradients queued so far; what they read may then be released."""
+            for ws in wss or ():
+                main0.wait_stream(ws)
+            held.clear()
+            cv.side_release()
 
         def aside(fn, tensors):
             """fn() on the weight-gradient stream, after everything queued so far on the current one; `tensors`: what it reads."""
@@ -1120,11 +1128,9 @@ class Engine:
             ws.wait_event(torch.cuda.current_stream(dreg.device).record_event())   # the operands and the zeroed accumulators are ready
             with torch.cuda.stream(ws):
                 fn()
-            for t in tensors:                              # their memory is not to be reused before the side stream is through
-                t.record_stream(ws)
-                a = getattr(t, "_rn_amax", None)
-                if a is not None:
-                    a[0].record_stream(ws)
+            # their memory is not to be reused before the side stream is through: held until the main stream has waited for it (join);
+            # record_stream would leave that to the allocator's event polling -- see cv.SIDE_HELD
+            held.append(tuple(tensors) + tuple(getattr(t, "_rn_amax", (None,))[0] for t in tensors))
 
         def wg(L, g, x, in_relu=False):
             """L.bwd_params(g, x) beside the data gradients.  A Winograd layer transforms g here (its data gradient wants one of the two
@@ -1157,8 +1163,7 @@ class Engine:
                     self.grad_hook(g)
             if flat is not None and layer.spec.name == buckets[next_bucket][2]:
                 if batched:
-                    for ws in wss or ():
-                        main0.wait_stream(ws)
+                    join()
                     self._unpack_bucket(next_bucket, pending, views)
                     pending.clear()
                 if self.bucket_hook is not None:             # every gradient of this slice is final: release it
@@ -1300,7 +1305,6 @@ class Engine:
         gstem = (cv.maxpool_bwd_bf16 if self.bwd16 else cv.maxpool_bwd)(S["stem"], g, S["pool_arg"], relu_mask=True)
         wg(Ls["conv1"], gstem, S["x4"])
         done(Ls["conv1"])
-        for ws in wss or ():
-            main0.wait_stream(ws)
+        join()
         assert flat is None or next_bucket == len(buckets), "backward finished layers in an order finish_order() does not describe"
         return grads
