@@ -1125,6 +1125,12 @@ class Engine:
             nonlocal wg_count
             ws = wss[wg_count % len(wss)]
             wg_count += 1
+            if cv.want_amax():
+                # amax tables of the operands exist BEFORE the fork: computed lazily over there (a tensor whose producer left none), the
+                # table would be cached on the tensor and read by this stream's next kernel with nothing ordering the two
+                for t in tensors:
+                    if t.dtype == torch.float32 and t.is_contiguous():
+                        cv.amax_words(t)
             ws.wait_event(torch.cuda.current_stream(dreg.device).record_event())   # the operands and the zeroed accumulators are ready
             with torch.cuda.stream(ws):
                 fn()
