@@ -173,3 +173,16 @@ print("ok")
 ''' % PKG
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr[-2000:])
+
+
+def test_winograd_planes_are_an_odd_number_of_blocks_apart():
+    """conv.wino_tpad (round 5): rows of one of the 36 planes of V / M / Z -- a multiple of 256 (no GEMM tile straddles two planes), at least
+    the tile count, and an ODD multiple (an even one puts the planes a multiple of 512 KiB apart for 256 channels: the output transform,
+    which combines one value of each plane, loses 8 % of its bandwidth -- profiles/r05_wgrad_stream.txt's neighbour r05_mf16_bounds.txt)."""
+    from retinanet_mi355x import conv
+    for T in (1, 255, 256, 257, 511, 512, 513, 4080, 16320, 21896, 22016, 22017, 100000):
+        tp = conv.wino_tpad(T)
+        assert tp >= T and tp % 256 == 0 and (tp // 256) % 2 == 1 and tp - T < 512, (T, tp)
+    conv.SIDE_HELD.append((None,))
+    conv.side_release()
+    assert conv.SIDE_HELD == []
