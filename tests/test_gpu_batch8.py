@@ -154,3 +154,34 @@ def test_tower_streams_change_no_bit(dev, mode, mfma, monkeypatch):
                 assert torch.equal(g_one[n], g_two[n]), "%s differs between one stream and two" % n
     finally:
         conv.set_option(conv.OPT_DETERMINISTIC, before)
+
+
+@pytest.mark.parametrize("mode", ["wino", "direct"])
+def test_weight_gradient_stream_changes_no_bit(dev, mode, mfma, monkeypatch):
+    """Round 5: the backbone's, the pyramid's and the stem's weight gradients run on a side stream (engine.py: wgrad_streams; for Winograd
+    layers the 36 reductions only), forked where a layer's output gradient is ready and joined where a bucket's unpack launch reads the
+    accumulators; their operands are held by reference until that join.  In deterministic mode the step's result does not depend on
+    timing: with the stream off, on, and with two of them the gradients must be equal BIT FOR BIT -- a missing event (a reduction reading
+    A dy A^T before its transform, an accumulator unpacked before its last weight gradient, an operand's memory handed out again too
+    early, an amax table made on the wrong stream) shows up here."""
+    from retinanet_mi355x import conv, synth
+    net = _net(dev, mode == "wino")
+    h, w = 360, 640
+    img = synth.frames(2, h, w, seed=9).to(dev)
+    ann = synth.labels_dir(2, 6, h, w, 8, seed=10, size_px=(40, 120)).to(dev)
+    before = conv.get_option(conv.OPT_DETERMINISTIC)
+    conv.set_deterministic(True)
+    try:
+        monkeypatch.setenv("RN_WGRAD_STREAMS", "0")
+        assert net._engine.wgrad_streams(dev) is None
+        l_one, g_one = _step(net, img, ann)
+        for n_streams in ("1", "2"):
+            monkeypatch.setenv("RN_WGRAD_STREAMS", n_streams)
+            assert len(net._engine.wgrad_streams(dev)) == int(n_streams)
+            for _ in range(3):                                      # several runs: a race need not show the first time
+                l_two, g_two = _step(net, img, ann)
+                assert l_one == l_two
+                for n in g_one:
+                    assert torch.equal(g_one[n], g_two[n]), "%s differs with %s weight-gradient stream(s)" % (n, n_streams)
+    finally:
+        conv.set_option(conv.OPT_DETERMINISTIC, before)
