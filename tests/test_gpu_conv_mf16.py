@@ -160,10 +160,12 @@ def test_plain_gemm_short_reductions(cv, dev, case):
     close(y.permute(0, 3, 1, 2), want)
 
 
-def test_plain_gemm_per_position_weights(cv, dev):
-    """The Winograd stage's launch shape: `images` of 256 rows with a weight matrix of their own each (rn_conv_desc.w_batch_stride),
-    K = 128, the tiles of one workgroup crossing from image to image."""
-    P, T, C, Co = 9, 256, 128, 256
+@pytest.mark.parametrize("C", [128, 256, 512])
+def test_plain_gemm_per_position_weights(cv, dev, C):
+    """The Winograd stage's launch shape: `images` of 256 rows with a weight matrix of their own each (rn_conv_desc.w_batch_stride), the
+    tiles of one workgroup crossing from image to image.  K = 128: activations straight into registers; K = 256 / 512 (round 5): staged
+    through the wave-private LDS strips (two column tiles share every row tile)."""
+    P, T, Co = 9, 256, 256
     V = rnd((P, 1, T, C), 41).to(dev)
     U = rnd((P, Co, C), 42, (2.0 / C) ** 0.5).to(dev)
     Uv = (cv.split_weights_f16 if cv._half else cv.split_weights)(U.view(P * Co, C).contiguous())
