@@ -44,6 +44,9 @@
 // profiles/r05_mf16_bounds.txt).  A wave fetches its own 32 rows x 128 bytes of the K-step by four direct-to-LDS instructions of 8 rows each
 // into a 4 KB strip nobody else touches (no extra barrier: its own s_waitcnt orders it) and reads them back as operands, conflict-free
 // (conv_wgrad_geom.h: Mf16AGeom).  The rows' geometry -- the divisions -- is computed once per row into a table instead of once per reader.
+// WV = 8 (same half of the round): the staged form with EIGHT waves on a 256 x 128 tile -- every wave still owns 32 rows x 128 columns, the
+// weights' planes are shared by twice as many rows (0.75 x the bytes through the CU's memory pipe per product), the epilogue strips are 8 rows
+// instead of 16 so that two workgroups (sixteen waves) fit a CU: 70 KB of LDS, 114-120 registers.  Every staged launch but the Winograd stage's.
 #include <type_traits>
 
 #include "conv_igemm_tile.h"
@@ -72,20 +75,21 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).h, (B).h, ACC, 0, 0, 0);        \
     } while (0)
 
-template <bool GENERAL, bool RAW, int TERMS, bool STG>
+template <bool GENERAL, bool RAW, int TERMS, bool STG, int WV = 4>
 __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const float *__restrict__ x, const float *__restrict__ w,
                                                float *__restrict__ y, const float *__restrict__ scale,
                                                const float *__restrict__ shift, const float *__restrict__ add,
                                                const float *__restrict__ mask, const float *__restrict__ add2, const int tile) {
-    constexpr int BK = 32, BM = 128, BN = 128, NSN = BN / 16;
+    constexpr int BK = 32, BM = 32 * WV, BN = 128, NSN = BN / 16;    // WV waves of 32 rows x 128 columns each (4: 128 x 128; 8: 256 x 128)
+    constexpr int SR = WV == 8 ? 8 : 16;                   // rows of a wave's epilogue strip (eight waves: half a 16-row block at a time)
     constexpr bool HALF = TERMS == 2;                      // two fp16 terms / three MFMAs instead of three bf16 terms / six
     constexpr int REC = 32 * TERMS, EB = 2 * TERMS;        // bytes of a pre-split record (16 values) / per weight element
     constexpr int BPL = BN * 16;                           // floats' worth of one 16-bit plane: rows x 64 bytes
     constexpr int BSTEP = TERMS * BPL;                     // one buffer: B planes h, m, l (TERMS 3) or hi, lo (TERMS 2)
-    constexpr int NBI = TERMS * BN / 16, IB = NBI / 4;     // direct-to-LDS instructions (16 rows x 64 bytes each) per step / per wave
+    constexpr int NBI = TERMS * BN / 16, IB = NBI / WV;    // direct-to-LDS instructions (16 rows x 64 bytes each) per step / per wave
     constexpr int LDT = BN + 4;
-    constexpr int LDSF = 2 * BSTEP > 4 * 16 * LDT ? 2 * BSTEP : 4 * 16 * LDT;   // two staging buffers; the epilogue's four strips
-    static_assert(NBI % 4 == 0 && (TERMS == 2 || TERMS == 3), "tile shape");
+    constexpr int LDSF = 2 * BSTEP > WV * SR * LDT ? 2 * BSTEP : WV * SR * LDT;   // two staging buffers; the epilogue's strips, one per wave
+    static_assert(NBI % WV == 0 && (WV == 4 || WV == 8) && (TERMS == 2 || TERMS == 3), "tile shape");
     __shared__ float lds[LDSF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,7 +122,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     int a_n[2] = {-1, -1}, a_rem[2] = {0, 0};              // TERMS 2: the rows' images (absolute) and pixels; -1: a row past M
     // STG: the wave's 32 rows x 32 values of a K-step are STAGED -- row-coalesced direct-to-LDS loads into a 4 KB strip of the wave's own
     // (conv_wgrad_geom.h: Mf16AGeom), read back in the operand layout.  A lane fills rows 8 j + (lane >> 3), j = 0 .. 3.
-    __shared__ __attribute__((aligned(16))) char a_stage[STG ? 4 * Mf16AGeom::WAVE_BYTES : 16];
+    __shared__ __attribute__((aligned(16))) char a_stage[STG ? WV * Mf16AGeom::WAVE_BYTES : 16];
     __shared__ int4 row_tab[STG ? BM : 1];                 // per tile row: (byte offset of its pixel at tap (0, 0), tap mask, image, pixel)
     unsigned s_mask[4] = {0u, 0u, 0u, 0u};
     int s_base[4] = {0, 0, 0, 0};
@@ -360,7 +364,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     // no workgroup barrier after the K loop.  Accumulator element e of lane l is row 4 * (l >> 4) + e, column l & 15 of its
     // 16 x 16 tile; out of the strip a lane takes float4s: BN / 4 consecutive lanes one whole row segment, so out, add and mask all
     // move as 16-byte accesses (conv_igemm_tile.h: same arithmetic, same macros).
-    float *T = lds + wave * (16 * LDT);
+    float *T = lds + wave * (SR * LDT);
     // (requesting these factors BEFORE the K loop, to have their latency covered, costs 8 % of the family's time -- 29.8 -> 32.3 ms per
     // training step, tools/dbg/ab_lib.sh -- they stay here)
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
@@ -376,15 +380,18 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
     const int64_t m_last = (int64_t)m0 + BM - 1 < M ? (int64_t)m0 + BM - 1 : M - 1;
     const bool rn_span = (int)(m0 / HoWo) != (int)(m_last / HoWo);           // the tile's rows lie in more than one image (scalar)
 #pragma unroll
-    for (int sm = 0; sm < 2; ++sm) {
+    for (int smh = 0; smh < 2 * (16 / SR); ++smh) {
+        const int sm = smh / (16 / SR), hp = smh % (16 / SR);   // the 16-row block and which SR rows of it go through the strip now
+        if (SR == 16 || (lg >> 1) == hp) {
 #pragma unroll
-        for (int sn = 0; sn < NSN; ++sn)
+            for (int sn = 0; sn < NSN; ++sn)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) T[(4 * lg + e) * LDT + 16 * sn + lr] = acc[sm][sn][e];
+                for (int e = 0; e < 4; ++e) T[(4 * lg + e - hp * SR) * LDT + 16 * sn + lr] = acc[sm][sn][e];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is this wave's own: order within the wave is all it needs
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        constexpr int NIT = 16 / RPI, G = 4;                 // 16 rows, RPI per instruction
+        constexpr int NIT = SR / RPI, G = 4;                 // SR rows, RPI per instruction
         if (col_ok) {
 #pragma unroll 1
             for (int g = 0; g < NIT; g += G) {
@@ -392,7 +399,7 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
                 float4 mk_[G], ad_[G];
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    const int64_t mr = (int64_t)m0 + 32 * wave + 16 * sm + lane / CPR + RPI * (g + i);
+                    const int64_t mr = (int64_t)m0 + 32 * wave + 16 * sm + hp * SR + lane / CPR + RPI * (g + i);
                     const int64_t m = mr < M ? mr : M - 1;
                     RN_EPI_ADDR(GENERAL)
                     off_[i] = off;
@@ -405,10 +412,10 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
                     const int r = lane / CPR + RPI * (g + i);
-                    const int64_t m = (int64_t)m0 + 32 * wave + 16 * sm + r;
+                    const int64_t m = (int64_t)m0 + 32 * wave + 16 * sm + hp * SR + r;
                     if (m < M) {
                         float4 t = *reinterpret_cast<const float4 *>(T + r * LDT + 4 * c4);
-                        if constexpr (HALF) { const float ru = row_unscale[32 * wave + 16 * sm + r]; t.x *= ru; t.y *= ru; t.z *= ru; t.w *= ru; }
+                        if constexpr (HALF) { const float ru = row_unscale[32 * wave + 16 * sm + hp * SR + r]; t.x *= ru; t.y *= ru; t.z *= ru; t.w *= ru; }
                         const int64_t off = off_[i];
                         float mk[4] = {mk_[i].x, mk_[i].y, mk_[i].z, mk_[i].w}, ad[4] = {ad_[i].x, ad_[i].y, ad_[i].z, ad_[i].w};
                         if (!RAW && d.add2_mode == 3) {
@@ -434,13 +441,13 @@ __device__ __forceinline__ void conv_mf16_tile(const rn_conv_desc &d, const floa
 #ifndef RN_MF16H_OCC
 #define RN_MF16H_OCC 3           // workgroups per CU the fp16 form's registers are cut for (120 registers, 33 KB of LDS: 4 fit; A/B below)
 #endif
-template <bool GENERAL, bool RAW, int TERMS, bool STG>
-__global__ __launch_bounds__(256, TERMS == 2 ? RN_MF16H_OCC : 3) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
+template <bool GENERAL, bool RAW, int TERMS, bool STG, int WV = 4>
+__global__ __launch_bounds__(64 * WV, WV == 8 ? 2 : (TERMS == 2 ? RN_MF16H_OCC : 3)) void conv_igemm_mf16_kernel(const rn_conv_desc d, const float *__restrict__ x,
                                                               const float *__restrict__ w, float *__restrict__ y,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const float *__restrict__ add, const float *__restrict__ mask,
                                                               const float *__restrict__ add2) {
-    conv_mf16_tile<GENERAL, RAW, TERMS, STG>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
+    conv_mf16_tile<GENERAL, RAW, TERMS, STG, WV>(d, x, w, y, scale, shift, add, mask, add2, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 template <int TERMS>
@@ -490,6 +497,7 @@ bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, co
                           const float *shift, const float *add, const float *mask, const float *add2, hipStream_t s, int *rc) {
     if (!mf16_ok(d) || (variant != 0 && variant != 4 && variant != 5)) return false;
     const int64_t tiles = mf16_tiles(d);
+    const int64_t M_rows = (int64_t)d->N * d->Ho * d->Wo;
     if (tiles < mf16_min_tiles() || tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles), block(256);
 #define RN_MF16_LAUNCH(G, R, T, S) hipLaunchKernelGGL((conv_igemm_mf16_kernel<G, R, T, S>), grid, block, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
@@ -498,6 +506,21 @@ bool rn_igemm_mf16_launch(int variant, const rn_conv_desc *d, const float *x, co
         // -4 % on the Winograd GEMMs (K = 256) and K >= 1024, +8 % on K = 64 / 128 (profiles/r05_mf16_bounds.txt, 4)
         static const int stg_min_k = [] { const char *e = getenv("RN_MF16_STG_MIN_K"); return e ? atoi(e) : 256; }();
         const bool stg = RN_MF16_STG != 0 && d->kh * d->kw * d->Cin >= stg_min_k;
+        // eight waves on a 256 x 128 tile (staged form only; 70 KB of LDS, two workgroups per CU = sixteen waves instead of twelve): the
+        // weights' planes are fetched once per 256 rows instead of per 128 -- 0.75 x the bytes through the CU's memory pipe per product.
+        // Measured (tools/bench_conv.py, profiles/r05_mf16_bounds.txt, 7): 1x1 1024->256 0.136 -> 0.122 ms, its data gradient 0.129 -> 0.115,
+        // 3x3 256->256 -4 %; the per-position launches of the Winograd stage (big -3 %, small +5 %; in the step 29.13 with them on it against
+        // 29.0 ms without) keep four waves.  RN_MF16_WV8_MIN: fewest 256-row tiles a launch needs (default 1; 0: never).
+        static const int wv8_min = [] { const char *e = getenv("RN_MF16_WV8_MIN"); return e ? atoi(e) : 1; }();
+        const int64_t tiles8 = ((M_rows + 255) / 256) * ((d->Cout + 127) / 128);
+        if (stg && wv8_min > 0 && d->w_batch_stride == 0 && tiles8 >= wv8_min && tiles8 <= 0x7fffffff) {
+            const dim3 grid8((unsigned)tiles8), block8(512);
+#define RN_MF16_LAUNCH8(G, R) hipLaunchKernelGGL((conv_igemm_mf16_kernel<G, R, 2, true, 8>), grid8, block8, 0, s, *d, x, w, y, scale, shift, add, mask, add2)
+            if (variant == 0) RN_MF16_LAUNCH8(false, true);
+            else if (variant == 4) RN_MF16_LAUNCH8(false, false);
+            else RN_MF16_LAUNCH8(true, false);
+#undef RN_MF16_LAUNCH8
+        } else
         if (variant == 0) { if (stg) RN_MF16_LAUNCH(false, true, 2, true); else RN_MF16_LAUNCH(false, true, 2, false); }
         else if (variant == 4) { if (stg) RN_MF16_LAUNCH(false, false, 2, true); else RN_MF16_LAUNCH(false, false, 2, false); }
         else { if (stg) RN_MF16_LAUNCH(true, false, 2, true); else RN_MF16_LAUNCH(true, false, 2, false); }
