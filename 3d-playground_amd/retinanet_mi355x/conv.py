@@ -500,12 +500,16 @@ def wino_conv_group(xs, U, outs=None, scale=None, shift=None, act=ACT_NONE, adds
 
 
 _WINO_Z = {}
-SIDE_HELD = []                                        # operands of side-stream launches (wino_wgrad_group(side=...)) until side_release()
+SIDE_HELD = {}                                        # side stream -> operands of its launches (wino_wgrad_group(side=...)) until side_release()
 
 
-def side_release():
-    """After the allocating stream has waited for the side stream: the held operands may be freed / reused."""
-    SIDE_HELD.clear()
+def side_release(side=None):
+    """After the allocating stream has waited for `side` (None: for every side stream): the operands held for its launches may be
+    freed / reused.  Keyed by stream: two engines in one process release only their own."""
+    if side is None:
+        SIDE_HELD.clear()
+    else:
+        SIDE_HELD.pop(side.cuda_stream, None)
 
 
 def _wino_z_buffer(device, floats):
@@ -589,7 +593,7 @@ def wino_wgrad_group(gs, xs, dw, colsum, flops=0.0, V=None, dU=None, fuse_dgrad_
         # events have not completed are replaced by fresh device allocations -- and the step time bimodal (64 or 90-140 ms from run to
         # run, profiles/r05_wgrad_stream.txt 7).  The tensors are held here instead and released by the caller (side_release) once the
         # stream they were allocated on has waited for the side stream.
-        SIDE_HELD.append((V, dU) + tuple(am))
+        SIDE_HELD.setdefault(side.cuda_stream, []).append((V, dU) + tuple(am))
     return v_dy                                      # (B^T dy B, shapes) for the data gradient that follows, or None when not fused
 
 

@@ -1117,8 +1117,8 @@ class Engine:
             """The main stream waits for the weight gradients queued so far; what they read may then be released."""
             for ws in wss or ():
                 main0.wait_stream(ws)
+                cv.side_release(ws)
             held.clear()
-            cv.side_release()
 
         def aside(fn, tensors):
             """fn() on the weight-gradient stream, after everything queued so far on the current one; `tensors`: what it reads."""

@@ -183,6 +183,12 @@ def test_winograd_planes_are_an_odd_number_of_blocks_apart():
     for T in (1, 255, 256, 257, 511, 512, 513, 4080, 16320, 21896, 22016, 22017, 100000):
         tp = conv.wino_tpad(T)
         assert tp >= T and tp % 256 == 0 and (tp // 256) % 2 == 1 and tp - T < 512, (T, tp)
-    conv.SIDE_HELD.append((None,))
+    class _S:                                                   # (a stream's identity is its handle)
+        def __init__(self, h):
+            self.cuda_stream = h
+    conv.SIDE_HELD.setdefault(1, []).append((None,))
+    conv.SIDE_HELD.setdefault(2, []).append((None,))
+    conv.side_release(_S(1))
+    assert list(conv.SIDE_HELD) == [2]                          # another engine's operands stay held
     conv.side_release()
-    assert conv.SIDE_HELD == []
+    assert conv.SIDE_HELD == {}
