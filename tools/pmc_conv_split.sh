@@ -12,7 +12,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   d=gpurun_out/pmc_split/g$i
   rm -rf "$d"
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$d" -- python3 tools/bench_conv.py --only "$ONLY" --mfma split > gpurun_out/pmc_split_g$i.log 2>&1 || echo "group $i failed"
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$d" -- python3 tools/bench_conv.py --only "$ONLY" --mfma ${RN_PMC_MODE:-split} > gpurun_out/pmc_split_g$i.log 2>&1 || echo "group $i failed"
   i=$((i+1))
 done
 python3 - <<'PY'
